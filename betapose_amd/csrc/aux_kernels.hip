@@ -1,0 +1,476 @@
+// Small HBM-bound kernels around the convolutions (gfx950): layout changes,
+// max-pool, residual add, nearest upsample, PixelShuffle, SE squeeze/excite,
+// YOLO head decode + objectness arg-max, heat-map arg-max, device-side crop and
+// Pillow-exact bicubic resize.  64-wide wavefront reductions via __shfl_down.
+#include "bp_common.h"
+
+namespace bp {
+
+static inline int grid_for(long long n, int block = 256, int cap = 4096) {
+    long long g = (n + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+// ---------------------------------------------------------------- layout
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int C, int HW) {
+    const long long total = (long long)N * C * HW;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        const long long t = e / C;
+        const int p = (int)(t % HW);
+        const int n = (int)(t / HW);
+        out[e] = in[((long long)n * C + c) * HW + p];
+    }
+}
+void launch_nchw_to_nhwc(const float* in, float* out, int N, int C, int H, int W, hipStream_t s) {
+    const long long total = (long long)N * C * H * W;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, out, N, C, H * W);
+}
+
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ in, int in_ld, float* __restrict__ out, int N, int C, int HW) {
+    const long long total = (long long)N * C * HW;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int p = (int)(e % HW);
+        const long long t = e / HW;
+        const int c = (int)(t % C);
+        const int n = (int)(t / C);
+        out[e] = in[((long long)n * HW + p) * in_ld + c];
+    }
+}
+void launch_nhwc_to_nchw(const float* in, int in_ld, float* out, int N, int C, int H, int W, hipStream_t s) {
+    const long long total = (long long)N * C * H * W;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, in_ld, out, N, C, H * W);
+}
+
+// ---------------------------------------------------------------- max-pool 3x3 / stride 2 / pad 1 (NHWC)
+__global__ void maxpool3s2p1_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int H, int W, int C,
+                                    int OH, int OW) {
+    const int C4 = C >> 2;
+    const long long total = (long long)N * OH * OW * C4;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(e % C4);
+        long long t = e / C4;
+        const int ox = (int)(t % OW);
+        t /= OW;
+        const int oy = (int)(t % OH);
+        const int n = (int)(t / OH);
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        for (int dy = 0; dy < 3; ++dy) {
+            const int iy = oy * 2 - 1 + dy;
+            if ((unsigned)iy >= (unsigned)H) continue;
+            for (int dx = 0; dx < 3; ++dx) {
+                const int ix = ox * 2 - 1 + dx;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                const float4 v = *reinterpret_cast<const float4*>(in + (((long long)n * H + iy) * W + ix) * C + c4 * 4);
+                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            }
+        }
+        *reinterpret_cast<float4*>(out + (((long long)n * OH + oy) * OW + ox) * C + c4 * 4) = m;
+    }
+}
+void launch_maxpool3s2p1(const float* in, float* out, int N, int H, int W, int C, int OH, int OW, hipStream_t s) {
+    BP_CHECK(C % 4 == 0, "maxpool: C % 4");
+    const long long total = (long long)N * OH * OW * (C / 4);
+    hipLaunchKernelGGL(maxpool3s2p1_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, out, N, H, W, C, OH, OW);
+}
+
+// ---------------------------------------------------------------- residual add / channel copy / upsample (fallbacks)
+__global__ void add_kernel(const float* __restrict__ a, int a_ld, const float* __restrict__ b, int b_ld,
+                           float* __restrict__ out, int out_ld, long long pixels, int C) {
+    const long long total = pixels * C;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        const long long p = e / C;
+        out[p * out_ld + c] = a[p * a_ld + c] + b[p * b_ld + c];
+    }
+}
+void launch_add(const float* a, int a_ld, const float* b, int b_ld, float* out, int out_ld, long long pixels, int C,
+                hipStream_t s) {
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(pixels * C)), dim3(256), 0, s, a, a_ld, b, b_ld, out, out_ld, pixels, C);
+}
+
+__global__ void copy_channels_kernel(const float* __restrict__ in, int in_ld, float* __restrict__ out, int out_ld,
+                                     long long pixels, int C) {
+    const long long total = pixels * C;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        const long long p = e / C;
+        out[p * out_ld + c] = in[p * in_ld + c];
+    }
+}
+void launch_copy_channels(const float* in, int in_ld, float* out, int out_ld, long long pixels, int C, hipStream_t s) {
+    hipLaunchKernelGGL(copy_channels_kernel, dim3(grid_for(pixels * C)), dim3(256), 0, s, in, in_ld, out, out_ld, pixels, C);
+}
+
+__global__ void upsample2_kernel(const float* __restrict__ in, int in_ld, float* __restrict__ out, int out_ld, int N,
+                                 int H, int W, int C) {
+    const long long total = (long long)N * 2 * H * 2 * W * C;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        long long t = e / C;
+        const int x = (int)(t % (2 * W));
+        t /= 2 * W;
+        const int y = (int)(t % (2 * H));
+        const int n = (int)(t / (2 * H));
+        out[(((long long)n * 2 * H + y) * 2 * W + x) * out_ld + c] = in[(((long long)n * H + (y >> 1)) * W + (x >> 1)) * in_ld + c];
+    }
+}
+void launch_upsample2(const float* in, int in_ld, float* out, int out_ld, int N, int H, int W, int C, hipStream_t s) {
+    hipLaunchKernelGGL(upsample2_kernel, dim3(grid_for((long long)N * 4 * H * W * C)), dim3(256), 0, s, in, in_ld, out,
+                       out_ld, N, H, W, C);
+}
+
+// PixelShuffle(2), NHWC in [N][H][W][C] -> out [N][2H][2W][C/4]; NCHW semantics: out[c, 2h+i, 2w+j] = in[c*4+i*2+j, h, w]
+__global__ void pixel_shuffle2_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int H, int W, int C) {
+    const int Co = C >> 2;
+    const long long total = (long long)N * H * W * C;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int co = (int)(e % Co);
+        long long t = e / Co;
+        const int x = (int)(t % (2 * W));
+        t /= 2 * W;
+        const int y = (int)(t % (2 * H));
+        const int n = (int)(t / (2 * H));
+        const int ci = co * 4 + (y & 1) * 2 + (x & 1);
+        out[e] = in[(((long long)n * H + (y >> 1)) * W + (x >> 1)) * C + ci];
+    }
+}
+void launch_pixel_shuffle2(const float* in, float* out, int N, int H, int W, int C, hipStream_t s) {
+    hipLaunchKernelGGL(pixel_shuffle2_kernel, dim3(grid_for((long long)N * H * W * C)), dim3(256), 0, s, in, out, N, H, W, C);
+}
+
+// ---------------------------------------------------------------- SE: global average pool + FC
+// grid (ceil(C/64), N), block 256 = 4 pixel-groups x 64 channels; lanes run over channels (coalesced NHWC)
+__global__ void avgpool_kernel(const float* __restrict__ in, int in_ld, float* __restrict__ out, int HW, int C) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int g = threadIdx.x >> 6;
+    const int n = blockIdx.y;
+    float s = 0.f;
+    if (c < C)
+        for (int p = g; p < HW; p += 4) s += in[((long long)n * HW + p) * in_ld + c];
+    red[g][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (g == 0 && c < C) {
+        const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        out[(long long)n * C + c] = t / (float)HW;
+    }
+}
+void launch_avgpool(const float* in, int in_ld, float* out, int N, int HW, int C, hipStream_t s) {
+    hipLaunchKernelGGL(avgpool_kernel, dim3((C + 63) / 64, N), dim3(256), 0, s, in, in_ld, out, HW, C);
+}
+
+// one wavefront per output neuron; float4 weight stream (pure HBM-bound GEMV)
+__global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                  const float* __restrict__ bias, float* __restrict__ out, int Cin,
+                                                  int Cout, int act) {
+    const int lane = threadIdx.x & 63;
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n = blockIdx.y;
+    if (o >= Cout) return;
+    const float4* wr = reinterpret_cast<const float4*>(w + (long long)o * Cin);
+    const float4* xr = reinterpret_cast<const float4*>(in + (long long)n * Cin);
+    float s = 0.f;
+    for (int i = lane; i < (Cin >> 2); i += 64) {
+        const float4 a = wr[i], b = xr[i];
+        s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) {
+        s += bias[o];
+        if (act == 2) s = s > 0.f ? s : 0.f;
+        else if (act == 3) s = 1.f / (1.f + __expf(-s));
+        out[(long long)n * Cout + o] = s;
+    }
+}
+void launch_fc(const float* in, const float* w, const float* bias, float* out, int N, int Cin, int Cout, int act,
+               hipStream_t s) {
+    BP_CHECK(Cin % 4 == 0, "fc: Cin % 4");
+    hipLaunchKernelGGL(fc_kernel, dim3((Cout + 3) / 4, N), dim3(256), 0, s, in, w, bias, out, Cin, Cout, act);
+}
+
+// ---------------------------------------------------------------- YOLO head decode (yolo/darknet.py:129-169)
+struct YoloHeads {
+    YoloHead h[4];
+    int n;
+};
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ void yolo_decode_kernel(YoloHeads hs, int N, int reso, int attrs, int rows, float* __restrict__ pred) {
+    const long long total = (long long)N * rows;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int row = (int)(e % rows);
+        const int n = (int)(e / rows);
+        int hi = 0;
+        for (int k = 1; k < hs.n; ++k)
+            if (row >= hs.h[k].row_off) hi = k;
+        const YoloHead& H = hs.h[hi];
+        const int g = H.g;
+        const int r = row - H.row_off;
+        const int a = r / (g * g);
+        const int cell = r - a * g * g;
+        const int gy = cell / g, gx = cell - gy * g;
+        const float stride = (float)(reso / g);
+        const float* t = H.t + ((long long)n * g * g + cell) * (3 * attrs) + a * attrs;
+        float* o = pred + e * attrs;
+        // anchors are divided by the stride then the box is multiplied back (darknet.py:151,165)
+        o[0] = (sigmoidf_(t[0]) + (float)gx) * stride;
+        o[1] = (sigmoidf_(t[1]) + (float)gy) * stride;
+        o[2] = (expf(t[2]) * (H.aw[a] / stride)) * stride;
+        o[3] = (expf(t[3]) * (H.ah[a] / stride)) * stride;
+        for (int k = 4; k < attrs; ++k) o[k] = sigmoidf_(t[k]);
+    }
+}
+void launch_yolo_decode(const YoloHead* heads, int nheads, int N, int reso, int attrs, int rows, float* pred,
+                        hipStream_t s) {
+    BP_CHECK(nheads <= 4, "at most 4 yolo heads");
+    YoloHeads hs;
+    hs.n = nheads;
+    for (int i = 0; i < nheads; ++i) hs.h[i] = heads[i];
+    hipLaunchKernelGGL(yolo_decode_kernel, dim3(grid_for((long long)N * rows)), dim3(256), 0, s, hs, N, reso, attrs, rows, pred);
+}
+
+// write_results with nms=False (yolo/util.py:118-223): per image the arg-max objectness row (first on
+// ties) among rows with obj > conf whose arg-max class is 0.  One block per image.
+__global__ __launch_bounds__(1024) void yolo_select_kernel(const float* __restrict__ pred, int rows, int attrs,
+                                                            float conf, int num_classes, float* __restrict__ sel) {
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    const int n = blockIdx.x;
+    const float* P = pred + (long long)n * rows * attrs;
+    const int ncls = min(num_classes, attrs - 5);
+    float best = -1.f;
+    int bi = 0x7fffffff;
+    for (int r = threadIdx.x; r < rows; r += blockDim.x) {
+        const float* q = P + (long long)r * attrs;
+        const float obj = q[4];
+        if (!(obj > conf)) continue;
+        // class arg-max over the masked row (first max wins); only class 0 rows are kept
+        int cls = 0;
+        float cm = q[5];
+        for (int k = 1; k < ncls; ++k)
+            if (q[5 + k] > cm) { cm = q[5 + k]; cls = k; }
+        if (cls != 0) continue;
+        if (obj > best || (obj == best && r < bi)) { best = obj; bi = r; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_down(best, off, 64);
+        const int oi = __shfl_down(bi, off, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sv[w] = best; si[w] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < (int)(blockDim.x >> 6); ++k)
+            if (sv[k] > best || (sv[k] == best && si[k] < bi)) { best = sv[k]; bi = si[k]; }
+        float* o = sel + (long long)n * 8;
+        if (best < 0.f) {
+            o[0] = __int_as_float(-1);
+            for (int k = 1; k < 8; ++k) o[k] = 0.f;
+        } else {
+            const float* q = P + (long long)bi * attrs;
+            o[0] = __int_as_float(bi);
+            o[1] = q[0] - q[2] / 2;
+            o[2] = q[1] - q[3] / 2;
+            o[3] = q[0] + q[2] / 2;
+            o[4] = q[1] + q[3] / 2;
+            o[5] = q[4];
+            o[6] = q[5];
+            o[7] = 0.f;
+        }
+    }
+}
+void launch_yolo_select(const float* pred, int N, int rows, int attrs, float conf, int num_classes, float* sel,
+                        hipStream_t s) {
+    hipLaunchKernelGGL(yolo_select_kernel, dim3(N), dim3(1024), 0, s, pred, rows, attrs, conf, num_classes, sel);
+}
+
+// ---------------------------------------------------------------- heat-map arg-max (+4 neighbours), eval.py:113-147
+__global__ __launch_bounds__(256) void heatmap_argmax_kernel(const float* __restrict__ hm, int H, int W,
+                                                              float* __restrict__ out) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    const int HW = H * W;
+    const float* P = hm + (long long)blockIdx.x * HW;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < HW; i += 256) {
+        const float v = P[i];
+        if (v > best) { best = v; bi = i; }   // ascending i per thread: first max kept
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_down(best, off, 64);
+        const int oi = __shfl_down(bi, off, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k)
+            if (sv[k] > best || (sv[k] == best && si[k] < bi)) { best = sv[k]; bi = si[k]; }
+        float* o = out + (long long)blockIdx.x * 6;
+        const int x = bi % W, y = bi / W;
+        o[0] = __int_as_float(bi);
+        o[1] = best;
+        const bool inner = x > 0 && x < W - 1 && y > 0 && y < H - 1;
+        o[2] = inner ? P[bi - 1] : 0.f;
+        o[3] = inner ? P[bi + 1] : 0.f;
+        o[4] = inner ? P[bi - W] : 0.f;
+        o[5] = inner ? P[bi + W] : 0.f;
+    }
+}
+void launch_heatmap_argmax(const float* hm, int N, int C, int H, int W, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(heatmap_argmax_kernel, dim3(N * C), dim3(256), 0, s, hm, H, W, out);
+}
+
+// ---------------------------------------------------------------- crop (dataloader.py:794-835, img.py:242-262)
+// One launch: thread 0 of each block recomputes the (cheap) window parameters; every thread then
+// produces output pixels.  The frame is BGR u8; the crop is RGB/255 - (0.406, 0.457, 0.480).
+struct CropWin {
+    float ulx, uly, brx, bry;  // pt1 / pt2 (float, pre-truncation)
+    int x0, y0, cw, ch;        // integer crop origin and size
+    int padl, padt, PW, PH;    // centred zero pad into a PH x PW canvas
+};
+__device__ __forceinline__ CropWin crop_window(float x1, float y1, float x2, float y2, int H, int W, int oh, int ow) {
+    CropWin c;
+    const float ht = y2 - y1, width = x2 - x1;
+    const float rate = width > 100.f ? 0.2f : 0.3f;
+    c.ulx = fmaxf(0.f, x1 - width * rate / 2);
+    c.uly = fmaxf(0.f, y1 - ht * rate / 2);
+    c.brx = fmaxf(fminf((float)(W - 1), x2 + width * rate / 2), c.ulx + 5);
+    c.bry = fmaxf(fminf((float)(H - 1), y2 + ht * rate / 2), c.uly + 5);
+    const int ulx = (int)c.ulx, uly = (int)c.uly, brx = (int)c.brx, bry = (int)c.bry;
+    // cropBox under torch>=1.x division semantics: int*int/int is a true division (fp32)
+    const int bh = bry - uly, bw = brx - ulx;
+    const float wscaled = (float)(bw * oh) / (float)ow;
+    float lenH = (float)bh >= wscaled ? (float)bh : wscaled;   // python max(a, b): first wins ties
+    float lenW = lenH * (float)ow / (float)oh;
+    c.PH = (int)lenH;
+    c.PW = (int)lenW;
+    c.x0 = ulx;
+    c.y0 = uly;
+    c.ch = min(bh, H - uly);
+    c.cw = min(bw, W - ulx);
+    c.ch = max(c.ch, 0);
+    c.cw = max(c.cw, 0);
+    const int dh = max(c.PH - c.ch, 0), dw = max(c.PW - c.cw, 0);
+    c.padt = (dh + 1) >> 1;  // ceil(d/2) before, floor(d/2) after
+    c.padl = (dw + 1) >> 1;
+    // Pad never crops: canvas is at least the crop
+    c.PH = max(c.PH, c.ch);
+    c.PW = max(c.PW, c.cw);
+    return c;
+}
+__device__ __forceinline__ float crop_tap(const uint8_t* __restrict__ frame, int W, const CropWin& c, int y, int x, int ch) {
+    const int cy = y - c.padt, cx = x - c.padl;
+    if ((unsigned)cy >= (unsigned)c.ch || (unsigned)cx >= (unsigned)c.cw) return 0.f;
+    const uint8_t* px = frame + ((long long)(c.y0 + cy) * W + (c.x0 + cx)) * 3;
+    // ch: 0=R,1=G,2=B of the RGB image; frame is BGR
+    const float mean = ch == 0 ? 0.406f : (ch == 1 ? 0.457f : 0.480f);
+    return (float)px[2 - ch] / 255.f - mean;
+}
+__global__ __launch_bounds__(256) void crop_kernel(const uint8_t* __restrict__ frame, int H, int W,
+                                                    const float* __restrict__ sel, int reso,
+                                                    const float* __restrict__ box_override, float* __restrict__ out_nhwc,
+                                                    float* __restrict__ out_nchw, float* __restrict__ pts, int oh, int ow) {
+    const int img = blockIdx.y;
+    frame += (long long)img * H * W * 3;
+    if (sel) sel += img * 8;
+    if (box_override) box_override += img * 4;
+    if (out_nhwc) out_nhwc += (long long)img * oh * ow * 3;
+    if (out_nchw) out_nchw += (long long)img * oh * ow * 3;
+    if (pts) pts += img * 8;
+    float x1, y1, x2, y2;
+    if (box_override) {
+        x1 = box_override[0]; y1 = box_override[1]; x2 = box_override[2]; y2 = box_override[3];
+    } else {
+        // box rescale of DetectionLoader.update (dataloader.py:354-364): stretch back to frame pixels
+        const float wr = (float)W / (float)reso, hr = (float)H / (float)reso;
+        x1 = sel[1] * wr; y1 = sel[2] * hr; x2 = sel[3] * wr; y2 = sel[4] * hr;
+    }
+    const CropWin c = crop_window(x1, y1, x2, y2, H, W, oh, ow);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && pts) {
+        pts[0] = c.ulx; pts[1] = c.uly; pts[2] = c.brx; pts[3] = c.bry;
+        pts[4] = x1; pts[5] = y1; pts[6] = x2; pts[7] = y2;
+    }
+    // bilinear, align_corners=True (torch upsample_bilinear2d): src = dst*(in-1)/(out-1)
+    const float sy = oh > 1 ? (float)(c.PH - 1) / (float)(oh - 1) : 0.f;
+    const float sx = ow > 1 ? (float)(c.PW - 1) / (float)(ow - 1) : 0.f;
+    const int total = oh * ow;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int oy = e / ow, ox = e - oy * ow;
+        const float fy = sy * oy, fx = sx * ox;
+        const int y0 = (int)fy, x0i = (int)fx;
+        const int y1i = y0 + (y0 < c.PH - 1 ? 1 : 0), x1i = x0i + (x0i < c.PW - 1 ? 1 : 0);
+        const float ly = fy - y0, lx = fx - x0i;
+        const float hy = 1.f - ly, hx = 1.f - lx;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const float v = hy * (hx * crop_tap(frame, W, c, y0, x0i, ch) + lx * crop_tap(frame, W, c, y0, x1i, ch)) +
+                            ly * (hx * crop_tap(frame, W, c, y1i, x0i, ch) + lx * crop_tap(frame, W, c, y1i, x1i, ch));
+            if (out_nhwc) out_nhwc[(long long)e * 3 + ch] = v;
+            if (out_nchw) out_nchw[(long long)ch * total + e] = v;
+        }
+    }
+}
+void launch_crop(const uint8_t* frames, int batch, int H, int W, const float* sel, int reso, const float* boxes,
+                 float* out_nhwc, float* out_nchw, float* pts, int oh, int ow, hipStream_t s) {
+    hipLaunchKernelGGL(crop_kernel, dim3(grid_for((long long)oh * ow, 256, 1024), batch), dim3(256), 0, s, frames, H, W,
+                       sel, reso, boxes, out_nhwc, out_nchw, pts, oh, ow);
+}
+
+// ---------------------------------------------------------------- Pillow-exact bicubic resize (u8, two passes)
+// Pillow's ImagingResample for 8-bit: per output pixel a window [xmin, xmin+xsize) with integer
+// coefficients (PRECISION_BITS = 22), accumulate ss = 1<<21 + sum(pix*k), result = clip8(ss >> 22);
+// horizontal pass first, then vertical, each rounding to u8.
+__global__ void resize_h_kernel(const uint8_t* __restrict__ in, int H, int W, uint8_t* __restrict__ tmp, int ow,
+                                const int* __restrict__ hb, const int* __restrict__ hk, int ks) {
+    in += (long long)blockIdx.y * H * W * 3;
+    tmp += (long long)blockIdx.y * H * ow * 3;
+    const int total = H * ow * 3;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int ch = e % 3;
+        const int t = e / 3;
+        const int ox = t % ow, y = t / ow;
+        const int xmin = hb[2 * ox], n = hb[2 * ox + 1];
+        const int* k = hk + ox * ks;
+        int ss = 1 << 21;
+        const uint8_t* row = in + ((long long)y * W + xmin) * 3 + ch;
+        for (int i = 0; i < n; ++i) ss += (int)row[i * 3] * k[i];
+        ss >>= 22;
+        tmp[e] = (uint8_t)(ss < 0 ? 0 : (ss > 255 ? 255 : ss));
+    }
+}
+__global__ void resize_v_kernel(const uint8_t* __restrict__ tmp, int H, int ow, float* __restrict__ out_nhwc,
+                                uint8_t* __restrict__ out_u8, int oh, const int* __restrict__ vb,
+                                const int* __restrict__ vk, int ks, int swap_rb) {
+    tmp += (long long)blockIdx.y * H * ow * 3;
+    if (out_nhwc) out_nhwc += (long long)blockIdx.y * oh * ow * 3;
+    if (out_u8) out_u8 += (long long)blockIdx.y * oh * ow * 3;
+    const int total = oh * ow * 3;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int ch = e % 3;
+        const int t = e / 3;
+        const int ox = t % ow, oy = t / ow;
+        const int ymin = vb[2 * oy], n = vb[2 * oy + 1];
+        const int* k = vk + oy * ks;
+        int ss = 1 << 21;
+        const int src_ch = swap_rb ? 2 - ch : ch;
+        const uint8_t* col = tmp + ((long long)ymin * ow + ox) * 3 + src_ch;
+        for (int i = 0; i < n; ++i) ss += (int)col[(long long)i * ow * 3] * k[i];
+        ss >>= 22;
+        const int v = ss < 0 ? 0 : (ss > 255 ? 255 : ss);
+        if (out_u8) out_u8[e] = (uint8_t)v;
+        if (out_nhwc) out_nhwc[e] = (float)v / 255.f;
+    }
+}
+void launch_resize_bicubic(const uint8_t* in, int batch, int H, int W, uint8_t* tmp, float* out_nhwc, uint8_t* out_u8,
+                           int oh, int ow, const ResizeTables& t, int swap_rb, hipStream_t s) {
+    hipLaunchKernelGGL(resize_h_kernel, dim3(grid_for((long long)H * ow * 3), batch), dim3(256), 0, s, in, H, W, tmp, ow,
+                       t.hb, t.hk, t.ksize_h);
+    hipLaunchKernelGGL(resize_v_kernel, dim3(grid_for((long long)oh * ow * 3), batch), dim3(256), 0, s, tmp, H, ow,
+                       out_nhwc, out_u8, oh, t.vb, t.vk, t.ksize_v, swap_rb);
+}
+
+}  // namespace bp

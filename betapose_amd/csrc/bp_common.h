@@ -1,0 +1,124 @@
+// Shared declarations for the betapose HIP engine (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+
+namespace bp {
+
+struct Error : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+#define BP_HIP(expr)                                                                      \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess)                                                             \
+            throw ::bp::Error(std::string(#expr) + ": " + hipGetErrorString(_e) + " @" +  \
+                              __FILE__ + ":" + std::to_string(__LINE__));                 \
+    } while (0)
+
+#define BP_CHECK(cond, msg)                                                               \
+    do {                                                                                  \
+        if (!(cond)) throw ::bp::Error(std::string(msg) + " (" #cond ") @" + __FILE__ +   \
+                                       ":" + std::to_string(__LINE__));                   \
+    } while (0)
+
+enum Act : int { ACT_LINEAR = 0, ACT_LEAKY = 1, ACT_RELU = 2 };
+
+// where the epilogue puts element (m = (b,oy,ox), n = out channel)
+enum StoreMode : int {
+    ST_NHWC = 0,     // out[m*ld + n]
+    ST_UP2 = 1,      // nearest x2: the 4 pixels (2oy+dy, 2ox+dx) of a [2OH x 2OW] NHWC map
+    ST_PIXSHUF = 2,  // PixelShuffle(2) with filters pre-permuted to n' = (i*2+j)*(Cout/4)+c
+    ST_NCHW = 3      // out[(b*Cout + n)*OH*OW + oy*OW + ox]
+};
+
+// One fused convolution: implicit GEMM  D[m,n] = sum_k A[m,k] W[n,k],  k = (ky,kx,ci),
+// NHWC activations, filters packed [CoutPad][Kpad] (BN folded), epilogue
+//   v = acc + bias[n];  res_after_act ? (act(v) + r) : act(v + r),  r = res[m,n]*scale[b,n]
+struct ConvParams {
+    const float* in;
+    int in_ld;
+    int N, H, W, Cin;
+    const float* w;
+    int Kpad;   // multiple of 32
+    int Ktrue;  // ksize*ksize*Cin
+    const float* bias;
+    float* out;
+    int out_ld;
+    int OH, OW, Cout;
+    int ksize, stride, pad;
+    int act;
+    const float* res;
+    int res_ld;
+    const float* res_scale;  // [N][Cout] or null
+    int res_after_act;
+    int store_mode;
+    int M;                 // N*OH*OW
+    int nchunks;           // Kpad/32
+    int splits;            // split-K factor (>=1)
+    int chunks_per_split;
+    float* partial;        // [splits][M][CoutPad] when splits > 1
+    int CoutPad;
+};
+
+// tile configuration ids for launch_conv
+enum ConvTile : int { TILE_64x64 = 0, TILE_128x64 = 1, TILE_32x64 = 2, TILE_64x32 = 3 };
+
+void launch_conv(const ConvParams& p, int tile, hipStream_t s);
+int conv_tile_bm(int tile);
+int conv_tile_bn(int tile);
+
+// ---- auxiliary kernels (aux_kernels.hip) ----
+void launch_nchw_to_nhwc(const float* in, float* out, int N, int C, int H, int W, hipStream_t s);
+void launch_nhwc_to_nchw(const float* in, int in_ld, float* out, int N, int C, int H, int W, hipStream_t s);
+void launch_maxpool3s2p1(const float* in, float* out, int N, int H, int W, int C, int OH, int OW, hipStream_t s);
+void launch_add(const float* a, int a_ld, const float* b, int b_ld, float* out, int out_ld,
+                long long pixels, int C, hipStream_t s);
+void launch_upsample2(const float* in, int in_ld, float* out, int out_ld, int N, int H, int W, int C, hipStream_t s);
+void launch_copy_channels(const float* in, int in_ld, float* out, int out_ld, long long pixels, int C, hipStream_t s);
+void launch_pixel_shuffle2(const float* in, float* out, int N, int H, int W, int C, hipStream_t s);
+void launch_avgpool(const float* in, int in_ld, float* out, int N, int HW, int C, hipStream_t s);
+// out[b][o] = act(bias[o] + sum_i w[o][i]*in[b][i]);  act: 2 relu, 3 sigmoid
+void launch_fc(const float* in, const float* w, const float* bias, float* out, int N, int Cin, int Cout,
+               int act, hipStream_t s);
+
+struct YoloHead {
+    const float* t;  // NHWC [N][g][g][nA*attrs], ld = nA*attrs
+    int g;
+    float aw[3], ah[3];  // anchors in pixels
+    int row_off;         // first row of this head in the [rows][attrs] output
+};
+// pred: [N][rows][attrs] (DetectionLayer row order); sel: [N][8] floats
+// (idx as int bits, x1,y1,x2,y2,obj,cls_conf,cls_idx); idx = -1 when nothing > conf
+void launch_yolo_decode(const YoloHead* heads, int nheads, int N, int reso, int attrs, int rows,
+                        float* pred, hipStream_t s);
+void launch_yolo_select(const float* pred, int N, int rows, int attrs, float conf, int num_classes,
+                        float* sel, hipStream_t s);
+// hm NCHW [N][C][H*W] -> out [N][C][6] = (idx as int bits, max, left, right, up, down)
+void launch_heatmap_argmax(const float* hm, int N, int C, int H, int W, float* out, hipStream_t s);
+
+// crop stage (dataloader.py:794-835 + img.py:242-262) on device.
+//  frames: BGR u8 [batch][H][W][3]; sel: [batch][8] select records (box in YOLO-input pixels) or boxes [batch][4];
+//  out_nhwc [oh][ow][3] (engine input) and/or out_nchw [3][oh][ow]; pts: (ul.x, ul.y, br.x, br.y)
+void launch_crop(const uint8_t* frames, int batch, int H, int W, const float* sel, int reso, const float* boxes,
+                 float* out_nhwc, float* out_nchw, float* pts, int oh, int ow, hipStream_t s);
+
+// Pillow-exact antialiased bicubic resize of a u8 HWC frame (two passes, 22-bit fixed point);
+// coefficient tables are built on the host (engine.cpp).
+struct ResizeTables {
+    const int* hb;      // [ow][2] (xmin, xsize)
+    const int* hk;      // [ow][ksize_h] fixed-point coeffs
+    int ksize_h;
+    const int* vb;      // [oh][2]
+    const int* vk;      // [oh][ksize_v]
+    int ksize_v;
+};
+// in: u8 [H][W][3] (BGR when swap_rb) -> tmp u8 [H][ow][3] -> out f32 NHWC [oh][ow][3] RGB /255
+void launch_resize_bicubic(const uint8_t* in, int batch, int H, int W, uint8_t* tmp, float* out_nhwc, uint8_t* out_u8,
+                           int oh, int ow, const ResizeTables& t, int swap_rb, hipStream_t s);
+
+}  // namespace bp

@@ -1,0 +1,436 @@
+// extern "C" boundary of libbetapose_hip.so -- see include/betapose_hip.h.
+#include "../../include/betapose_hip.h"
+
+#include <cstring>
+#include <fstream>
+#include <memory>
+#include <sstream>
+#include <vector>
+
+#include "engine.h"
+
+namespace bp {
+int solve_pnp(const double* P, const double* U, int n, const double* K, double* R, double* t);
+}
+
+static thread_local std::string g_err;
+
+#define BP_TRY try {
+#define BP_CATCH                                   \
+    }                                              \
+    catch (const std::exception& e) {              \
+        g_err = e.what();                          \
+        return -1;                                 \
+    }                                              \
+    catch (...) {                                  \
+        g_err = "unknown error";                   \
+        return -1;                                 \
+    }
+
+struct bp_yolo {
+    std::unique_ptr<bp::YoloNet> net;
+    int device;
+};
+struct bp_kpd {
+    std::unique_ptr<bp::KpdNet> net;
+    int device;
+};
+
+struct bp_pipeline {
+    bp_yolo* y;
+    bp_kpd* k;
+    int H, W, batch;
+    float conf;
+    int num_classes;
+    bp::Arena arena;
+    uint8_t* frames = nullptr;
+    uint8_t* tmp = nullptr;
+    float* results = nullptr;    // [batch][316]
+    float* sel = nullptr;        // [batch][8]
+    float* pts = nullptr;        // [batch][8]
+    float* kp = nullptr;         // [batch][50][6]
+    float* hm = nullptr;
+    float* fixed_box = nullptr;  // [batch][4] or null
+    bool use_fixed = false;
+    int *hb = nullptr, *hk = nullptr, *vb = nullptr, *vk = nullptr;
+    int ksh = 0, ksv = 0;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipStream_t cap_stream = nullptr;
+    ~bp_pipeline() {
+        if (exec) (void)hipGraphExecDestroy(exec);
+        if (graph) (void)hipGraphDestroy(graph);
+        if (cap_stream) (void)hipStreamDestroy(cap_stream);
+    }
+};
+
+static std::string read_text(const char* path) {
+    std::ifstream f(path);
+    if (!f) throw bp::Error(std::string("cannot open ") + path);
+    std::stringstream ss;
+    ss << f.rdbuf();
+    return ss.str();
+}
+
+extern "C" {
+
+const char* bp_last_error(void) { return g_err.c_str(); }
+int bp_version(void) { return 100; }
+
+int bp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+int bp_device_name(int device, char* out, int cap) {
+    BP_TRY
+    hipDeviceProp_t p;
+    BP_HIP(hipGetDeviceProperties(&p, device));
+    std::snprintf(out, cap, "%s (%s)", p.name, p.gcnArchName);
+    return 0;
+    BP_CATCH
+}
+
+// ------------------------------------------------------------------ detector
+int bp_yolo_create_from_memory(const char* cfg_text, const float* stream, size_t n_floats, int reso, int max_batch,
+                               int device, bp_yolo** out) {
+    BP_TRY
+    BP_CHECK(cfg_text && stream && out, "null argument");
+    BP_HIP(hipSetDevice(device));
+    std::unique_ptr<bp_yolo> y(new bp_yolo);
+    y->device = device;
+    y->net.reset(new bp::YoloNet(cfg_text, stream, n_floats, reso, max_batch));
+    *out = y.release();
+    return 0;
+    BP_CATCH
+}
+
+int bp_yolo_create(const char* cfg_path, const char* weights_path, int reso, int max_batch, int device, bp_yolo** out) {
+    BP_TRY
+    const std::string cfg = read_text(cfg_path);
+    std::ifstream f(weights_path, std::ios::binary);
+    if (!f) throw bp::Error(std::string("cannot open ") + weights_path);
+    f.seekg(0, std::ios::end);
+    const size_t bytes = (size_t)f.tellg();
+    f.seekg(0);
+    BP_CHECK(bytes >= 16, "truncated .weights header");
+    int32_t hdr[3];
+    f.read(reinterpret_cast<char*>(hdr), 12);
+    // parser.c:1161-1174: major*10+minor >= 2 -> 64-bit "seen", else 32-bit
+    const size_t off = (hdr[0] * 10 + hdr[1] >= 2) ? 20 : 16;
+    BP_CHECK(bytes >= off && (bytes - off) % 4 == 0, "malformed .weights payload");
+    std::vector<float> stream((bytes - off) / 4);
+    f.seekg(off);
+    f.read(reinterpret_cast<char*>(stream.data()), bytes - off);
+    return bp_yolo_create_from_memory(cfg.c_str(), stream.data(), stream.size(), reso, max_batch, device, out);
+    BP_CATCH
+}
+
+void bp_yolo_destroy(bp_yolo* y) { delete y; }
+int bp_yolo_rows(const bp_yolo* y) { return y ? y->net->rows() : -1; }
+int bp_yolo_attrs(const bp_yolo* y) { return y ? y->net->attrs() : -1; }
+
+int bp_yolo_forward(bp_yolo* y, const float* d_img, int batch, float* d_pred, void* stream) {
+    BP_TRY
+    BP_CHECK(y && d_img && d_pred, "null argument");
+    y->net->forward(d_img, false, batch, d_pred, 0.f, 0, nullptr, (hipStream_t)stream);
+    return 0;
+    BP_CATCH
+}
+int bp_yolo_forward_select(bp_yolo* y, const float* d_img, int batch, float conf, int num_classes, float* d_pred,
+                           float* d_sel, void* stream) {
+    BP_TRY
+    BP_CHECK(y && d_img && d_sel, "null argument");
+    y->net->forward(d_img, false, batch, d_pred, conf, num_classes, d_sel, (hipStream_t)stream);
+    return 0;
+    BP_CATCH
+}
+
+static int tap_info(const bp::Net& n, int i, char* name, int cap, int* C, int* H, int* W) {
+    if (i < 0 || i >= n.tap_count()) { g_err = "tap index"; return -1; }
+    if (name && cap > 0) std::snprintf(name, cap, "%s", n.tap_name(i));
+    n.tap_shape(i, C, H, W);
+    return 0;
+}
+int bp_yolo_tap_count(const bp_yolo* y) { return y->net->tap_count(); }
+int bp_yolo_tap_info(const bp_yolo* y, int i, char* name, int cap, int* C, int* H, int* W) {
+    return tap_info(*y->net, i, name, cap, C, H, W);
+}
+int bp_yolo_tap_copy(bp_yolo* y, int i, int batch, float* d_out, void* stream) {
+    BP_TRY
+    y->net->tap_copy(i, batch, d_out, (hipStream_t)stream);
+    return 0;
+    BP_CATCH
+}
+
+// ------------------------------------------------------------------ key-point detector
+int bp_kpd_create(const float* stream, size_t n_floats, int n_classes, int max_batch, int device, bp_kpd** out) {
+    BP_TRY
+    BP_CHECK(stream && out, "null argument");
+    BP_HIP(hipSetDevice(device));
+    std::unique_ptr<bp_kpd> k(new bp_kpd);
+    k->device = device;
+    k->net.reset(new bp::KpdNet(stream, n_floats, n_classes, max_batch));
+    *out = k.release();
+    return 0;
+    BP_CATCH
+}
+void bp_kpd_destroy(bp_kpd* k) { delete k; }
+int bp_kpd_forward(bp_kpd* k, const float* d_inps, int batch, float* d_hm, void* stream) {
+    BP_TRY
+    BP_CHECK(k && d_inps && d_hm, "null argument");
+    k->net->forward(d_inps, false, batch, d_hm, nullptr, (hipStream_t)stream);
+    return 0;
+    BP_CATCH
+}
+int bp_kpd_forward_argmax(bp_kpd* k, const float* d_inps, int batch, float* d_hm, float* d_kp, void* stream) {
+    BP_TRY
+    BP_CHECK(k && d_inps && d_kp, "null argument");
+    k->net->forward(d_inps, false, batch, d_hm, d_kp, (hipStream_t)stream);
+    return 0;
+    BP_CATCH
+}
+int bp_kpd_tap_count(const bp_kpd* k) { return k->net->tap_count(); }
+int bp_kpd_tap_info(const bp_kpd* k, int i, char* name, int cap, int* C, int* H, int* W) {
+    return tap_info(*k->net, i, name, cap, C, H, W);
+}
+int bp_kpd_tap_copy(bp_kpd* k, int i, int batch, float* d_out, void* stream) {
+    BP_TRY
+    k->net->tap_copy(i, batch, d_out, (hipStream_t)stream);
+    return 0;
+    BP_CATCH
+}
+
+int bp_yolo_set_policy(bp_yolo* y, int t, int mc, int ft) {
+    y->net->set_splitk_policy(t, mc);
+    y->net->set_force_tile(ft);
+    return 0;
+}
+int bp_kpd_set_policy(bp_kpd* k, int t, int mc, int ft) {
+    k->net->set_splitk_policy(t, mc);
+    k->net->set_force_tile(ft);
+    return 0;
+}
+static int op_stats(const bp::Net& n, double* flops, double* bytes, int cap) {
+    const auto& ops = n.ops();
+    for (int i = 0; i < (int)ops.size() && i < cap; ++i) {
+        if (flops) flops[i] = ops[i].flops;
+        if (bytes) bytes[i] = ops[i].bytes;
+    }
+    return (int)ops.size();
+}
+int bp_yolo_op_stats(const bp_yolo* y, double* flops, double* bytes, int cap) { return op_stats(*y->net, flops, bytes, cap); }
+int bp_kpd_op_stats(const bp_kpd* k, double* flops, double* bytes, int cap) { return op_stats(*k->net, flops, bytes, cap); }
+size_t bp_yolo_device_bytes(const bp_yolo* y) { return y->net->device_bytes(); }
+size_t bp_kpd_device_bytes(const bp_kpd* k) { return k->net->device_bytes(); }
+
+// ------------------------------------------------------------------ stand-alone stages
+int bp_crop(const uint8_t* d_frames, int batch, int H, int W, const float* d_sel, int reso, const float* d_boxes,
+            float* d_out_nchw, float* d_out_nhwc, float* d_pts, int oh, int ow, void* stream) {
+    BP_TRY
+    BP_CHECK(d_frames && (d_sel || d_boxes) && (d_out_nchw || d_out_nhwc), "null argument");
+    bp::launch_crop(d_frames, batch, H, W, d_sel, reso, d_boxes, d_out_nhwc, d_out_nchw, d_pts, oh, ow, (hipStream_t)stream);
+    BP_HIP(hipGetLastError());
+    return 0;
+    BP_CATCH
+}
+
+int bp_resize_bicubic(const uint8_t* d_in, int batch, int H, int W, int oh, int ow, int swap_rb, uint8_t* d_out_u8,
+                      float* d_out_nhwc, void* stream) {
+    BP_TRY
+    BP_CHECK(d_in && (d_out_u8 || d_out_nhwc), "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const bp::ResizePlan ph = bp::make_bicubic_plan(W, ow), pv = bp::make_bicubic_plan(H, oh);
+    bp::Arena a;
+    int* hb = (int*)a.alloc_bytes(ph.bounds.size() * 4);
+    int* hk = (int*)a.alloc_bytes(ph.coeffs.size() * 4);
+    int* vb = (int*)a.alloc_bytes(pv.bounds.size() * 4);
+    int* vk = (int*)a.alloc_bytes(pv.coeffs.size() * 4);
+    uint8_t* tmp = (uint8_t*)a.alloc_bytes((size_t)batch * H * ow * 3);
+    BP_HIP(hipMemcpyAsync(hb, ph.bounds.data(), ph.bounds.size() * 4, hipMemcpyHostToDevice, s));
+    BP_HIP(hipMemcpyAsync(hk, ph.coeffs.data(), ph.coeffs.size() * 4, hipMemcpyHostToDevice, s));
+    BP_HIP(hipMemcpyAsync(vb, pv.bounds.data(), pv.bounds.size() * 4, hipMemcpyHostToDevice, s));
+    BP_HIP(hipMemcpyAsync(vk, pv.coeffs.data(), pv.coeffs.size() * 4, hipMemcpyHostToDevice, s));
+    bp::ResizeTables t{hb, hk, ph.ksize, vb, vk, pv.ksize};
+    bp::launch_resize_bicubic(d_in, batch, H, W, tmp, d_out_nhwc, d_out_u8, oh, ow, t, swap_rb, s);
+    BP_HIP(hipGetLastError());
+    BP_HIP(hipStreamSynchronize(s));   // tables live in a local arena
+    return 0;
+    BP_CATCH
+}
+
+int bp_conv2d(const float* d_in, int N, int H, int W, int Cin, const float* h_w, const float* h_bias, int Cout, int k,
+              int stride, int pad, int act, int store_mode, const float* d_res, int res_after_act, int tile, int splits,
+              float* d_out, int iters, float* ms_per_iter, void* stream) {
+    BP_TRY
+    BP_CHECK(d_in && h_w && d_out, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    struct OneConv : bp::Net {
+        OneConv() : Net(1) {}
+        using Net::add_conv;
+        using Net::finalize;
+        using Net::ops_;
+        using Net::partial_;
+        using Net::partial_floats_;
+        using Net::arena_;
+    } net;
+    const int OH = (H + 2 * pad - k) / stride + 1, OW = (W + 2 * pad - k) / stride + 1;
+    bp::Tensor in; in.p = const_cast<float*>(d_in); in.H = H; in.W = W; in.C = Cin; in.ld = Cin;
+    bp::Tensor out; out.p = d_out; out.H = OH; out.W = OW; out.C = Cout;
+    out.ld = store_mode == bp::ST_PIXSHUF ? Cout / 4 : Cout;
+    bp::Tensor res; res.p = const_cast<float*>(d_res); res.ld = Cout; res.C = Cout; res.H = OH; res.W = OW;
+    bp::ConvWeights cw; cw.w = h_w; cw.bias = h_bias;
+    net.add_conv("conv", in, out, cw, Cout, k, stride, pad, act, store_mode, d_res ? &res : nullptr, nullptr,
+                 res_after_act, 1e-5f, OH, OW);
+    bp::ConvParams p = net.ops_[0].conv;
+    p.N = N; p.M = N * OH * OW;
+    int t = tile;
+    if (t < 0) t = ((p.M + 127) / 128) * (p.CoutPad / 64) >= 1024 ? bp::TILE_128x64 : bp::TILE_64x64;
+    int sp = splits;
+    if (sp <= 0) {
+        const int bm = bp::conv_tile_bm(t);
+        const long long blocks = (long long)((p.M + bm - 1) / bm) * (p.CoutPad / 64);
+        sp = 1;
+        while (blocks * sp < 512 && p.nchunks / (sp + 1) >= 4 && sp < 64) ++sp;
+    }
+    int per = (p.nchunks + sp - 1) / sp;
+    sp = (p.nchunks + per - 1) / per;
+    p.splits = sp; p.chunks_per_split = per;
+    if (sp > 1) p.partial = net.arena_.alloc((size_t)sp * p.M * p.CoutPad);
+    bp::launch_conv(p, t, s);
+    BP_HIP(hipStreamSynchronize(s));
+    if (iters > 0 && ms_per_iter) {
+        hipEvent_t e0, e1;
+        BP_HIP(hipEventCreate(&e0));
+        BP_HIP(hipEventCreate(&e1));
+        BP_HIP(hipEventRecord(e0, s));
+        for (int i = 0; i < iters; ++i) bp::launch_conv(p, t, s);
+        BP_HIP(hipEventRecord(e1, s));
+        BP_HIP(hipEventSynchronize(e1));
+        float ms = 0;
+        BP_HIP(hipEventElapsedTime(&ms, e0, e1));
+        *ms_per_iter = ms / iters;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    }
+    return 0;
+    BP_CATCH
+}
+
+// ------------------------------------------------------------------ fused per-frame pipeline
+static void pipeline_enqueue(bp_pipeline* p, hipStream_t s) {
+    bp::YoloNet& yn = *p->y->net;
+    bp::KpdNet& kn = *p->k->net;
+    const int reso = yn.reso();
+    bp::ResizeTables t{p->hb, p->hk, p->ksh, p->vb, p->vk, p->ksv};
+    // a1: Pillow-exact bicubic stretch to reso x reso, BGR -> RGB, /255, straight into the detector's NHWC input
+    bp::launch_resize_bicubic(p->frames, p->batch, p->H, p->W, p->tmp, yn.input_nhwc(), nullptr, reso, reso, t, 1, s);
+    // a3-a5: detector + decode + arg-max objectness
+    yn.forward(yn.input_nhwc(), true, p->batch, nullptr, p->conf, p->num_classes, p->sel, s);
+    // a6-a7: box rescale + crop window + bilinear crop into the KPD's NHWC input
+    bp::launch_crop(p->frames, p->batch, p->H, p->W, p->use_fixed ? nullptr : p->sel, reso,
+                    p->use_fixed ? p->fixed_box : nullptr, kn.input_nhwc(), nullptr, p->pts, kn.in_h(), kn.in_w(), s);
+    // a8-a9: KPD + heat-map arg-max
+    kn.forward(kn.input_nhwc(), true, p->batch, p->hm, p->kp, s);
+    // gather the three small records into one result row per frame
+    for (int b = 0; b < p->batch; ++b) {
+        float* r = p->results + (size_t)b * BP_RESULT_FLOATS;
+        BP_HIP(hipMemcpyAsync(r, p->sel + b * 8, 8 * sizeof(float), hipMemcpyDeviceToDevice, s));
+        BP_HIP(hipMemcpyAsync(r + 8, p->pts + b * 8, 8 * sizeof(float), hipMemcpyDeviceToDevice, s));
+        BP_HIP(hipMemcpyAsync(r + 16, p->kp + (size_t)b * 300, 300 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+}
+
+int bp_pipeline_create(bp_yolo* y, bp_kpd* k, int frame_h, int frame_w, int batch, float conf, int num_classes,
+                       bp_pipeline** out) {
+    BP_TRY
+    BP_CHECK(y && k && out, "null argument");
+    BP_CHECK(batch >= 1 && batch <= y->net->max_batch() && batch <= k->net->max_batch(), "pipeline batch > engine max_batch");
+    BP_CHECK(k->net->out_c() == 50, "pipeline expects 50 key points");
+    BP_HIP(hipSetDevice(y->device));
+    std::unique_ptr<bp_pipeline> p(new bp_pipeline);
+    p->y = y; p->k = k; p->H = frame_h; p->W = frame_w; p->batch = batch; p->conf = conf; p->num_classes = num_classes;
+    const int reso = y->net->reso();
+    p->frames = (uint8_t*)p->arena.alloc_bytes((size_t)batch * frame_h * frame_w * 3);
+    p->tmp = (uint8_t*)p->arena.alloc_bytes((size_t)batch * frame_h * reso * 3);
+    p->results = p->arena.alloc((size_t)batch * BP_RESULT_FLOATS);
+    p->sel = p->arena.alloc((size_t)batch * 8);
+    p->pts = p->arena.alloc((size_t)batch * 8);
+    p->kp = p->arena.alloc((size_t)batch * 300);
+    p->hm = p->arena.alloc((size_t)batch * 50 * k->net->out_h() * k->net->out_w());
+    p->fixed_box = p->arena.alloc((size_t)batch * 4);
+    const bp::ResizePlan ph = bp::make_bicubic_plan(frame_w, reso), pv = bp::make_bicubic_plan(frame_h, reso);
+    p->ksh = ph.ksize; p->ksv = pv.ksize;
+    p->hb = (int*)p->arena.alloc_bytes(ph.bounds.size() * 4);
+    p->hk = (int*)p->arena.alloc_bytes(ph.coeffs.size() * 4);
+    p->vb = (int*)p->arena.alloc_bytes(pv.bounds.size() * 4);
+    p->vk = (int*)p->arena.alloc_bytes(pv.coeffs.size() * 4);
+    BP_HIP(hipMemcpy(p->hb, ph.bounds.data(), ph.bounds.size() * 4, hipMemcpyHostToDevice));
+    BP_HIP(hipMemcpy(p->hk, ph.coeffs.data(), ph.coeffs.size() * 4, hipMemcpyHostToDevice));
+    BP_HIP(hipMemcpy(p->vb, pv.bounds.data(), pv.bounds.size() * 4, hipMemcpyHostToDevice));
+    BP_HIP(hipMemcpy(p->vk, pv.coeffs.data(), pv.coeffs.size() * 4, hipMemcpyHostToDevice));
+    BP_HIP(hipMemset(p->results, 0, (size_t)batch * BP_RESULT_FLOATS * sizeof(float)));
+    *out = p.release();
+    return 0;
+    BP_CATCH
+}
+void bp_pipeline_destroy(bp_pipeline* p) { delete p; }
+uint8_t* bp_pipeline_frames(bp_pipeline* p) { return p->frames; }
+float* bp_pipeline_results(bp_pipeline* p) { return p->results; }
+float* bp_pipeline_heatmaps(bp_pipeline* p) { return p->hm; }
+
+static void drop_graph(bp_pipeline* p) {
+    if (p->exec) { (void)hipGraphExecDestroy(p->exec); p->exec = nullptr; }
+    if (p->graph) { (void)hipGraphDestroy(p->graph); p->graph = nullptr; }
+}
+
+int bp_pipeline_set_fixed_box(bp_pipeline* p, const float* box) {
+    BP_TRY
+    drop_graph(p);
+    p->use_fixed = box != nullptr;
+    if (box) {
+        std::vector<float> h((size_t)p->batch * 4);
+        for (int b = 0; b < p->batch; ++b) std::memcpy(&h[b * 4], box, 4 * sizeof(float));
+        BP_HIP(hipMemcpy(p->fixed_box, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    return 0;
+    BP_CATCH
+}
+
+int bp_pipeline_run(bp_pipeline* p, int use_graph, void* stream) {
+    BP_TRY
+    hipStream_t s = (hipStream_t)stream;
+    if (!use_graph) {
+        pipeline_enqueue(p, s);
+        return 0;
+    }
+    if (!p->exec) {
+        if (!p->cap_stream) BP_HIP(hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking));
+        BP_HIP(hipStreamBeginCapture(p->cap_stream, hipStreamCaptureModeThreadLocal));
+        try {
+            pipeline_enqueue(p, p->cap_stream);
+        } catch (...) {
+            hipGraph_t g = nullptr;
+            (void)hipStreamEndCapture(p->cap_stream, &g);
+            if (g) (void)hipGraphDestroy(g);
+            throw;
+        }
+        BP_HIP(hipStreamEndCapture(p->cap_stream, &p->graph));
+        BP_HIP(hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0));
+    }
+    BP_HIP(hipGraphLaunch(p->exec, s));
+    return 0;
+    BP_CATCH
+}
+
+// ------------------------------------------------------------------ host post-processing
+int bp_solve_pnp(const double* pts3d, const double* pts2d, int n, const double* K, double* R, double* t) {
+    BP_TRY
+    BP_CHECK(pts3d && pts2d && K && R && t, "null argument");
+    const int rc = bp::solve_pnp(pts3d, pts2d, n, K, R, t);
+    if (rc != 0) throw bp::Error("solve_pnp failed (need >= 6 non-degenerate points)");
+    return 0;
+    BP_CATCH
+}
+
+}  // extern "C"

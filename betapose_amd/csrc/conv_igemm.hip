@@ -1,0 +1,284 @@
+// Fused convolution for gfx950: implicit-GEMM (no im2col buffer) on the fp32 MFMA
+// pipe (v_mfma_f32_32x32x2_f32: exact fp32 FMA chain, 256 FLOP/clk/CU), NHWC
+// activations, BN-folded filters packed [Cout][ky][kx][ci], epilogue fusing bias,
+// LeakyReLU/ReLU, residual add (YOLO shortcut / ResNet bottleneck), SE channel
+// scale, nearest-x2 upsample, PixelShuffle(2) and NCHW stores.
+//
+// Replaces, for the hot path, cudnnConvolutionForward + normalize/scale_bias/
+// add_bias/activate/shortcut/upsample kernels of the reference's Darknet CUDA
+// backend (train_YOLO/src/convolutional_kernels.cu:121-383, blas_kernels.cu) and
+// the torch.nn Conv2d/BatchNorm2d/LeakyReLU/ReLU/PixelShuffle modules of
+// yolo/darknet.py:240-259 and KPD/src/models/layers/{SE_Resnet,DUC}.py.
+//
+// Block = 256 threads = 4 waves (one per SIMD), 2x2 over a (64*TM)x(64*TN) output
+// tile; K is walked in chunks of 32 (one filter tap slice: ci0..ci0+31 are
+// contiguous in NHWC), global -> registers -> LDS double buffer, one barrier per
+// chunk.  LDS rows are padded to 36 floats so the ds_read_b128 fragment reads are
+// bank-conflict free (row stride 144 B covers all 64 banks over 16 rows).
+// Fragment trick: lane l reads A[row=l&31][4h..4h+3] (h=l>>5) as one b128 and feeds
+// component j to MFMA j, so MFMA j contracts k = {j, 4+j} of the 8-wide sub-chunk;
+// B uses the same k mapping, and the sum over k is order-free.
+#include "bp_common.h"
+
+namespace bp {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static constexpr int BK = 32;
+static constexpr int LDS_LD = 36;
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == ACT_LEAKY) return v > 0.f ? v : 0.1f * v;
+    if (act == ACT_RELU) return v > 0.f ? v : 0.f;
+    return v;
+}
+
+// v = raw accumulator for output element (m, n)
+__device__ __forceinline__ void epilogue_store(const ConvParams& p, int m, int n, float v) {
+    v += p.bias[n];
+    int b = 0, pix = m;
+    const int hw = p.OH * p.OW;
+    const bool need_pix = p.store_mode != ST_NHWC || p.res_scale != nullptr;
+    if (need_pix) {
+        b = m / hw;
+        pix = m - b * hw;
+    }
+    float r = 0.f;
+    if (p.res) {
+        r = p.res[(long long)m * p.res_ld + n];
+        if (p.res_scale) r *= p.res_scale[b * p.Cout + n];
+    }
+    if (!p.res_after_act) v += r;
+    v = apply_act(v, p.act);
+    if (p.res_after_act) v += r;
+    switch (p.store_mode) {
+        case ST_NHWC:
+            p.out[(long long)m * p.out_ld + n] = v;
+            break;
+        case ST_UP2: {
+            const int oy = pix / p.OW, ox = pix - oy * p.OW;
+            const int W2 = 2 * p.OW;
+            float* o = p.out + ((long long)(b * 2 * p.OH + 2 * oy) * W2 + 2 * ox) * p.out_ld + n;
+            o[0] = v;
+            o[p.out_ld] = v;
+            o[(long long)W2 * p.out_ld] = v;
+            o[(long long)(W2 + 1) * p.out_ld] = v;
+        } break;
+        case ST_PIXSHUF: {
+            const int oy = pix / p.OW, ox = pix - oy * p.OW;
+            const int cq = p.Cout >> 2;
+            const int ij = n / cq, c = n - ij * cq;
+            const int y = 2 * oy + (ij >> 1), x = 2 * ox + (ij & 1);
+            p.out[((long long)(b * 2 * p.OH + y) * (2 * p.OW) + x) * p.out_ld + c] = v;
+        } break;
+        case ST_NCHW:
+            p.out[((long long)b * p.Cout + n) * hw + pix] = v;
+            break;
+    }
+}
+
+// one float4 (4 consecutive k) of im2col row for chunk c; zero outside the image / past Ktrue
+template <bool VEC>
+__device__ __forceinline__ float4 load_a_row(const ConvParams& p, int c, int cpt, int c4, int bh, int iy0, int ix0) {
+    float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (VEC) {
+        const int tap = c / cpt;
+        const int ci0 = (c - tap * cpt) << 5;
+        const int ky = tap / p.ksize;
+        const int kx = tap - ky * p.ksize;
+        const int iy = iy0 + ky, ix = ix0 + kx;
+        if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+            out = *reinterpret_cast<const float4*>(p.in + ((long long)(bh + iy) * p.W + ix) * p.in_ld + ci0 + c4 * 4);
+    } else {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int k = c * BK + c4 * 4 + e;
+            float x = 0.f;
+            if (k < p.Ktrue) {
+                const int tap = k / p.Cin;
+                const int ci = k - tap * p.Cin;
+                const int ky = tap / p.ksize;
+                const int kx = tap - ky * p.ksize;
+                const int iy = iy0 + ky, ix = ix0 + kx;
+                if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                    x = p.in[((long long)(bh + iy) * p.W + ix) * p.in_ld + ci];
+            }
+            v[e] = x;
+        }
+        out = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    return out;
+}
+
+template <int TM, int TN, bool VEC>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int RA = BM / 32, RB = BN / 32;
+    __shared__ __attribute__((aligned(16))) float As[2][BM * LDS_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDS_LD];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n_tiles_n = p.CoutPad / BN;
+    const int tile_n = blockIdx.x % n_tiles_n;
+    const int tile_m = blockIdx.x / n_tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int split = blockIdx.z;
+    const int c_begin = split * p.chunks_per_split;
+    const int c_end = min(p.nchunks, c_begin + p.chunks_per_split);
+
+    const int lr = tid >> 3, c4 = tid & 7;
+    const int hw = p.OH * p.OW;
+
+    int a_bh[RA], a_iy0[RA], a_ix0[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        const int m = m0 + lr + 32 * i;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int b = mm / hw;
+        const int rem = mm - b * hw;
+        const int oy = rem / p.OW;
+        const int ox = rem - oy * p.OW;
+        a_bh[i] = b * p.H;
+        a_iy0[i] = ok ? oy * p.stride - p.pad : -(1 << 20);
+        a_ix0[i] = ox * p.stride - p.pad;
+    }
+
+    float4 ra[RA], rb[RB];
+    const int cpt = VEC ? (p.Cin >> 5) : 1;  // chunks per filter tap
+
+#define BP_LOAD_CHUNK(c_)                                                                          \
+    {                                                                                              \
+        const int cc = (c_);                                                                       \
+        _Pragma("unroll") for (int i = 0; i < RA; ++i)                                             \
+            ra[i] = load_a_row<VEC>(p, cc, cpt, c4, a_bh[i], a_iy0[i], a_ix0[i]);                  \
+        _Pragma("unroll") for (int i = 0; i < RB; ++i)                                             \
+            rb[i] = *reinterpret_cast<const float4*>(p.w + (long long)(n0 + lr + 32 * i) * p.Kpad + \
+                                                     cc * BK + c4 * 4);                            \
+    }
+#define BP_STORE_LDS(buf_)                                                                         \
+    {                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < RA; ++i)                                             \
+            *reinterpret_cast<float4*>(&As[buf_][(lr + 32 * i) * LDS_LD + c4 * 4]) = ra[i];        \
+        _Pragma("unroll") for (int i = 0; i < RB; ++i)                                             \
+            *reinterpret_cast<float4*>(&Bs[buf_][(lr + 32 * i) * LDS_LD + c4 * 4]) = rb[i];        \
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int frag_off = (lane & 31) * LDS_LD + (lane >> 5) * 4;
+    const int a_off = wm * (BM / 2) * LDS_LD + frag_off;
+    const int b_off = wn * (BN / 2) * LDS_LD + frag_off;
+
+    if (c_begin < c_end) {
+        BP_LOAD_CHUNK(c_begin);
+        BP_STORE_LDS(0);
+    }
+    __syncthreads();
+#define BP_COMPUTE(buf_)                                                                              \
+    {                                                                                                 \
+        const float* Ab = &As[buf_][a_off];                                                           \
+        const float* Bb = &Bs[buf_][b_off];                                                           \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                            \
+            float4 a[TM], b[TN];                                                                      \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) a[i] =                                     \
+                *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_LD + ks * 8);                      \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) b[j] =                                     \
+                *reinterpret_cast<const float4*>(Bb + j * 32 * LDS_LD + ks * 8);                      \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) { \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0); \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0); \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0); \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0); \
+            }                                                                                         \
+        }                                                                                             \
+    }
+    // steady state: prefetch chunk c+1 into registers, contract chunk c from LDS, park c+1 in the
+    // other LDS buffer, one barrier.  The last chunk is peeled so the loop body has no conditionals
+    // (a conditional prefetch makes hipcc park the prefetch registers in scratch behind a vmcnt(0)).
+    int buf = 0;
+    for (int c = c_begin; c + 1 < c_end; ++c) {
+        BP_LOAD_CHUNK(c + 1);
+        BP_COMPUTE(buf);
+        BP_STORE_LDS(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    if (c_begin < c_end) BP_COMPUTE(buf);
+
+    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int m = m0 + row;
+                if (m < p.M) {
+                    if (p.splits > 1) {
+                        p.partial[((long long)split * p.M + m) * p.CoutPad + n] = acc[i][j][r];
+                    } else if (n < p.Cout) {
+                        epilogue_store(p, m, n, acc[i][j][r]);
+                    }
+                }
+            }
+        }
+}
+
+// sum split-K partial slabs and run the fused epilogue
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p) {
+    const long long total = (long long)p.M * p.Cout;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(e / p.Cout);
+        const int n = (int)(e - (long long)m * p.Cout);
+        float v = 0.f;
+        for (int s = 0; s < p.splits; ++s) v += p.partial[((long long)s * p.M + m) * p.CoutPad + n];
+        epilogue_store(p, m, n, v);
+    }
+}
+
+int conv_tile_bm(int tile) { return tile == TILE_128x64 ? 128 : 64; }
+int conv_tile_bn(int tile) { return 64; }
+
+template <int TM, int TN>
+static void launch_t(const ConvParams& p, hipStream_t s) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    dim3 grid(((p.M + BM - 1) / BM) * (p.CoutPad / BN), 1, p.splits);
+    const bool vec = (p.Cin % 32 == 0) && (p.in_ld % 4 == 0);
+    if (vec)
+        hipLaunchKernelGGL((conv_igemm_kernel<TM, TN, true>), grid, dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL((conv_igemm_kernel<TM, TN, false>), grid, dim3(256), 0, s, p);
+}
+
+void launch_conv(const ConvParams& p, int tile, hipStream_t s) {
+    BP_CHECK(p.CoutPad % 64 == 0, "CoutPad must be a multiple of 64");
+    BP_CHECK(p.Kpad % BK == 0 && p.nchunks == p.Kpad / BK, "Kpad");
+    BP_CHECK(p.splits >= 1 && (p.splits == 1 || p.partial != nullptr), "split-K workspace");
+    switch (tile) {
+        case TILE_128x64: launch_t<2, 1>(p, s); break;
+        default: launch_t<1, 1>(p, s); break;
+    }
+    BP_HIP(hipGetLastError());
+    if (p.splits > 1) {
+        const long long total = (long long)p.M * p.Cout;
+        int blocks = (int)std::min<long long>((total + 255) / 256, 2048);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p);
+        BP_HIP(hipGetLastError());
+    }
+}
+
+}  // namespace bp

@@ -1,0 +1,618 @@
+// Plan construction + execution for the detector (YOLOv3 from a Darknet cfg) and the
+// key-point detector (FastPose = SE-ResNet-101 + DUC).  Host side only: parsing,
+// BN folding, filter packing, buffer layout, launch order.  All arithmetic of the hot
+// path runs in the HIP kernels of conv_igemm.hip / aux_kernels.hip.
+#include "engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <sstream>
+
+namespace bp {
+
+// ------------------------------------------------------------------ arena
+Arena::~Arena() {
+    for (void* p : ptrs_) (void)hipFree(p);
+}
+void* Arena::alloc_bytes(size_t bytes) {
+    void* p = nullptr;
+    bytes = (bytes + 255) & ~size_t(255);
+    BP_HIP(hipMalloc(&p, bytes));
+    ptrs_.push_back(p);
+    total_ += bytes;
+    return p;
+}
+float* Arena::alloc(size_t n) { return static_cast<float*>(alloc_bytes(n * sizeof(float))); }
+
+// ------------------------------------------------------------------ Net
+Tensor Net::new_tensor(int H, int W, int C) {
+    Tensor t;
+    t.H = H; t.W = W; t.C = C; t.ld = C;
+    t.p = arena_.alloc((size_t)max_batch_ * H * W * C);
+    return t;
+}
+
+static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+static void choose_launch(const Op& op, int batch, int force_tile, int sk_target, int sk_min_chunks, int* tile,
+                          int* splits, int* cps) {
+    const ConvParams& c = op.conv;
+    const long long M = (long long)batch * c.OH * c.OW;
+    const int nt = c.CoutPad / 64;
+    int t = TILE_64x64;
+    if (((M + 127) / 128) * nt >= 1024) t = TILE_128x64;
+    if (force_tile >= 0) t = force_tile;
+    const int bm = conv_tile_bm(t);
+    const long long blocks = ((M + bm - 1) / bm) * nt;
+    int s = 1;
+    while (blocks * s < sk_target && c.nchunks / (s + 1) >= sk_min_chunks && s < 64) ++s;
+    int per = (c.nchunks + s - 1) / s;
+    s = (c.nchunks + per - 1) / per;
+    *tile = t; *splits = s; *cps = per;
+}
+
+int Net::add_conv(const std::string& name, const Tensor& in, const Tensor& out_view, const ConvWeights& cw, int Cout,
+                  int k, int stride, int pad, int act, int store_mode, const Tensor* res, const float* res_scale,
+                  int res_after_act, float bn_eps, int OH, int OW) {
+    const int Cin = in.C;
+    const int K = k * k * Cin;
+    const int Kpad = round_up(K, 32);
+    const int CoutPad = round_up(Cout, 64);
+    std::vector<float> W((size_t)CoutPad * Kpad, 0.f), B(CoutPad, 0.f);
+    for (int co = 0; co < Cout; ++co) {
+        double s = 1.0, b = 0.0;
+        if (cw.bn_scale) {
+            s = (double)cw.bn_scale[co] / std::sqrt((double)cw.bn_var[co] + (double)bn_eps);
+            b = (double)cw.bn_bias[co] - (double)cw.bn_mean[co] * s;
+        } else if (cw.bias) {
+            b = cw.bias[co];
+        }
+        int n = co;
+        if (store_mode == ST_PIXSHUF) n = (co & 3) * (Cout / 4) + (co >> 2);
+        B[n] = (float)b;
+        float* dst = W.data() + (size_t)n * Kpad;
+        const float* src = cw.w + (size_t)co * Cin * k * k;
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int t = 0; t < k * k; ++t) dst[(size_t)t * Cin + ci] = (float)((double)src[(size_t)ci * k * k + t] * s);
+    }
+    float* dW = arena_.alloc(W.size());
+    float* dB = arena_.alloc(B.size());
+    BP_HIP(hipMemcpy(dW, W.data(), W.size() * sizeof(float), hipMemcpyHostToDevice));
+    BP_HIP(hipMemcpy(dB, B.data(), B.size() * sizeof(float), hipMemcpyHostToDevice));
+
+    Op op;
+    op.type = OP_CONV;
+    op.name = name;
+    ConvParams& c = op.conv;
+    c.in = in.p; c.in_ld = in.ld; c.N = 1; c.H = in.H; c.W = in.W; c.Cin = Cin;
+    c.w = dW; c.Kpad = Kpad; c.Ktrue = K; c.bias = dB;
+    c.out = out_view.p; c.out_ld = out_view.ld; c.OH = OH; c.OW = OW; c.Cout = Cout;
+    c.ksize = k; c.stride = stride; c.pad = pad; c.act = act;
+    c.res = res ? res->p : nullptr; c.res_ld = res ? res->ld : 0; c.res_scale = res_scale;
+    c.res_after_act = res_after_act; c.store_mode = store_mode;
+    c.M = OH * OW; c.nchunks = Kpad / 32; c.splits = 1; c.chunks_per_split = c.nchunks; c.partial = nullptr;
+    c.CoutPad = CoutPad;
+    op.flops = 2.0 * OH * OW * (double)Cout * K;
+    op.bytes = 4.0 * ((double)Cout * K + (double)in.H * in.W * Cin + (double)OH * OW * Cout + (res ? (double)OH * OW * Cout : 0.0));
+    ops_.push_back(op);
+    return (int)ops_.size() - 1;
+}
+
+void Net::finalize() {
+    size_t need = 0;
+    for (const Op& op : ops_) {
+        if (op.type != OP_CONV) continue;
+        for (int b = 1; b <= max_batch_; ++b) {
+            int tile, splits, cps;
+            choose_launch(op, b, force_tile_, sk_target_, sk_min_chunks_, &tile, &splits, &cps);
+            // worst case over policies that may be set later: allow up to 64 splits at batch 1
+            if (splits > 1) need = std::max(need, (size_t)splits * b * op.conv.OH * op.conv.OW * op.conv.CoutPad);
+        }
+    }
+    need = std::max(need, (size_t)4 << 20);   // headroom so a later policy change can still split small layers
+    partial_floats_ = need;
+    partial_ = need ? arena_.alloc(need) : nullptr;
+}
+
+void Net::run_ops(int batch, hipStream_t s) {
+    BP_CHECK(batch >= 1 && batch <= max_batch_, "batch out of range");
+    for (const Op& op : ops_) {
+        switch (op.type) {
+            case OP_CONV: {
+                ConvParams p = op.conv;
+                p.N = batch;
+                p.M = batch * p.OH * p.OW;
+                int tile, splits, cps;
+                choose_launch(op, batch, force_tile_, sk_target_, sk_min_chunks_, &tile, &splits, &cps);
+                while (splits > 1 && (size_t)splits * p.M * p.CoutPad > partial_floats_) {
+                    --splits;
+                    cps = (p.nchunks + splits - 1) / splits;
+                    splits = (p.nchunks + cps - 1) / cps;
+                }
+                p.splits = splits; p.chunks_per_split = cps; p.partial = partial_;
+                launch_conv(p, tile, s);
+            } break;
+            case OP_MAXPOOL:
+                launch_maxpool3s2p1(op.a, op.out, batch, op.H, op.W, op.C, op.OH, op.OW, s);
+                break;
+            case OP_ADD:
+                launch_add(op.a, op.a_ld, op.b, op.b_ld, op.out, op.out_ld, (long long)batch * op.H * op.W, op.C, s);
+                break;
+            case OP_UPSAMPLE:
+                launch_upsample2(op.a, op.a_ld, op.out, op.out_ld, batch, op.H, op.W, op.C, s);
+                break;
+            case OP_COPYCH:
+                launch_copy_channels(op.a, op.a_ld, op.out, op.out_ld, (long long)batch * op.H * op.W, op.C, s);
+                break;
+            case OP_PIXSHUF:
+                launch_pixel_shuffle2(op.a, op.out, batch, op.H, op.W, op.C, s);
+                break;
+            case OP_AVGPOOL:
+                launch_avgpool(op.a, op.a_ld, op.out, batch, op.H * op.W, op.C, s);
+                break;
+            case OP_FC:
+                launch_fc(op.a, op.w, op.bias, op.out, batch, op.Cin, op.Cout, op.act, s);
+                break;
+            default:
+                throw Error("unknown op");
+        }
+    }
+    BP_HIP(hipGetLastError());
+}
+
+void Net::tap_copy(int i, int batch, float* d_out_nchw, hipStream_t s) const {
+    BP_CHECK(i >= 0 && i < (int)taps_.size(), "tap index");
+    const Tensor& t = taps_[i];
+    launch_nhwc_to_nchw(t.p, t.ld, d_out_nchw, batch, t.C, t.H, t.W, s);
+    BP_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ cfg parsing (yolo/darknet.py:45-74 semantics)
+struct CfgBlock {
+    std::string type;
+    std::map<std::string, std::string> kv;
+    bool has(const std::string& k) const { return kv.count(k) != 0; }
+    int geti(const std::string& k, int def) const {
+        auto it = kv.find(k);
+        return it == kv.end() ? def : std::atoi(it->second.c_str());
+    }
+    std::string gets(const std::string& k) const {
+        auto it = kv.find(k);
+        return it == kv.end() ? std::string() : it->second;
+    }
+};
+static std::string trim(const std::string& s) {
+    size_t a = s.find_first_not_of(" \t\r\n"), b = s.find_last_not_of(" \t\r\n");
+    return a == std::string::npos ? std::string() : s.substr(a, b - a + 1);
+}
+static std::vector<CfgBlock> parse_cfg(const std::string& text) {
+    std::vector<CfgBlock> out;
+    std::istringstream is(text);
+    std::string line;
+    while (std::getline(is, line)) {
+        line = trim(line);
+        if (line.empty() || line[0] == '#') continue;
+        if (line[0] == '[') {
+            CfgBlock b;
+            b.type = trim(line.substr(1, line.find(']') - 1));
+            out.push_back(b);
+        } else {
+            size_t eq = line.find('=');
+            BP_CHECK(eq != std::string::npos && !out.empty(), "malformed cfg line");
+            out.back().kv[trim(line.substr(0, eq))] = trim(line.substr(eq + 1));
+        }
+    }
+    // a leading [net]/[network] block (Darknet-C cfgs) carries no layer
+    if (!out.empty() && (out[0].type == "net" || out[0].type == "network")) out.erase(out.begin());
+    return out;
+}
+static std::vector<int> parse_ints(const std::string& s) {
+    std::vector<int> v;
+    std::istringstream is(s);
+    std::string tok;
+    while (std::getline(is, tok, ',')) {
+        tok = trim(tok);
+        if (!tok.empty()) v.push_back(std::atoi(tok.c_str()));
+    }
+    return v;
+}
+
+// ------------------------------------------------------------------ YoloNet
+YoloNet::YoloNet(const std::string& cfg_text, const float* stream, size_t n_floats, int reso, int max_batch)
+    : Net(max_batch), reso_(reso) {
+    BP_CHECK(reso % 32 == 0 && reso > 32, "reso must be a multiple of 32 and > 32 (dataloader.py:298-299)");
+    const std::vector<CfgBlock> L = parse_cfg(cfg_text);
+    const int n = (int)L.size();
+    BP_CHECK(n > 0, "empty cfg");
+    struct Shape { int C, H, W; };
+    std::vector<Shape> shp(n);
+    std::vector<int> alias(n);            // root layer whose tensor this layer's output is
+    std::vector<std::vector<int>> members(n);
+    // ---- shapes + aliases
+    for (int i = 0; i < n; ++i) {
+        const CfgBlock& b = L[i];
+        Shape prev = i ? shp[i - 1] : Shape{3, reso, reso};
+        alias[i] = i;
+        if (b.type == "convolutional") {
+            const int k = b.geti("size", 1), st = b.geti("stride", 1);
+            const int pad = b.has("pad") && !b.gets("pad").empty() ? (k - 1) / 2 : 0;   // string truthiness, darknet.py:250
+            shp[i] = {b.geti("filters", 1), (prev.H + 2 * pad - k) / st + 1, (prev.W + 2 * pad - k) / st + 1};
+        } else if (b.type == "shortcut") {
+            BP_CHECK(i >= 1, "shortcut at layer 0");
+            shp[i] = prev;
+        } else if (b.type == "upsample") {
+            BP_CHECK(b.geti("stride", 2) == 2, "only x2 upsample");
+            shp[i] = {prev.C, prev.H * 2, prev.W * 2};
+        } else if (b.type == "route") {
+            std::vector<int> ls = parse_ints(b.gets("layers"));
+            BP_CHECK(ls.size() == 1 || ls.size() == 2, "route with 1 or 2 layers");
+            const int a = i + ls[0];                       // always relative (darknet.py:347,352)
+            BP_CHECK(a >= 0 && a < i, "route source");
+            if (ls.size() == 1) {
+                shp[i] = shp[a];
+                alias[i] = alias[a];
+            } else {
+                const int c = ls[1];                       // absolute (darknet.py:351)
+                BP_CHECK(c >= 0 && c < i, "route source");
+                BP_CHECK(shp[a].H == shp[c].H && shp[a].W == shp[c].W, "route spatial mismatch");
+                shp[i] = {shp[a].C + shp[c].C, shp[a].H, shp[a].W};
+                members[i] = {alias[a], alias[c]};
+            }
+        } else if (b.type == "yolo") {
+            shp[i] = prev;
+            alias[i] = alias[i - 1];                        // outputs[i] = outputs[i-1]
+        } else {
+            throw Error("unsupported cfg block [" + b.type + "]");
+        }
+    }
+    // ---- consumers per root
+    std::vector<std::vector<int>> cons(n);
+    auto use = [&](int src, int by) { cons[alias[src]].push_back(by); };
+    for (int i = 0; i < n; ++i) {
+        const CfgBlock& b = L[i];
+        if (b.type == "convolutional" || b.type == "upsample") { if (i) use(i - 1, i); }
+        else if (b.type == "shortcut") { use(i - 1, i); use(i + b.geti("from", -3), i); }
+        else if (b.type == "route") { for (int m : members[i]) cons[m].push_back(i); if (members[i].empty()) {} }
+        else if (b.type == "yolo") use(i - 1, i);
+    }
+    // ---- fusion: conv -> (shortcut | upsample) when the conv output has no other reader
+    std::vector<int> fused_into(n, -1), fused_from(n, -1);
+    for (int i = 0; i + 1 < n; ++i) {
+        if (L[i].type != "convolutional") continue;
+        const std::string& nt = L[i + 1].type;
+        if (cons[i].size() == 1 && cons[i][0] == i + 1) {
+            if (nt == "shortcut" && alias[i + 1 + L[i + 1].geti("from", -3)] != i) { fused_into[i] = i + 1; fused_from[i + 1] = i; }
+            else if (nt == "upsample") { fused_into[i] = i + 1; fused_from[i + 1] = i; }
+        }
+    }
+    // ---- tensors: concat buffers first, members become views
+    std::vector<Tensor> T(n);
+    std::vector<char> has(n, 0);
+    in_nhwc_ = arena_.alloc((size_t)max_batch * reso * reso * 3);
+    std::vector<std::pair<int, int>> copy_members;   // (route, member) pairs that need a copy op
+    for (int i = 0; i < n; ++i) {
+        if (members[i].empty()) continue;
+        T[i] = new_tensor(shp[i].H, shp[i].W, shp[i].C);
+        has[i] = 1;
+        int off = 0;
+        for (int m : members[i]) {
+            const bool producible = L[m].type == "convolutional" || L[m].type == "shortcut" || L[m].type == "upsample";
+            if (!has[m] && producible && members[m].empty()) {
+                T[m] = T[i];
+                T[m].p = T[i].p + off;
+                T[m].C = shp[m].C;
+                has[m] = 1;
+            } else {
+                copy_members.push_back({i, m});
+            }
+            off += shp[m].C;
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        if (has[i] || alias[i] != i) continue;
+        if (L[i].type == "convolutional" && fused_into[i] >= 0) continue;   // lives only inside the fused epilogue
+        T[i] = new_tensor(shp[i].H, shp[i].W, shp[i].C);
+        has[i] = 1;
+    }
+    auto tensor_of = [&](int i) -> const Tensor& {
+        const int r = alias[i];
+        BP_CHECK(has[r], "internal: tensor not materialised");
+        return T[r];
+    };
+    // ---- weights cursor
+    size_t cur = 0;
+    auto take = [&](size_t cnt) {
+        BP_CHECK(cur + cnt <= n_floats, "weights stream too short for this cfg");
+        const float* p = stream + cur;
+        cur += cnt;
+        return p;
+    };
+    // ---- emit
+    Tensor input;
+    input.p = in_nhwc_; input.H = reso; input.W = reso; input.C = 3; input.ld = 3;
+    int row_off = 0;
+    for (int i = 0; i < n; ++i) {
+        const CfgBlock& b = L[i];
+        if (b.type == "convolutional") {
+            const Tensor& in = i ? tensor_of(i - 1) : input;
+            const int k = b.geti("size", 1), st = b.geti("stride", 1);
+            const int pad = b.has("pad") && !b.gets("pad").empty() ? (k - 1) / 2 : 0;
+            const int Cout = shp[i].C, Cin = in.C;
+            ConvWeights cw;
+            if (b.geti("batch_normalize", 0) > 0) {
+                cw.bn_bias = take(Cout); cw.bn_scale = take(Cout); cw.bn_mean = take(Cout); cw.bn_var = take(Cout);
+            } else {
+                cw.bias = take(Cout);
+            }
+            cw.w = take((size_t)Cout * Cin * k * k);
+            const std::string a = b.gets("activation");
+            const int act = a == "leaky" ? ACT_LEAKY : (a == "relu" ? ACT_RELU : ACT_LINEAR);
+            BP_CHECK(a == "leaky" || a == "linear" || a == "relu", "unsupported activation " + a);
+            int mode = ST_NHWC;
+            const Tensor* res = nullptr;
+            int dst = i;
+            if (fused_into[i] >= 0) {
+                dst = fused_into[i];
+                if (L[dst].type == "shortcut") res = &tensor_of(dst + L[dst].geti("from", -3));
+                else mode = ST_UP2;
+            }
+            add_conv("conv" + std::to_string(i), in, T[alias[dst]], cw, Cout, k, st, pad, act, mode, res, nullptr,
+                     /*res_after_act=*/1, 1e-5f, shp[i].H, shp[i].W);
+            add_tap(std::to_string(dst), T[alias[dst]]);
+        } else if (b.type == "shortcut") {
+            if (fused_from[i] >= 0) continue;
+            const Tensor& a = tensor_of(i - 1);
+            const Tensor& c = tensor_of(i + b.geti("from", -3));
+            Op op; op.type = OP_ADD; op.name = "shortcut" + std::to_string(i);
+            op.a = a.p; op.a_ld = a.ld; op.b = c.p; op.b_ld = c.ld; op.out = T[i].p; op.out_ld = T[i].ld;
+            op.H = shp[i].H; op.W = shp[i].W; op.C = shp[i].C;
+            ops_.push_back(op);
+            add_tap(std::to_string(i), T[i]);
+        } else if (b.type == "upsample") {
+            if (fused_from[i] >= 0) continue;
+            const Tensor& a = tensor_of(i - 1);
+            Op op; op.type = OP_UPSAMPLE; op.name = "upsample" + std::to_string(i);
+            op.a = a.p; op.a_ld = a.ld; op.out = T[i].p; op.out_ld = T[i].ld;
+            op.H = a.H; op.W = a.W; op.C = a.C;
+            ops_.push_back(op);
+            add_tap(std::to_string(i), T[i]);
+        } else if (b.type == "route") {
+            if (members[i].empty()) continue;
+            int off = 0;
+            for (int m : members[i]) {
+                for (auto& cm : copy_members)
+                    if (cm.first == i && cm.second == m) {
+                        Op op; op.type = OP_COPYCH; op.name = "concat" + std::to_string(i);
+                        op.a = T[m].p; op.a_ld = T[m].ld; op.out = T[i].p + off; op.out_ld = T[i].ld;
+                        op.H = shp[i].H; op.W = shp[i].W; op.C = shp[m].C;
+                        ops_.push_back(op);
+                    }
+                off += shp[m].C;
+            }
+            add_tap(std::to_string(i), T[i]);
+        } else if (b.type == "yolo") {
+            const Tensor& t = tensor_of(i - 1);
+            std::vector<int> mask = parse_ints(b.gets("mask"));
+            std::vector<int> an = parse_ints(b.gets("anchors"));
+            const int classes = b.geti("classes", 1);
+            BP_CHECK(mask.size() == 3, "yolo layer needs 3 masked anchors");
+            BP_CHECK(t.C == 3 * (5 + classes) && t.ld == t.C, "yolo head channel count");
+            BP_CHECK(attrs_ == 0 || attrs_ == 5 + classes, "heads disagree on classes");
+            attrs_ = 5 + classes;
+            YoloHead h{};
+            h.t = t.p; h.g = t.H; h.row_off = row_off;
+            for (int a = 0; a < 3; ++a) {
+                BP_CHECK(2 * mask[a] + 1 < (int)an.size(), "anchor mask");
+                h.aw[a] = (float)an[2 * mask[a]];
+                h.ah[a] = (float)an[2 * mask[a] + 1];
+            }
+            heads_.push_back(h);
+            row_off += 3 * t.H * t.W;
+        }
+    }
+    BP_CHECK(!heads_.empty() && heads_.size() <= 4, "cfg must have 1..4 yolo layers");
+    rows_ = row_off;
+    pred_ = arena_.alloc((size_t)max_batch * rows_ * attrs_);
+    finalize();
+}
+
+void YoloNet::forward(const float* d_img, bool nhwc_input, int batch, float* d_pred, float conf, int num_classes,
+                      float* d_sel, hipStream_t s) {
+    BP_CHECK(batch >= 1 && batch <= max_batch_, "batch out of range");
+    if (nhwc_input) {
+        if (d_img != in_nhwc_)
+            BP_HIP(hipMemcpyAsync(in_nhwc_, d_img, (size_t)batch * reso_ * reso_ * 3 * sizeof(float),
+                                  hipMemcpyDeviceToDevice, s));
+    } else {
+        launch_nchw_to_nhwc(d_img, in_nhwc_, batch, 3, reso_, reso_, s);
+    }
+    run_ops(batch, s);
+    // heads hold per-image strides for max_batch_ == layout of batch b (contiguous by image), so decode as is
+    float* pred = d_pred ? d_pred : pred_;
+    launch_yolo_decode(heads_.data(), (int)heads_.size(), batch, reso_, attrs_, rows_, pred, s);
+    if (d_sel) launch_yolo_select(pred, batch, rows_, attrs_, conf, num_classes, d_sel, s);
+    BP_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ KpdNet (FastPose)
+KpdNet::KpdNet(const float* stream, size_t n_floats, int n_classes, int max_batch, int inH, int inW)
+    : Net(max_batch), inH_(inH), inW_(inW) {
+    BP_CHECK(inH % 32 == 0 && inW % 32 == 0, "KPD input must be a multiple of 32");
+    BP_CHECK(n_classes >= 1, "n_classes");
+    outC_ = std::min(n_classes, 50);   // InferenNet_fast narrows to the first 50 maps (main_fast_inference.py:44)
+    size_t cur = 0;
+    auto take = [&](size_t cnt) {
+        BP_CHECK(cur + cnt <= n_floats, "KPD stream too short");
+        const float* p = stream + cur;
+        cur += cnt;
+        return p;
+    };
+    auto take_conv_bn = [&](int cout, int cin, int k) {
+        ConvWeights cw;
+        cw.bn_bias = take(cout); cw.bn_scale = take(cout); cw.bn_mean = take(cout); cw.bn_var = take(cout);
+        cw.w = take((size_t)cout * cin * k * k);
+        return cw;
+    };
+    auto upload = [&](const float* h, size_t cnt) {
+        float* d = arena_.alloc(cnt);
+        BP_HIP(hipMemcpy(d, h, cnt * sizeof(float), hipMemcpyHostToDevice));
+        return d;
+    };
+    in_nhwc_ = arena_.alloc((size_t)max_batch * inH * inW * 3);
+    Tensor x;
+    x.p = in_nhwc_; x.H = inH; x.W = inW; x.C = 3; x.ld = 3;
+    // stem: 7x7/2 + BN + ReLU, max-pool 3/2/1   (SE_Resnet.py:54-58,71)
+    {
+        ConvWeights cw = take_conv_bn(64, 3, 7);
+        Tensor t = new_tensor(inH / 2, inW / 2, 64);
+        add_conv("stem", x, t, cw, 64, 7, 2, 3, ACT_RELU, ST_NHWC, nullptr, nullptr, 0, 1e-5f, t.H, t.W);
+        Tensor p = new_tensor(inH / 4, inW / 4, 64);
+        Op op; op.type = OP_MAXPOOL; op.name = "maxpool";
+        op.a = t.p; op.out = p.p; op.H = t.H; op.W = t.W; op.C = 64; op.OH = p.H; op.OW = p.W;
+        ops_.push_back(op);
+        x = p;
+        add_tap("stem", x);
+    }
+    const int planes_[4] = {64, 128, 256, 512}, nblocks_[4] = {3, 4, 23, 3}, strides_[4] = {1, 2, 2, 2};
+    int inplanes = 64;
+    for (int li = 0; li < 4; ++li) {
+        const int planes = planes_[li];
+        for (int bi = 0; bi < nblocks_[li]; ++bi) {
+            const int st = bi == 0 ? strides_[li] : 1;
+            const bool first = bi == 0;
+            const std::string nm = "preact.layer" + std::to_string(li + 1) + "." + std::to_string(bi);
+            ConvWeights c1 = take_conv_bn(planes, inplanes, 1);
+            ConvWeights c2 = take_conv_bn(planes, planes, 3);
+            ConvWeights c3 = take_conv_bn(planes * 4, planes, 1);
+            const int OH = x.H / st, OW = x.W / st;
+            Tensor t1 = new_tensor(x.H, x.W, planes);
+            add_conv(nm + ".conv1", x, t1, c1, planes, 1, 1, 0, ACT_RELU, ST_NHWC, nullptr, nullptr, 0, 1e-5f, x.H, x.W);
+            Tensor t2 = new_tensor(OH, OW, planes);
+            add_conv(nm + ".conv2", t1, t2, c2, planes, 3, st, 1, ACT_RELU, ST_NHWC, nullptr, nullptr, 0, 1e-5f, OH, OW);
+            Tensor out = new_tensor(OH, OW, planes * 4);
+            if (!first) {
+                // out = relu(bn3(conv3) + x)   (SE_Resnet.py:31-40)
+                add_conv(nm + ".conv3", t2, out, c3, planes * 4, 1, 1, 0, ACT_RELU, ST_NHWC, &x, nullptr, 0, 1e-5f, OH, OW);
+            } else {
+                // SE block: T = bn3(conv3); y = sigmoid(fc2(relu(fc0(avgpool(T))))); out = relu(bn_d(conv_d(x)) + T*y)
+                const int C = planes * 4;
+                const float* w0 = take((size_t)C * C); const float* b0 = take(C);
+                const float* w2 = take((size_t)C * C); const float* b2 = take(C);
+                ConvWeights cd = take_conv_bn(C, inplanes, 1);
+                Tensor Tt = new_tensor(OH, OW, C);
+                add_conv(nm + ".conv3", t2, Tt, c3, C, 1, 1, 0, ACT_LINEAR, ST_NHWC, nullptr, nullptr, 0, 1e-5f, OH, OW);
+                float* pooled = arena_.alloc((size_t)max_batch * C);
+                float* hid = arena_.alloc((size_t)max_batch * C);
+                float* y = arena_.alloc((size_t)max_batch * C);
+                Op ap; ap.type = OP_AVGPOOL; ap.name = nm + ".se.pool";
+                ap.a = Tt.p; ap.a_ld = Tt.ld; ap.out = pooled; ap.H = OH; ap.W = OW; ap.C = C;
+                ops_.push_back(ap);
+                Op f0; f0.type = OP_FC; f0.name = nm + ".se.fc.0";
+                f0.a = pooled; f0.w = upload(w0, (size_t)C * C); f0.bias = upload(b0, C); f0.out = hid; f0.Cin = C; f0.Cout = C; f0.act = 2;
+                f0.flops = 2.0 * C * C; f0.bytes = 4.0 * C * C;
+                ops_.push_back(f0);
+                Op f2 = f0; f2.name = nm + ".se.fc.2";
+                f2.a = hid; f2.w = upload(w2, (size_t)C * C); f2.bias = upload(b2, C); f2.out = y; f2.act = 3;
+                ops_.push_back(f2);
+                add_conv(nm + ".downsample", x, out, cd, C, 1, st, 0, ACT_RELU, ST_NHWC, &Tt, y, 0, 1e-5f, OH, OW);
+            }
+            x = out;
+            inplanes = planes * 4;
+            add_tap(nm, x);
+        }
+    }
+    // PixelShuffle(2): [2048, H/32, W/32] -> [512, H/16, W/16]   (FastPose.py:30)
+    {
+        Tensor t = new_tensor(x.H * 2, x.W * 2, x.C / 4);
+        Op op; op.type = OP_PIXSHUF; op.name = "suffle1";
+        op.a = x.p; op.out = t.p; op.H = x.H; op.W = x.W; op.C = x.C;
+        ops_.push_back(op);
+        x = t;
+    }
+    // DUC x2: conv3x3 + BN + ReLU with the PixelShuffle folded into the store   (DUC.py:18-23)
+    const int duc_out[2] = {1024, 512};
+    for (int d = 0; d < 2; ++d) {
+        ConvWeights cw = take_conv_bn(duc_out[d], x.C, 3);
+        Tensor t = new_tensor(x.H * 2, x.W * 2, duc_out[d] / 4);
+        add_conv("duc" + std::to_string(d + 1), x, t, cw, duc_out[d], 3, 1, 1, ACT_RELU, ST_PIXSHUF, nullptr, nullptr, 0,
+                 1e-5f, x.H, x.W);
+        x = t;
+        add_tap("duc" + std::to_string(d + 1), x);
+    }
+    // conv_out 3x3 (+bias), only the maps InferenNet_fast keeps, stored NCHW for the arg-max kernel
+    {
+        ConvWeights cw;
+        cw.bias = take(n_classes);
+        cw.w = take((size_t)n_classes * x.C * 9);
+        hm_ = arena_.alloc((size_t)max_batch * outC_ * x.H * x.W);
+        Tensor t; t.p = hm_; t.H = x.H; t.W = x.W; t.C = outC_; t.ld = outC_;
+        hm_op_ = add_conv("conv_out", x, t, cw, outC_, 3, 1, 1, ACT_LINEAR, ST_NCHW, nullptr, nullptr, 0, 1e-5f, x.H, x.W);
+    }
+    BP_CHECK(cur == n_floats, "KPD stream has trailing data (wrong n_classes?)");
+    finalize();
+}
+
+void KpdNet::forward(const float* d_inps, bool nhwc_input, int batch, float* d_hm, float* d_kp, hipStream_t s) {
+    BP_CHECK(batch >= 1 && batch <= max_batch_, "batch out of range");
+    if (nhwc_input) {
+        if (d_inps != in_nhwc_)
+            BP_HIP(hipMemcpyAsync(in_nhwc_, d_inps, (size_t)batch * inH_ * inW_ * 3 * sizeof(float),
+                                  hipMemcpyDeviceToDevice, s));
+    } else {
+        launch_nchw_to_nhwc(d_inps, in_nhwc_, batch, 3, inH_, inW_, s);
+    }
+    ops_[hm_op_].conv.out = d_hm ? d_hm : hm_;
+    run_ops(batch, s);
+    if (d_kp) launch_heatmap_argmax(d_hm ? d_hm : hm_, batch, outC_, out_h(), out_w(), d_kp, s);
+    BP_HIP(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ Pillow bicubic coefficient tables
+// Restates Pillow's precompute_coeffs + normalize_coeffs_8bpc (src/libImaging/Resample.c; third-party,
+// not under /root/reference; pinned integer-exactly against the installed Pillow in the tests).
+static double bicubic_filter(double x) {
+    const double a = -0.5;
+    if (x < 0.0) x = -x;
+    if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+    if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+    return 0.0;
+}
+ResizePlan make_bicubic_plan(int in_size, int out_size) {
+    ResizePlan pl;
+    pl.in_size = in_size; pl.out_size = out_size;
+    const double scale = (double)in_size / out_size;
+    double filterscale = scale < 1.0 ? 1.0 : scale;
+    const double support = 2.0 * filterscale;
+    const int ksize = (int)std::ceil(support) * 2 + 1;
+    pl.ksize = ksize;
+    pl.bounds.assign((size_t)out_size * 2, 0);
+    pl.coeffs.assign((size_t)out_size * ksize, 0);
+    std::vector<double> k(ksize);
+    for (int xx = 0; xx < out_size; ++xx) {
+        const double center = (xx + 0.5) * scale;
+        double ww = 0.0;
+        const double ss = 1.0 / filterscale;
+        int xmin = (int)(center - support + 0.5);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5);
+        if (xmax > in_size) xmax = in_size;
+        xmax -= xmin;
+        for (int x = 0; x < xmax; ++x) {
+            const double w = bicubic_filter((x + xmin - center + 0.5) * ss);
+            k[x] = w;
+            ww += w;
+        }
+        for (int x = 0; x < xmax; ++x)
+            if (ww != 0.0) k[x] /= ww;
+        for (int x = 0; x < xmax; ++x) {
+            const double v = k[x] * (double)(1 << 22);
+            pl.coeffs[(size_t)xx * ksize + x] = v < 0 ? (int)(-0.5 + v) : (int)(0.5 + v);
+        }
+        pl.bounds[2 * xx] = xmin;
+        pl.bounds[2 * xx + 1] = xmax;
+    }
+    return pl;
+}
+
+}  // namespace bp

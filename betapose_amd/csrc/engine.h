@@ -1,0 +1,135 @@
+// Network plans for the two models of the hot path, built on the fused kernels.
+#pragma once
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "bp_common.h"
+
+namespace bp {
+
+struct Tensor {       // NHWC view
+    float* p = nullptr;
+    int H = 0, W = 0, C = 0;
+    int ld = 0;       // floats between consecutive pixels (>= C; > C inside a concat buffer)
+};
+
+class Arena {
+public:
+    ~Arena();
+    float* alloc(size_t n_floats);
+    void* alloc_bytes(size_t bytes);
+    size_t total_bytes() const { return total_; }
+private:
+    std::vector<void*> ptrs_;
+    size_t total_ = 0;
+};
+
+enum OpType : int {
+    OP_CONV, OP_NCHW2NHWC, OP_MAXPOOL, OP_ADD, OP_UPSAMPLE, OP_COPYCH, OP_PIXSHUF, OP_AVGPOOL, OP_FC,
+    OP_NHWC2NCHW
+};
+
+struct Op {
+    OpType type;
+    ConvParams conv{};   // OP_CONV (per-image geometry; N/M/partial patched at run time)
+    int tile = TILE_64x64;
+    // generic operands
+    const float* a = nullptr; int a_ld = 0;
+    const float* b = nullptr; int b_ld = 0;
+    float* out = nullptr; int out_ld = 0;
+    int H = 0, W = 0, C = 0, OH = 0, OW = 0;
+    // fc
+    const float* w = nullptr; const float* bias = nullptr; int Cin = 0, Cout = 0, act = 0;
+    std::string name;
+    double flops = 0;    // per image
+    double bytes = 0;    // algorithmic bytes per image (weights counted once per launch elsewhere)
+};
+
+struct ConvWeights {   // one conv as it arrives in the stream (un-folded)
+    const float* w = nullptr;          // OIHW
+    const float* bn_bias = nullptr, *bn_scale = nullptr, *bn_mean = nullptr, *bn_var = nullptr;
+    const float* bias = nullptr;
+};
+
+class Net {
+public:
+    explicit Net(int max_batch) : max_batch_(max_batch) {}
+    virtual ~Net() = default;
+    int max_batch() const { return max_batch_; }
+    void run_ops(int batch, hipStream_t s);
+    size_t device_bytes() const { return arena_.total_bytes(); }
+    const std::vector<Op>& ops() const { return ops_; }
+    // test hook: copy a recorded intermediate (NHWC view) to a dense NCHW device buffer
+    int tap_count() const { return (int)taps_.size(); }
+    const char* tap_name(int i) const { return tap_names_[i].c_str(); }
+    void tap_shape(int i, int* C, int* H, int* W) const { *C = taps_[i].C; *H = taps_[i].H; *W = taps_[i].W; }
+    void tap_copy(int i, int batch, float* d_out_nchw, hipStream_t s) const;
+    void set_splitk_policy(int target_blocks, int min_chunks) { sk_target_ = target_blocks; sk_min_chunks_ = min_chunks; }
+    void set_force_tile(int t) { force_tile_ = t; }
+
+protected:
+    // emit a fused conv; returns index into ops_
+    int add_conv(const std::string& name, const Tensor& in, const Tensor& out_view, const ConvWeights& cw, int Cout,
+                 int k, int stride, int pad, int act, int store_mode, const Tensor* res, const float* res_scale,
+                 int res_after_act, float bn_eps, int OH, int OW);
+    void add_tap(const std::string& name, const Tensor& t) { taps_.push_back(t); tap_names_.push_back(name); }
+    Tensor new_tensor(int H, int W, int C);
+    void finalize();   // allocate split-K workspace
+
+    int max_batch_;
+    Arena arena_;
+    std::vector<Op> ops_;
+    std::vector<Tensor> taps_;
+    std::vector<std::string> tap_names_;
+    float* partial_ = nullptr;
+    size_t partial_floats_ = 0;
+    int sk_target_ = 512, sk_min_chunks_ = 4;
+    int force_tile_ = -1;
+};
+
+class YoloNet : public Net {
+public:
+    YoloNet(const std::string& cfg_text, const float* stream, size_t n_floats, int reso, int max_batch);
+    int rows() const { return rows_; }
+    int attrs() const { return attrs_; }
+    int reso() const { return reso_; }
+    // img: NCHW f32 [B,3,reso,reso] RGB 0..1 (or NHWC when nhwc_input); pred [B,rows,attrs] (may be null when sel given)
+    void forward(const float* d_img, bool nhwc_input, int batch, float* d_pred, float conf, int num_classes,
+                 float* d_sel, hipStream_t s);
+    float* input_nhwc() { return in_nhwc_; }
+    float* pred_buffer() { return pred_; }
+private:
+    int reso_, rows_ = 0, attrs_ = 0;
+    float* in_nhwc_ = nullptr;
+    float* pred_ = nullptr;
+    std::vector<YoloHead> heads_;
+};
+
+class KpdNet : public Net {
+public:
+    KpdNet(const float* stream, size_t n_floats, int n_classes, int max_batch, int inH = 320, int inW = 256);
+    int out_c() const { return outC_; }
+    int out_h() const { return inH_ / 4; }
+    int out_w() const { return inW_ / 4; }
+    int in_h() const { return inH_; }
+    int in_w() const { return inW_; }
+    // inps: NCHW f32 [B,3,320,256] (or NHWC); hm NCHW [B,50,80,64] (null -> internal); kp [B,50,6] (nullable)
+    void forward(const float* d_inps, bool nhwc_input, int batch, float* d_hm, float* d_kp, hipStream_t s);
+    float* input_nhwc() { return in_nhwc_; }
+private:
+    int inH_, inW_, outC_;
+    float* in_nhwc_ = nullptr;
+    float* hm_ = nullptr;
+    int hm_op_ = -1;
+};
+
+// host-side Pillow coefficient tables (a1)
+struct ResizePlan {
+    int in_size = 0, out_size = 0, ksize = 0;
+    std::vector<int> bounds, coeffs;
+};
+ResizePlan make_bicubic_plan(int in_size, int out_size);
+
+}  // namespace bp

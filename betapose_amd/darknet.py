@@ -1,0 +1,192 @@
+"""``Darknet`` -- the detector, same call surface as the reference's
+``yolo/darknet.py:Darknet`` (3_6Dpose_estimator/yolo/darknet.py:209-432) so that
+``DetectionLoader`` (dataloader.py:285-301) runs with only its import changed:
+
+    det_model = Darknet("yolo/cfg/yolov3-single.cfg", reso=416)
+    det_model.load_weights("models/yolo/01.weights")
+    det_model.net_info['height'] = 416
+    det_model.cuda(); det_model.eval()
+    prediction = det_model(img)            # f32[B,3,R,R] -> f32[B, sum 3g^2, 5+C]
+
+All arithmetic runs in libbetapose_hip.so (hand-written HIP for gfx950); this class
+only parses the cfg, reads the ``.weights`` file and moves pointers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from .cfg import parse_cfg, parse_cfg_text, yolov3_single_cfg_text
+from .weights import darknet_stream_size, read_darknet_weights
+
+
+def _cfg_text(blocks) -> str:
+    out = []
+    for b in blocks:
+        out.append("[%s]" % b["type"])
+        for k, v in b.items():
+            if k != "type":
+                out.append("%s=%s" % (k, v))
+        out.append("")
+    return "\n".join(out)
+
+
+class Darknet:
+    def __init__(self, cfgfile: str, reso: int = 416, max_batch: int = 1, device: Optional[int] = None):
+        self.blocks = parse_cfg(cfgfile)
+        self.reso = int(reso)
+        self.net_info = self.blocks[0]          # aliases block 0, as in the reference (darknet.py:232)
+        self.max_batch = int(max_batch)
+        self._device = device
+        self._stream: Optional[np.ndarray] = None
+        self._h = None
+        self.header = None
+        self.seen = 0
+        self.training = False
+
+    # ---- nn.Module-like surface used by the reference callers
+    def load_weights(self, path: str, cutoff=None):
+        if cutoff is not None:
+            raise NotImplementedError("cutoff is not used on the inference path")
+        self.header, self.seen, flat = read_darknet_weights(path)
+        self.load_stream(flat)
+        return self
+
+    def load_stream(self, flat: np.ndarray):
+        need = darknet_stream_size([b for b in self.blocks if b["type"] != "net"])
+        if flat.size < need:
+            raise ValueError("weights stream has %d floats, cfg needs %d" % (flat.size, need))
+        self._stream = np.ascontiguousarray(flat[:need], dtype=np.float32)
+        self._destroy()
+        return self
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def cuda(self, device=None):
+        if device is not None:
+            self._device = int(device) if not hasattr(device, "index") else device.index
+        self._ensure()
+        return self
+
+    def to(self, device):
+        return self.cuda(device)
+
+    def __call__(self, x, y_true=None):
+        return self.forward(x)
+
+    # ---- engine
+    def _ensure(self):
+        if self._h is not None:
+            return
+        import torch
+        _lib.require_gpu()
+        if self._stream is None:
+            raise RuntimeError("call load_weights() before the first forward")
+        if self._device is None:
+            self._device = torch.cuda.current_device()
+        h = C.c_void_p()
+        blocks = [b for b in self.blocks if b["type"] != "net"]
+        _lib.check(_lib.lib().bp_yolo_create_from_memory(
+            _cfg_text(blocks).encode(), self._stream.ctypes.data, self._stream.size, self.reso, self.max_batch,
+            self._device, C.byref(h)))
+        self._h = h
+        self.rows = _lib.lib().bp_yolo_rows(h)
+        self.attrs = _lib.lib().bp_yolo_attrs(h)
+
+    def _destroy(self):
+        if self._h is not None:
+            _lib.lib().bp_yolo_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self._destroy()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        self._ensure()
+        return self._h
+
+    def _prep(self, x):
+        import torch
+        self._ensure()
+        if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != self.reso or x.shape[3] != self.reso:
+            raise ValueError("expected [B,3,%d,%d], got %s" % (self.reso, self.reso, tuple(x.shape)))
+        if x.shape[0] > self.max_batch:
+            raise ValueError("batch %d > max_batch %d" % (x.shape[0], self.max_batch))
+        return x.to(device="cuda:%d" % self._device, dtype=torch.float32).contiguous()
+
+    def forward(self, x):
+        """f32[B,3,R,R] (RGB 0..1) -> f32[B, rows, 5+C] in DetectionLayer row order."""
+        import torch
+        x = self._prep(x)
+        pred = torch.empty((x.shape[0], self.rows, self.attrs), device=x.device, dtype=torch.float32)
+        _lib.check(_lib.lib().bp_yolo_forward(self._h, x.data_ptr(), x.shape[0], pred.data_ptr(), _lib.current_stream()))
+        return pred
+
+    def forward_select(self, x, confidence: float = 0.01, num_classes: int = 80, want_pred: bool = False):
+        """Fused forward + ``dynamic_write_results`` (yolo/util.py:104-223, NMS off):
+        returns ``sel`` f32[B,8] = (idx as int bits, x1,y1,x2,y2,obj,cls_conf,cls_idx); idx=-1 -> no detection."""
+        import torch
+        x = self._prep(x)
+        sel = torch.empty((x.shape[0], 8), device=x.device, dtype=torch.float32)
+        pred = torch.empty((x.shape[0], self.rows, self.attrs), device=x.device, dtype=torch.float32) if want_pred else None
+        _lib.check(_lib.lib().bp_yolo_forward_select(self._h, x.data_ptr(), x.shape[0], float(confidence), int(num_classes),
+                                                     pred.data_ptr() if want_pred else None, sel.data_ptr(),
+                                                     _lib.current_stream()))
+        return (sel, pred) if want_pred else sel
+
+    # ---- inspection hooks (tests)
+    def taps(self):
+        self._ensure()
+        L = _lib.lib()
+        out = []
+        name = C.create_string_buffer(64)
+        c, h, w = C.c_int(), C.c_int(), C.c_int()
+        for i in range(L.bp_yolo_tap_count(self._h)):
+            _lib.check(L.bp_yolo_tap_info(self._h, i, name, 64, C.byref(c), C.byref(h), C.byref(w)))
+            out.append((name.value.decode(), c.value, h.value, w.value))
+        return out
+
+    def tap(self, i: int, batch: int = 1):
+        import torch
+        name, c, h, w = self.taps()[i]
+        t = torch.empty((batch, c, h, w), device="cuda:%d" % self._device, dtype=torch.float32)
+        _lib.check(_lib.lib().bp_yolo_tap_copy(self._h, i, batch, t.data_ptr(), _lib.current_stream()))
+        return t
+
+    def set_policy(self, sk_target_blocks: int = 512, sk_min_chunks: int = 4, force_tile: int = -1):
+        self._ensure()
+        _lib.lib().bp_yolo_set_policy(self._h, sk_target_blocks, sk_min_chunks, force_tile)
+
+    def op_stats(self):
+        self._ensure()
+        n = _lib.lib().bp_yolo_op_stats(self._h, None, None, 0)
+        f = (C.c_double * n)()
+        b = (C.c_double * n)()
+        _lib.lib().bp_yolo_op_stats(self._h, f, b, n)
+        return np.array(f), np.array(b)
+
+
+def sel_to_dets(sel) -> "object":
+    """sel f32[B,8] (device or cpu) -> what ``dynamic_write_results`` returns:
+    int ``0`` when no image has a detection, else f32[n,8] rows
+    (batch_idx, x1,y1,x2,y2, obj, cls_conf, cls_idx)  (yolo/util.py:206-222)."""
+    import torch
+    s = sel.detach().cpu()
+    idx = s[:, 0].contiguous().view(torch.int32)
+    keep = idx >= 0
+    if not bool(keep.any()):
+        return 0
+    rows = []
+    for b in torch.nonzero(keep).flatten().tolist():
+        rows.append(torch.cat((torch.tensor([float(b)]), s[b, 1:8])))
+    return torch.stack(rows)

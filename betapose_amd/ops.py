@@ -1,0 +1,95 @@
+"""Stand-alone device stages of the hot path (thin ctypes wrappers, torch tensors
+as device memory): fused conv (unit-test / benchmark hook), crop, Pillow-exact
+bicubic resize, PnP."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+
+ACT = {"linear": 0, "leaky": 1, "relu": 2}
+STORE = {"nhwc": 0, "up2": 1, "pixshuf": 2, "nchw": 3}
+TILE = {"auto": -1, "64x64": 0, "128x64": 1}
+
+
+def conv2d_nhwc(x, weight, bias=None, stride: int = 1, pad: int = 0, act: str = "linear", store: str = "nhwc",
+                res=None, res_after_act: bool = False, tile: str = "auto", splits: int = 0, iters: int = 0):
+    """One fused convolution.  ``x``: cuda f32 [N,H,W,Cin] (NHWC); ``weight``: host
+    numpy/torch [Cout,Cin,k,k]; returns the output tensor laid out per ``store`` and,
+    when ``iters`` > 0, also the measured ms per launch."""
+    import torch
+    _lib.require_gpu()
+    w = np.ascontiguousarray(weight.detach().cpu().numpy() if hasattr(weight, "detach") else weight, dtype=np.float32)
+    b = None
+    if bias is not None:
+        b = np.ascontiguousarray(bias.detach().cpu().numpy() if hasattr(bias, "detach") else bias, dtype=np.float32)
+    N, H, W, Cin = x.shape
+    Cout, _, k, _ = w.shape
+    OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    x = x.contiguous()
+    if store == "nhwc":
+        out = torch.empty((N, OH, OW, Cout), device=x.device, dtype=torch.float32)
+    elif store == "up2":
+        out = torch.empty((N, 2 * OH, 2 * OW, Cout), device=x.device, dtype=torch.float32)
+    elif store == "pixshuf":
+        out = torch.empty((N, 2 * OH, 2 * OW, Cout // 4), device=x.device, dtype=torch.float32)
+    else:
+        out = torch.empty((N, Cout, OH, OW), device=x.device, dtype=torch.float32)
+    ms = C.c_float(0)
+    _lib.check(_lib.lib().bp_conv2d(x.data_ptr(), N, H, W, Cin, w.ctypes.data, b.ctypes.data if b is not None else None,
+                                    Cout, k, stride, pad, ACT[act], STORE[store],
+                                    res.contiguous().data_ptr() if res is not None else None, int(res_after_act),
+                                    TILE[tile], int(splits), out.data_ptr(), int(iters), C.byref(ms),
+                                    _lib.current_stream()))
+    return (out, ms.value) if iters > 0 else out
+
+
+def crop(frames_bgr_u8, sel=None, boxes=None, reso: int = 416, oh: int = 320, ow: int = 256, nchw: bool = True):
+    """Device crop (dataloader.py:354-364,794-835; img.py:242-262).  ``frames``: cuda u8
+    [B,H,W,3] BGR; ``sel`` [B,8] (YOLO-input-pixel boxes) or ``boxes`` [B,4] (frame pixels).
+    Returns (inps [B,3,oh,ow] or [B,oh,ow,3], pts [B,8] = pt1.x,pt1.y,pt2.x,pt2.y, box x1,y1,x2,y2)."""
+    import torch
+    _lib.require_gpu()
+    f = frames_bgr_u8.contiguous()
+    B, H, W, _ = f.shape
+    out = torch.empty((B, 3, oh, ow) if nchw else (B, oh, ow, 3), device=f.device, dtype=torch.float32)
+    pts = torch.empty((B, 8), device=f.device, dtype=torch.float32)
+    _lib.check(_lib.lib().bp_crop(f.data_ptr(), B, H, W, sel.contiguous().data_ptr() if sel is not None else None, reso,
+                                  boxes.contiguous().data_ptr() if boxes is not None else None,
+                                  out.data_ptr() if nchw else None, None if nchw else out.data_ptr(), pts.data_ptr(),
+                                  oh, ow, _lib.current_stream()))
+    return out, pts
+
+
+def resize_bicubic(frames_u8, oh: int = 416, ow: int = 416, swap_rb: bool = True, want: str = "f32"):
+    """Pillow-exact antialiased bicubic (dataloader.py:94-99).  ``frames``: cuda u8 [B,H,W,3].
+    ``want`` 'u8' -> u8 [B,oh,ow,3]; 'f32' -> f32 NHWC /255."""
+    import torch
+    _lib.require_gpu()
+    f = frames_u8.contiguous()
+    B, H, W, _ = f.shape
+    if want == "u8":
+        out = torch.empty((B, oh, ow, 3), device=f.device, dtype=torch.uint8)
+        _lib.check(_lib.lib().bp_resize_bicubic(f.data_ptr(), B, H, W, oh, ow, int(swap_rb), out.data_ptr(), None,
+                                                _lib.current_stream()))
+    else:
+        out = torch.empty((B, oh, ow, 3), device=f.device, dtype=torch.float32)
+        _lib.check(_lib.lib().bp_resize_bicubic(f.data_ptr(), B, H, W, oh, ow, int(swap_rb), None, out.data_ptr(),
+                                                _lib.current_stream()))
+    return out
+
+
+def solve_pnp(points_3d, points_2d, K):
+    """utils/utils.py:17-41 ``pnp``: returns (R [3,3], t [3,1]) f64.  Host-only (no GPU needed)."""
+    p3 = np.ascontiguousarray(points_3d, dtype=np.float64)
+    p2 = np.ascontiguousarray(np.asarray(points_2d)[:, :2], dtype=np.float64)
+    assert p3.shape[0] == p2.shape[0], "points 3D and points 2D must have same number of vertices"
+    Kc = np.ascontiguousarray(K, dtype=np.float64)
+    R = np.empty((3, 3), np.float64)
+    t = np.empty(3, np.float64)
+    _lib.check(_lib.lib().bp_solve_pnp(p3.ctypes.data, p2.ctypes.data, p3.shape[0], Kc.ctypes.data, R.ctypes.data,
+                                       t.ctypes.data))
+    return R, t.reshape(3, 1)

@@ -1,0 +1,134 @@
+/* betapose_hip.h -- C ABI of libbetapose_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the per-frame inference hot path of sjtuytc/betapose
+ * (SURVEY.md section 8b).  Plain C: opaque handles, raw device/host pointers and
+ * sizes, int status codes (0 = ok, <0 = error; text via bp_last_error()).  Nothing
+ * here throws, calls exit() or keeps hidden global engine state, so one engine per
+ * rank/stream can coexist.  All "d_" pointers are device (HIP) pointers; `stream`
+ * is a hipStream_t passed as void* (NULL = default stream).  Calls on one handle
+ * must be serialised by the caller; different handles may be used from different
+ * host threads.
+ *
+ * What each entry point replaces in the reference (paths under
+ * /root/reference/3_6Dpose_estimator):
+ *   bp_yolo_create*        Darknet(cfgfile, reso) + load_weights(path)      yolo/darknet.py:217-221,365-432
+ *                          (C twin: init(cfg, weights, gpu)                 train_YOLO/src/yolo_v2_class.hpp:49)
+ *   bp_yolo_forward        Darknet.forward -> [B, 10647, 5+C]               yolo/darknet.py:319-363,129-169
+ *   bp_yolo_forward_select + dynamic_write_results (nms hard-wired off)     yolo/util.py:104-223
+ *   bp_kpd_create          InferenNet_fast.__init__ / load_state_dict      KPD/src/main_fast_inference.py:26-40
+ *   bp_kpd_forward         InferenNet_fast.forward -> [B,50,80,64]         main_fast_inference.py:42-46, models/FastPose.py:28-35
+ *   bp_kpd_forward_argmax  + the arg-max half of getPrediction              KPD/src/utils/eval.py:113-131
+ *   bp_crop                crop_from_dets + cropBox + box rescale          dataloader.py:354-364,794-835; KPD/src/utils/img.py:242-262
+ *   bp_resize_bicubic      transforms.Resize((416,416), 3) + ToTensor      dataloader.py:94-99,162
+ *   bp_pipeline_*          DetectionLoader.update -> DetectionProcessor.update -> main loop
+ *                          (dataloader.py:330-401,438-457; betapose_evaluate.py:145-176) fused on device
+ *   bp_pose_nms1 / bp_solve_pnp   pose_nms (n = 1 fast path), pnp          pPose_nms.py:24-122; utils/utils.py:17-41
+ *
+ * Weight streams.  "YOLO stream" = payload of a Darknet .weights file after its
+ * header (train_YOLO/src/parser.c:1148-1174): per [convolutional] block in cfg order
+ * {bn.bias, bn.scale, bn.mean, bn.var | conv.bias}, conv.weight[out,in,k,k], fp32.
+ * "KPD stream" = the FastPose state_dict flattened the same way: convs in
+ * module-definition order (preact.conv1; per bottleneck conv1, conv2, conv3,
+ * [se.fc.0.weight, se.fc.0.bias, se.fc.2.weight, se.fc.2.bias, downsample.0];
+ * duc1.conv, duc2.conv, conv_out) with {bn.bias, bn.weight, running_mean,
+ * running_var} (or conv.bias for conv_out) before each conv.weight.  The Python host
+ * unpickles the .pkl; C never parses pickle.
+ */
+#ifndef BETAPOSE_HIP_H
+#define BETAPOSE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bp_yolo bp_yolo;
+typedef struct bp_kpd bp_kpd;
+typedef struct bp_pipeline bp_pipeline;
+
+/* floats per frame in the pipeline result record:
+ *   [0..7]   select: idx (int bits; -1 = no detection), x1,y1,x2,y2 (YOLO-input pixels), obj, cls_conf, cls_idx
+ *   [8..15]  pt1.x, pt1.y, pt2.x, pt2.y (crop window, frame pixels), box x1,y1,x2,y2 (frame pixels)
+ *   [16..]   50 x (argmax idx (int bits), max, left, right, up, down)                       */
+#define BP_RESULT_FLOATS 316
+#define BP_KP_FLOATS 6
+#define BP_SEL_FLOATS 8
+
+const char* bp_last_error(void);
+int bp_version(void);
+int bp_device_count(void);                      /* yolo_v2_class.hpp:52 get_device_count */
+int bp_device_name(int device, char* out, int cap);
+
+/* ---- detector ---- */
+int bp_yolo_create(const char* cfg_path, const char* weights_path, int reso, int max_batch, int device, bp_yolo** out);
+int bp_yolo_create_from_memory(const char* cfg_text, const float* stream, size_t n_floats, int reso, int max_batch,
+                               int device, bp_yolo** out);
+void bp_yolo_destroy(bp_yolo* y);
+int bp_yolo_rows(const bp_yolo* y);             /* 10647 at reso 416 */
+int bp_yolo_attrs(const bp_yolo* y);            /* 5 + classes */
+int bp_yolo_forward(bp_yolo* y, const float* d_img_nchw, int batch, float* d_pred, void* stream);
+/* d_pred may be NULL; d_sel: [batch][8] */
+int bp_yolo_forward_select(bp_yolo* y, const float* d_img_nchw, int batch, float conf, int num_classes, float* d_pred,
+                           float* d_sel, void* stream);
+/* test/inspection hooks: intermediate layer outputs (dense NCHW copies) */
+int bp_yolo_tap_count(const bp_yolo* y);
+int bp_yolo_tap_info(const bp_yolo* y, int i, char* name, int cap, int* C, int* H, int* W);
+int bp_yolo_tap_copy(bp_yolo* y, int i, int batch, float* d_out_nchw, void* stream);
+
+/* ---- key-point detector ---- */
+int bp_kpd_create(const float* stream, size_t n_floats, int n_classes, int max_batch, int device, bp_kpd** out);
+void bp_kpd_destroy(bp_kpd* k);
+int bp_kpd_forward(bp_kpd* k, const float* d_inps_nchw, int batch, float* d_hm, void* stream);
+/* d_hm may be NULL; d_kp: [batch][50][6] */
+int bp_kpd_forward_argmax(bp_kpd* k, const float* d_inps_nchw, int batch, float* d_hm, float* d_kp, void* stream);
+int bp_kpd_tap_count(const bp_kpd* k);
+int bp_kpd_tap_info(const bp_kpd* k, int i, char* name, int cap, int* C, int* H, int* W);
+int bp_kpd_tap_copy(bp_kpd* k, int i, int batch, float* d_out_nchw, void* stream);
+
+/* launch-policy knobs (tuning / tests): split-K target block count, minimum chunks per split, forced tile (-1 auto) */
+int bp_yolo_set_policy(bp_yolo* y, int sk_target_blocks, int sk_min_chunks, int force_tile);
+int bp_kpd_set_policy(bp_kpd* k, int sk_target_blocks, int sk_min_chunks, int force_tile);
+/* per-op static description: returns number of ops; fills up to cap entries of (flops, bytes) per image */
+int bp_yolo_op_stats(const bp_yolo* y, double* flops, double* bytes, int cap);
+int bp_kpd_op_stats(const bp_kpd* k, double* flops, double* bytes, int cap);
+size_t bp_yolo_device_bytes(const bp_yolo* y);
+size_t bp_kpd_device_bytes(const bp_kpd* k);
+
+/* ---- stand-alone device stages ---- */
+/* d_frames: [batch][H][W][3] u8 BGR.  Either d_sel ([batch][8], box in reso-pixel units, rescaled by W/reso, H/reso)
+ * or d_boxes ([batch][4] frame-pixel x1,y1,x2,y2) gives the boxes.  Outputs: d_out_nchw [batch][3][oh][ow] and/or
+ * d_out_nhwc [batch][oh][ow][3]; d_pts [batch][8]. */
+int bp_crop(const uint8_t* d_frames, int batch, int H, int W, const float* d_sel, int reso, const float* d_boxes,
+            float* d_out_nchw, float* d_out_nhwc, float* d_pts, int oh, int ow, void* stream);
+/* Pillow-exact antialiased bicubic: d_in [batch][H][W][3] u8 -> d_out_u8 [batch][oh][ow][3] (nullable) and/or
+ * d_out_nhwc f32 /255 (nullable).  swap_rb: read BGR, write RGB. */
+int bp_resize_bicubic(const uint8_t* d_in, int batch, int H, int W, int oh, int ow, int swap_rb, uint8_t* d_out_u8,
+                      float* d_out_nhwc, void* stream);
+/* one fused convolution on device tensors (unit tests / kernel benchmarks).  h_w: host OIHW filter, h_bias host or NULL.
+ * d_in NHWC [N,H,W,Cin]; d_out per store_mode (0 NHWC, 1 nearest-x2 NHWC, 2 PixelShuffle(2) NHWC, 3 NCHW);
+ * act 0 linear / 1 leaky(0.1) / 2 relu; d_res NHWC residual or NULL; tile -1 auto; splits 0 auto. */
+int bp_conv2d(const float* d_in, int N, int H, int W, int Cin, const float* h_w, const float* h_bias, int Cout, int k,
+              int stride, int pad, int act, int store_mode, const float* d_res, int res_after_act, int tile, int splits,
+              float* d_out, int iters, float* ms_per_iter, void* stream);
+
+/* ---- whole frame on device: resize -> detector -> select -> crop -> KPD -> arg-max, optionally as one hipGraph ---- */
+int bp_pipeline_create(bp_yolo* y, bp_kpd* k, int frame_h, int frame_w, int batch, float conf, int num_classes,
+                       bp_pipeline** out);
+void bp_pipeline_destroy(bp_pipeline* p);
+uint8_t* bp_pipeline_frames(bp_pipeline* p);    /* device [batch][H][W][3] u8 BGR, caller fills */
+float* bp_pipeline_results(bp_pipeline* p);     /* device [batch][BP_RESULT_FLOATS] */
+float* bp_pipeline_heatmaps(bp_pipeline* p);    /* device [batch][50][80][64] */
+int bp_pipeline_set_fixed_box(bp_pipeline* p, const float* box_xyxy_or_null);
+int bp_pipeline_run(bp_pipeline* p, int use_graph, void* stream);
+
+/* ---- host post-processing (f64, no device work) ---- */
+/* SOLVEPNP_ITERATIVE-style: DLT initialisation + Levenberg-Marquardt on the reprojection error.
+ * pts3d [n][3], pts2d [n][2], K [9] row-major; outputs R [9] row-major, t [3]. */
+int bp_solve_pnp(const double* pts3d, const double* pts2d, int n, const double* K, double* R, double* t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BETAPOSE_HIP_H */

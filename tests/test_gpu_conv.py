@@ -1,0 +1,119 @@
+"""Fused conv kernel (conv_igemm.hip) against torch-CPU fp32 conv2d on the same
+inputs: every kernel size / stride / channel class / epilogue / store mode the two
+networks use, both tile shapes, forced split-K.  Tolerance: fp32 accumulation-order
+noise only (|d| <= 2e-5 * (1 + |ref|) at O(1) activations)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from betapose_amd import ops  # noqa: E402
+
+
+def _ref(x_nhwc, w, b, stride, pad, act, res, res_after_act):
+    x = x_nhwc.permute(0, 3, 1, 2).contiguous()
+    y = F.conv2d(x, w, b, stride=stride, padding=pad)
+    r = res.permute(0, 3, 1, 2) if res is not None else None
+    if r is not None and not res_after_act:
+        y = y + r
+    if act == "leaky":
+        y = F.leaky_relu(y, 0.1)
+    elif act == "relu":
+        y = F.relu(y)
+    if r is not None and res_after_act:
+        y = y + r
+    return y   # NCHW
+
+
+def _check(out, ref, tol=2e-5):
+    d = (out - ref).abs()
+    lim = tol * (1 + ref.abs())
+    assert bool((d <= lim).all()), "max |d| %.3e at ref %.3e" % (float(d.max()), float(ref.flatten()[d.argmax()]))
+
+
+CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad, act
+    (1, 32, 32, 3, 32, 3, 1, 1, "leaky"),      # YOLO layer 0 class (scalar gather path)
+    (1, 40, 32, 3, 64, 7, 2, 3, "relu"),       # KPD stem class
+    (1, 26, 26, 32, 64, 3, 2, 1, "leaky"),     # 3x3/s2
+    (1, 13, 13, 64, 32, 1, 1, 0, "leaky"),     # 1x1
+    (2, 13, 13, 128, 256, 3, 1, 1, "leaky"),   # 3x3/s1, batch 2, M tail
+    (1, 13, 13, 256, 18, 1, 1, 0, "linear"),   # head: Cout < tile
+    (1, 20, 16, 128, 50, 3, 1, 1, "linear"),   # conv_out class
+    (1, 10, 8, 256, 512, 1, 2, 0, "linear"),   # 1x1/s2 downsample
+    (1, 7, 5, 96, 64, 3, 1, 1, "relu"),        # odd sizes
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("tile", ["64x64", "128x64"])
+def test_conv_shapes(cuda, case, tile):
+    N, H, W, Cin, Cout, k, st, pad, act = case
+    g = torch.Generator().manual_seed(100 + CASES.index(case))
+    x = torch.randn(N, H, W, Cin, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g)
+    ref = _ref(x, w, b, st, pad, act, None, False)
+    out = ops.conv2d_nhwc(x.to(cuda), w, b, stride=st, pad=pad, act=act, tile=tile, splits=1)
+    _check(out.cpu().permute(0, 3, 1, 2), ref)
+
+
+@pytest.mark.parametrize("splits", [2, 3, 7])
+def test_conv_splitk(cuda, splits):
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(1, 13, 13, 256, generator=g)
+    w = torch.randn(192, 256, 3, 3, generator=g) / 48
+    b = torch.randn(192, generator=g)
+    res = torch.randn(1, 13, 13, 192, generator=g)
+    ref = _ref(x, w, b, 1, 1, "leaky", res, True)
+    out = ops.conv2d_nhwc(x.to(cuda), w, b, stride=1, pad=1, act="leaky", res=res.to(cuda), res_after_act=True,
+                          splits=splits)
+    _check(out.cpu().permute(0, 3, 1, 2), ref)
+
+
+@pytest.mark.parametrize("after", [True, False])
+def test_conv_residual_orders(cuda, after):
+    """YOLO shortcut adds after the activation (darknet.py:338-340); the ResNet bottleneck
+    adds before the ReLU (SE_Resnet.py:39-40)."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 16, 12, 64, generator=g)
+    w = torch.randn(128, 64, 1, 1, generator=g) / 8
+    b = torch.randn(128, generator=g)
+    res = torch.randn(1, 16, 12, 128, generator=g)
+    act = "leaky" if after else "relu"
+    ref = _ref(x, w, b, 1, 0, act, res, after)
+    out = ops.conv2d_nhwc(x.to(cuda), w, b, act=act, res=res.to(cuda), res_after_act=after)
+    _check(out.cpu().permute(0, 3, 1, 2), ref)
+
+
+def test_conv_store_modes(cuda):
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 10, 8, 64, generator=g)
+    w = torch.randn(128, 64, 3, 3, generator=g) / 24
+    b = torch.randn(128, generator=g)
+    ref = _ref(x, w, b, 1, 1, "relu", None, False)
+    xd = x.to(cuda)
+    up = ops.conv2d_nhwc(xd, w, b, pad=1, act="relu", store="up2").cpu().permute(0, 3, 1, 2)
+    _check(up, F.interpolate(ref, scale_factor=2, mode="nearest"))
+    ps = ops.conv2d_nhwc(xd, w, b, pad=1, act="relu", store="pixshuf").cpu().permute(0, 3, 1, 2)
+    _check(ps, F.pixel_shuffle(ref, 2))
+    nc = ops.conv2d_nhwc(xd, w, b, pad=1, act="relu", store="nchw").cpu()
+    _check(nc, ref)
+
+
+def test_conv_full_size_layer_property(cuda):
+    """Full-size YOLO layer (128->256 @52x52, the 11x class): linearity in the input,
+    a size-independent property -- conv(a*x1 + x2) == a*conv(x1) + conv(x2) for a linear epilogue."""
+    g = torch.Generator().manual_seed(11)
+    x1 = torch.randn(1, 52, 52, 128, generator=g).to(cuda)
+    x2 = torch.randn(1, 52, 52, 128, generator=g).to(cuda)
+    w = torch.randn(256, 128, 3, 3, generator=g) / 34
+    y1 = ops.conv2d_nhwc(x1, w, None, pad=1)
+    y2 = ops.conv2d_nhwc(x2, w, None, pad=1)
+    y3 = ops.conv2d_nhwc(2.0 * x1 + x2, w, None, pad=1)
+    assert float((y3 - (2.0 * y1 + y2)).abs().max()) < 5e-5
+    # and a spot check of 64 outputs against the definition
+    ref = F.conv2d(x1.cpu().permute(0, 3, 1, 2), w, padding=1)
+    _check(y1.cpu().permute(0, 3, 1, 2)[:, ::37, ::13, ::11], ref[:, ::37, ::13, ::11])

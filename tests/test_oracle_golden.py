@@ -1,0 +1,94 @@
+"""Pins the CPU oracle (oracle/) against golden vectors produced by the REFERENCE's own
+Python (tools/make_golden.py).  Runs without a GPU.  torch-CPU kernels may differ between
+machines in the last bits, so float comparisons carry a small tolerance; integer results
+(arg-max indices, key-point pixels, u8 images) must be exact."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import helpers
+from betapose_amd import weights as W
+from oracle import kpd_ref, post_ref, yolo_ref
+
+
+@pytest.fixture(scope="module")
+def pipe():
+    return helpers.golden("pipeline.npz")
+
+
+@pytest.fixture(scope="module")
+def post():
+    return helpers.golden("post.npz")
+
+
+def test_oracle_yolo_matches_reference(pipe):
+    blocks = helpers.yolo_blocks()
+    convs = W.split_darknet_stream(blocks, helpers.yolo_stream())
+    fr = helpers.frames()[0]
+    x = helpers.yolo_input_from_frame(fr)
+    assert np.allclose(x.numpy().ravel()[pipe["in_samp"]], pipe["f0_yolo_in_samp"], atol=0)
+    assert int(torch.round(x * 255).long().sum()) == int(pipe["f0_yolo_in_u8sum"])
+    pred = yolo_ref.darknet_forward(blocks, convs, x)
+    np.testing.assert_allclose(pred[0].numpy()[pipe["row_samp"]], pipe["f0_pred_rows"], rtol=1e-5, atol=1e-4)
+    assert int(torch.argmax(pred[0, :, 4])) == int(pipe["f0_obj_argmax"])
+    assert int(yolo_ref.select_index(pred, 0.01)[0]) == int(pipe["f0_obj_argmax"])
+    dets = yolo_ref.write_results(pred, 0.01, 80)
+    np.testing.assert_allclose(dets.numpy(), pipe["f0_det_row"], rtol=1e-5, atol=1e-4)
+    im_dim = torch.tensor([[640.0, 480.0, 640.0, 480.0]])
+    boxes, scores = yolo_ref.rescale_boxes(dets, im_dim, 416)
+    np.testing.assert_allclose(boxes.numpy(), pipe["f0_boxes"], rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(scores.numpy(), pipe["f0_scores"], rtol=1e-5)
+    assert yolo_ref.write_results(pred, 0.9999, 80) == 0
+
+
+def test_oracle_crop_matches_reference(pipe):
+    for i, fr in enumerate(helpers.frames(int(pipe["n_frames"]))):
+        k = "f%d_" % i
+        inps, pt1, pt2 = post_ref.crop_from_dets_frame(fr, torch.from_numpy(pipe[k + "boxes"]))
+        np.testing.assert_array_equal(pt1.numpy(), pipe[k + "pt1"])
+        np.testing.assert_array_equal(pt2.numpy(), pipe[k + "pt2"])
+        np.testing.assert_allclose(inps.numpy().ravel()[pipe["crop_samp"]], pipe[k + "crop_samp"], atol=1e-6)
+        assert abs(float(inps.double().sum()) - float(pipe[k + "crop_sum"])) < 1e-2
+
+
+def test_oracle_kpd_matches_reference(pipe):
+    sd = helpers.kpd_state_dict()
+    inps, _, _ = post_ref.crop_from_dets_frame(helpers.frames()[0], torch.from_numpy(pipe["f0_boxes"]))
+    hm = kpd_ref.fastpose_forward(sd, inps)
+    np.testing.assert_allclose(hm.numpy().ravel()[pipe["hm_samp"]], pipe["f0_hm_samp"], atol=2e-5)
+    assert np.array_equal(hm.view(50, -1).argmax(1).numpy(), pipe["f0_kp_idx"])
+
+
+def test_oracle_get_prediction_and_nms_match_reference(pipe, post):
+    hms = torch.from_numpy(post["gp_hms"].astype(np.float32))
+    a, b, c = post_ref.get_prediction(hms, torch.from_numpy(post["gp_pt1"]), torch.from_numpy(post["gp_pt2"]))
+    np.testing.assert_array_equal(a.numpy(), post["gp_preds_hm"])
+    np.testing.assert_allclose(b.numpy(), post["gp_preds_img"], rtol=1e-6, atol=1e-5)
+    np.testing.assert_array_equal(c.numpy(), post["gp_maxval"])
+    res = post_ref.pose_nms(torch.from_numpy(post["nms_in_boxes"]), torch.from_numpy(post["nms_in_scores"]),
+                            torch.from_numpy(post["nms_in_poses"]), torch.from_numpy(post["nms_in_pscores"]))
+    assert len(res) == int(post["nms_out_n"])
+    for j, r in enumerate(res):
+        np.testing.assert_allclose(r["keypoints"].numpy(), post["nms_out%d_kp" % j], rtol=1e-6, atol=1e-5)
+        np.testing.assert_allclose(r["kp_score"].numpy(), post["nms_out%d_score" % j], rtol=1e-6, atol=1e-6)
+        assert abs(float(r["proposal_score"]) - float(post["nms_out%d_prop" % j])) < 1e-5
+        np.testing.assert_array_equal(r["bbox"].numpy(), post["nms_out%d_bbox" % j])
+    # the n = 1 pipeline case
+    for i in range(int(pipe["n_frames"])):
+        k = "f%d_" % i
+        res = post_ref.pose_nms(torch.from_numpy(pipe[k + "boxes"]), torch.from_numpy(pipe[k + "scores"]),
+                                torch.from_numpy(pipe[k + "preds_img"]), torch.from_numpy(pipe[k + "preds_scores"]))
+        assert len(res) == int(pipe[k + "nms_n"])
+        if res:
+            np.testing.assert_allclose(res[0]["keypoints"].numpy(), pipe[k + "nms_kp"], rtol=1e-6, atol=1e-5)
+            np.testing.assert_allclose(res[0]["kp_score"].numpy(), pipe[k + "nms_score"], rtol=1e-6, atol=1e-6)
+
+
+def test_oracle_metrics_match_reference(post):
+    assert abs(post_ref.add_err(post["m_gt"], post["m_est"], post["m_model"]) - float(post["m_add"])) < 1e-12
+    from betapose_amd.synth import CAM_K
+    assert abs(post_ref.projection_error_2d(post["m_gt"], post["m_est"], post["m_model"], CAM_K) - float(post["m_proj"])) < 1e-9
+    assert abs(post_ref.iou([10, 10, 110, 210], [30, 40, 100, 260]) - float(post["m_iou"][0])) < 1e-12
+    assert post_ref.iou([10, 10, 50, 50], [60, 60, 80, 80]) == float(post["m_iou"][1]) == 0.0
