@@ -1,0 +1,273 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/sec of the Betapose per-frame inference hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+One "step" = one pass of the hot path over one batch (default batch 1 = BASELINE.json
+configs[1]) of synthetic 640x480 BGR u8 frames that are already resident in HBM:
+  device (one hipGraph): Pillow-exact bicubic stretch to 416^2 -> YOLOv3 (fp32 MFMA) ->
+      decode + arg-max objectness -> box rescale + crop 320x256 -> FastPose (SE-ResNet-101 + DUC)
+      -> heat-map arg-max -> 316-float record
+  host: D2H of the record, key-point decoding, pPose-NMS, PnP  (software-pipelined one step deep)
+Weights are seeded random tensors of the reference architectures (no checkpoints ship).
+Frames shard by image: each rank runs its own frames (weak scaling), weights are broadcast from
+rank 0 over RCCL at start-up and the per-frame result records are all-gathered at the end.
+
+Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel, measured live with
+HIP events) and "cpu_baseline" (oracle on the host cores, N=1 only, bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+TILE_NAMES = {0: "1, 1", 1: "2, 1"}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=1, help="frames per step (1 = the reference's own batch)")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--fixed-box", action="store_true", help="deterministic crop box (220,140,420,340)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--pool", type=int, default=8, help="distinct synthetic frames per rank")
+    return ap.parse_args()
+
+
+def cpu_baseline(seconds: float, kp3d, cam_K):
+    """The oracle (torch-CPU / numpy restatement of the reference path) timed on this box's host cores."""
+    import torch
+    from PIL import Image
+    from betapose_amd import cfg as C, synth, weights as W
+    from oracle import kpd_ref, post_ref, yolo_ref
+    torch.set_num_threads(os.cpu_count() or 1)
+    blocks = C.parse_cfg_text(C.yolov3_single_cfg_text())
+    convs = W.split_darknet_stream(blocks, synth.synth_yolo_stream(1, blocks))
+    sd = {k: torch.from_numpy(v) for k, v in synth.synth_fastpose_state_dict(2).items()}
+    for c in convs:   # tensors once, not per frame
+        for k in list(c.keys()):
+            if isinstance(c[k], np.ndarray):
+                c[k] = np.ascontiguousarray(c[k])
+    im_dim = torch.tensor([[640.0, 480.0, 640.0, 480.0]])
+
+    def one(frame):
+        img = Image.fromarray(np.ascontiguousarray(frame[:, :, ::-1])).resize((416, 416), 3)
+        x = torch.from_numpy(np.asarray(img, dtype=np.uint8).transpose(2, 0, 1).copy()).float().div(255).unsqueeze(0)
+        pred = yolo_ref.darknet_forward(blocks, convs, x)
+        dets = yolo_ref.write_results(pred, 0.01, 80)
+        if isinstance(dets, int):
+            return None
+        boxes, scores = yolo_ref.rescale_boxes(dets, im_dim, 416)
+        inps, pt1, pt2 = post_ref.crop_from_dets_frame(frame, boxes)
+        hm = kpd_ref.fastpose_forward(sd, inps)
+        _, preds_img, preds_scores = post_ref.get_prediction(hm, pt1, pt2)
+        res = post_ref.pose_nms(boxes, scores, preds_img, preds_scores)
+        if res:
+            post_ref.pnp_least_squares(kp3d, res[0]["keypoints"].numpy(), cam_K)
+        return res
+
+    frames = synth.synth_frames(4, 1234)
+    one(frames[0])   # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        one(frames[n % len(frames)])
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or n >= 64:
+            break
+    return {"value": n / el, "unit": "frames/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d synthetic 640x480 frames through oracle/ (PIL resize, torch-CPU fp32 YOLOv3+FastPose, "
+                      "getPrediction, pose_nms, scipy PnP) in %.1f s" % (n, el),
+            "cpu_model": _cpu_model()}
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def roofline(det, pose, batch):
+    """Dominant kernel = the conv_igemm instantiation with the largest summed device time; its achieved
+    TFLOP/s = algorithmic FLOPs per launch / mean launch duration (HIP events around the kernel itself)."""
+    groups = {}
+    total_ms = 0.0
+    for net in (det, pose):
+        ms, info = net.profile(batch=batch, iters=10)
+        flops, _bytes = net.op_stats()
+        total_ms += float(ms.sum())
+        for i in range(len(ms)):
+            if not info[i, 0]:
+                continue
+            key = (int(info[i, 1]), int(info[i, 2]))
+            g = groups.setdefault(key, {"ms": 0.0, "flops": 0.0, "launches": 0, "bytes": 0.0})
+            g["ms"] += float(ms[i])
+            g["flops"] += float(flops[i]) * batch
+            g["bytes"] += float(_bytes[i])
+            g["launches"] += 1
+    key = max(groups, key=lambda k: groups[k]["ms"])
+    g = groups[key]
+    conv_ms = sum(v["ms"] for v in groups.values())
+    conv_flops = sum(v["flops"] for v in groups.values())
+    achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12
+    return {
+        "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+        "kernel": "bp::conv_igemm_kernel<%s, %s>" % (TILE_NAMES.get(key[0], "?"), "true" if key[1] else "false"),
+        "launches_per_step": g["launches"], "avg_launch_us": round(g["ms"] / g["launches"] * 1e3, 2),
+        "flops_per_launch": g["flops"] / g["launches"],
+        "all_conv": {"achieved": round(conv_flops / (conv_ms * 1e-3) / 1e12, 2), "ms_per_step": round(conv_ms, 4),
+                     "gflop_per_step": round(conv_flops / 1e9, 2)},
+        "device_ms_per_step_eager_sum": round(total_ms, 4),
+    }
+
+
+def main():
+    a = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+    from betapose_amd import _lib, cfg as C, synth
+    from betapose_amd.darknet import Darknet
+    from betapose_amd.kpd import FastPoseHIP
+    from betapose_amd.pipeline import FramePipeline, finish_record
+    from betapose_amd.weights import fastpose_stream_from_state_dict
+
+    _lib.require_gpu()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    # ---- weights: rank 0 builds the two fp32 streams, everyone else receives them over RCCL
+    blocks = C.parse_cfg_text(C.yolov3_single_cfg_text())
+    if rank == 0:
+        ys = torch.from_numpy(synth.synth_yolo_stream(1, blocks)).to(dev)
+        ks = torch.from_numpy(fastpose_stream_from_state_dict(synth.synth_fastpose_state_dict(2))).to(dev)
+        sizes = torch.tensor([ys.numel(), ks.numel()], device=dev)
+    else:
+        sizes = torch.zeros(2, dtype=torch.long, device=dev)
+    if world > 1:
+        dist.broadcast(sizes, 0)
+        if rank != 0:
+            ys = torch.empty(int(sizes[0]), device=dev)
+            ks = torch.empty(int(sizes[1]), device=dev)
+        dist.broadcast(ys, 0)
+        dist.broadcast(ks, 0)
+    det = Darknet("yolo/cfg/yolov3-single.cfg", reso=416, max_batch=a.batch, device=local)
+    det.load_stream(ys.cpu().numpy())
+    pose = FastPoseHIP.from_stream(ks.cpu().numpy(), n_classes=50, max_batch=a.batch, device=local)
+    del ys, ks
+    det.cuda()
+    pose.cuda()
+
+    pipe = FramePipeline(det, pose, 480, 640, batch=a.batch, confidence=0.01, num_classes=80, use_graph=not a.no_graph)
+    if a.fixed_box:
+        pipe.set_fixed_box([220, 140, 420, 340])
+    kp3d, cam_K = synth.synth_kp3d(50), synth.CAM_K
+
+    # ---- inputs resident in HBM: a pool of distinct frames per rank
+    pool = [torch.from_numpy(np.stack(synth.synth_frames(a.batch, 1234 + 1000 * rank + 37 * j))).to(dev)
+            for j in range(a.pool)]
+    pinned = [torch.empty((a.batch, pipe.results.shape[1]), dtype=torch.float32).pin_memory() for _ in range(2)]
+    events = [torch.cuda.Event(), torch.cuda.Event()]
+    records = np.zeros((a.steps, a.batch, pipe.results.shape[1]), np.float32)
+    stats = {"det": 0, "pose": 0}
+
+    def issue(i):
+        pipe.frames.copy_(pool[i % a.pool], non_blocking=True)
+        pipe.enqueue()
+        pinned[i & 1].copy_(pipe.results, non_blocking=True)
+        events[i & 1].record()
+
+    def finish(i, keep):
+        events[i & 1].synchronize()
+        rec = pinned[i & 1].numpy()
+        for b in range(a.batch):
+            out = finish_record(rec[b], "%06d.png" % (i * a.batch + b), kp3d, cam_K)
+            if keep:
+                stats["det"] += out.get("boxes") is not None
+                stats["pose"] += len(out["result"]) > 0
+        if keep:
+            records[i] = rec
+
+    def run(nsteps, keep):
+        for i in range(nsteps):
+            issue(i)
+            if i:
+                finish(i - 1, keep)
+        finish(nsteps - 1, keep)
+
+    run(max(a.warmup, 1), False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(a.steps, True)
+    gathered = None
+    if world > 1:   # xGMI gather of detections only: [steps, batch, 316] floats per rank
+        mine = torch.from_numpy(records).to(dev)
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t[0])
+
+    out = None
+    if rank == 0:
+        frames_total = world * a.steps * a.batch
+        out = {
+            "metric": "frames/sec (640x480, 50-kp KPD)", "value": round(frames_total / el, 2), "unit": "frames/sec",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(el / a.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (seeded 640x480 BGR u8 frames resident in HBM; seeded random weights of the "
+                    "reference architectures)",
+            "config": {"workload": "BASELINE configs[1]: single-object frame, YOLOv3 416x416 (1 class) -> 1 crop "
+                                   "320x256 -> FastPose SE-ResNet-101+DUC (the reference's real KPD, SURVEY F1) -> "
+                                   "50 kp arg-max -> pPose-NMS -> PnP",
+                       "batch": a.batch, "global_batch": a.batch * world, "frame": "640x480x3 u8",
+                       "parallelism": "frames sharded by image, 1 process per GPU (dp%d)" % world,
+                       "hip_graph": not a.no_graph, "fixed_box": a.fixed_box,
+                       "graph_nodes": pipe.kernel_count()},
+            "detections": stats["det"], "poses": stats["pose"],
+        }
+    if rank == 0 and not a.no_roofline:
+        out["roofline"] = roofline(det, pose, a.batch)
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(a.cpu_seconds, kp3d, cam_K)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -53,7 +53,10 @@ PROTOTYPES = {
     "bp_resize_bicubic": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "bp_conv2d": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
                             C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, c_float_p, vp]),
-    "bp_pipeline_create": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.POINTER(vp)]),
+    "bp_pipeline_create": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, vp, vp, vp, C.POINTER(vp)]),
+    "bp_pipeline_kernel_count": (C.c_int, [vp]),
+    "bp_yolo_profile": (C.c_int, [vp, C.c_int, C.c_int, c_float_p, c_int_p, C.c_int, vp]),
+    "bp_kpd_profile": (C.c_int, [vp, C.c_int, C.c_int, c_float_p, c_int_p, C.c_int, vp]),
     "bp_pipeline_destroy": (None, [vp]),
     "bp_pipeline_frames": (vp, [vp]),
     "bp_pipeline_results": (vp, [vp]),

@@ -68,6 +68,10 @@ struct ConvParams {
 // tile configuration ids for launch_conv
 enum ConvTile : int { TILE_64x64 = 0, TILE_128x64 = 1, TILE_32x64 = 2, TILE_64x32 = 3 };
 
+// when non-null, launch_conv brackets the implicit-GEMM kernel itself (not the split-K reduce) with these events
+struct ConvProfHook { hipEvent_t e0, e1; };
+extern thread_local ConvProfHook* g_conv_prof;
+
 void launch_conv(const ConvParams& p, int tile, hipStream_t s);
 int conv_tile_bm(int tile);
 int conv_tile_bn(int tile);

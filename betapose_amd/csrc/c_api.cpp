@@ -221,6 +221,16 @@ static int op_stats(const bp::Net& n, double* flops, double* bytes, int cap) {
 }
 int bp_yolo_op_stats(const bp_yolo* y, double* flops, double* bytes, int cap) { return op_stats(*y->net, flops, bytes, cap); }
 int bp_kpd_op_stats(const bp_kpd* k, double* flops, double* bytes, int cap) { return op_stats(*k->net, flops, bytes, cap); }
+int bp_yolo_profile(bp_yolo* y, int batch, int iters, float* ms, int* info, int cap, void* stream) {
+    BP_TRY
+    return y->net->profile(batch, iters, ms, info, cap, (hipStream_t)stream);
+    BP_CATCH
+}
+int bp_kpd_profile(bp_kpd* k, int batch, int iters, float* ms, int* info, int cap, void* stream) {
+    BP_TRY
+    return k->net->profile(batch, iters, ms, info, cap, (hipStream_t)stream);
+    BP_CATCH
+}
 size_t bp_yolo_device_bytes(const bp_yolo* y) { return y->net->device_bytes(); }
 size_t bp_kpd_device_bytes(const bp_kpd* k) { return k->net->device_bytes(); }
 
@@ -342,7 +352,7 @@ static void pipeline_enqueue(bp_pipeline* p, hipStream_t s) {
 }
 
 int bp_pipeline_create(bp_yolo* y, bp_kpd* k, int frame_h, int frame_w, int batch, float conf, int num_classes,
-                       bp_pipeline** out) {
+                       uint8_t* d_frames, float* d_results, float* d_hm, bp_pipeline** out) {
     BP_TRY
     BP_CHECK(y && k && out, "null argument");
     BP_CHECK(batch >= 1 && batch <= y->net->max_batch() && batch <= k->net->max_batch(), "pipeline batch > engine max_batch");
@@ -351,13 +361,13 @@ int bp_pipeline_create(bp_yolo* y, bp_kpd* k, int frame_h, int frame_w, int batc
     std::unique_ptr<bp_pipeline> p(new bp_pipeline);
     p->y = y; p->k = k; p->H = frame_h; p->W = frame_w; p->batch = batch; p->conf = conf; p->num_classes = num_classes;
     const int reso = y->net->reso();
-    p->frames = (uint8_t*)p->arena.alloc_bytes((size_t)batch * frame_h * frame_w * 3);
+    p->frames = d_frames ? d_frames : (uint8_t*)p->arena.alloc_bytes((size_t)batch * frame_h * frame_w * 3);
     p->tmp = (uint8_t*)p->arena.alloc_bytes((size_t)batch * frame_h * reso * 3);
-    p->results = p->arena.alloc((size_t)batch * BP_RESULT_FLOATS);
+    p->results = d_results ? d_results : p->arena.alloc((size_t)batch * BP_RESULT_FLOATS);
     p->sel = p->arena.alloc((size_t)batch * 8);
     p->pts = p->arena.alloc((size_t)batch * 8);
     p->kp = p->arena.alloc((size_t)batch * 300);
-    p->hm = p->arena.alloc((size_t)batch * 50 * k->net->out_h() * k->net->out_w());
+    p->hm = d_hm ? d_hm : p->arena.alloc((size_t)batch * 50 * k->net->out_h() * k->net->out_w());
     p->fixed_box = p->arena.alloc((size_t)batch * 4);
     const bp::ResizePlan ph = bp::make_bicubic_plan(frame_w, reso), pv = bp::make_bicubic_plan(frame_h, reso);
     p->ksh = ph.ksize; p->ksv = pv.ksize;
@@ -378,6 +388,12 @@ void bp_pipeline_destroy(bp_pipeline* p) { delete p; }
 uint8_t* bp_pipeline_frames(bp_pipeline* p) { return p->frames; }
 float* bp_pipeline_results(bp_pipeline* p) { return p->results; }
 float* bp_pipeline_heatmaps(bp_pipeline* p) { return p->hm; }
+int bp_pipeline_kernel_count(bp_pipeline* p) {
+    if (!p->graph) return -1;
+    size_t n = 0;
+    if (hipGraphGetNodes(p->graph, nullptr, &n) != hipSuccess) return -1;
+    return (int)n;
+}
 
 static void drop_graph(bp_pipeline* p) {
     if (p->exec) { (void)hipGraphExecDestroy(p->exec); p->exec = nullptr; }

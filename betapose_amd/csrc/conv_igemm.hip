@@ -250,6 +250,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p) 
     }
 }
 
+thread_local ConvProfHook* g_conv_prof = nullptr;
+
 int conv_tile_bm(int tile) { return tile == TILE_128x64 ? 128 : 64; }
 int conv_tile_bn(int tile) { return 64; }
 
@@ -268,10 +270,12 @@ void launch_conv(const ConvParams& p, int tile, hipStream_t s) {
     BP_CHECK(p.CoutPad % 64 == 0, "CoutPad must be a multiple of 64");
     BP_CHECK(p.Kpad % BK == 0 && p.nchunks == p.Kpad / BK, "Kpad");
     BP_CHECK(p.splits >= 1 && (p.splits == 1 || p.partial != nullptr), "split-K workspace");
+    if (g_conv_prof) BP_HIP(hipEventRecord(g_conv_prof->e0, s));
     switch (tile) {
         case TILE_128x64: launch_t<2, 1>(p, s); break;
         default: launch_t<1, 1>(p, s); break;
     }
+    if (g_conv_prof) BP_HIP(hipEventRecord(g_conv_prof->e1, s));
     BP_HIP(hipGetLastError());
     if (p.splits > 1) {
         const long long total = (long long)p.M * p.Cout;

@@ -115,50 +115,95 @@ void Net::finalize() {
     partial_ = need ? arena_.alloc(need) : nullptr;
 }
 
+void Net::run_op(const Op& op, int batch, hipStream_t s) {
+    switch (op.type) {
+        case OP_CONV: {
+            ConvParams p = op.conv;
+            p.N = batch;
+            p.M = batch * p.OH * p.OW;
+            int tile, splits, cps;
+            choose_launch(op, batch, force_tile_, sk_target_, sk_min_chunks_, &tile, &splits, &cps);
+            while (splits > 1 && (size_t)splits * p.M * p.CoutPad > partial_floats_) {
+                --splits;
+                cps = (p.nchunks + splits - 1) / splits;
+                splits = (p.nchunks + cps - 1) / cps;
+            }
+            p.splits = splits; p.chunks_per_split = cps; p.partial = partial_;
+            launch_conv(p, tile, s);
+        } break;
+        case OP_MAXPOOL:
+            launch_maxpool3s2p1(op.a, op.out, batch, op.H, op.W, op.C, op.OH, op.OW, s);
+            break;
+        case OP_ADD:
+            launch_add(op.a, op.a_ld, op.b, op.b_ld, op.out, op.out_ld, (long long)batch * op.H * op.W, op.C, s);
+            break;
+        case OP_UPSAMPLE:
+            launch_upsample2(op.a, op.a_ld, op.out, op.out_ld, batch, op.H, op.W, op.C, s);
+            break;
+        case OP_COPYCH:
+            launch_copy_channels(op.a, op.a_ld, op.out, op.out_ld, (long long)batch * op.H * op.W, op.C, s);
+            break;
+        case OP_PIXSHUF:
+            launch_pixel_shuffle2(op.a, op.out, batch, op.H, op.W, op.C, s);
+            break;
+        case OP_AVGPOOL:
+            launch_avgpool(op.a, op.a_ld, op.out, batch, op.H * op.W, op.C, s);
+            break;
+        case OP_FC:
+            launch_fc(op.a, op.w, op.bias, op.out, batch, op.Cin, op.Cout, op.act, s);
+            break;
+        default:
+            throw Error("unknown op");
+    }
+}
+
 void Net::run_ops(int batch, hipStream_t s) {
     BP_CHECK(batch >= 1 && batch <= max_batch_, "batch out of range");
-    for (const Op& op : ops_) {
-        switch (op.type) {
-            case OP_CONV: {
-                ConvParams p = op.conv;
-                p.N = batch;
-                p.M = batch * p.OH * p.OW;
-                int tile, splits, cps;
-                choose_launch(op, batch, force_tile_, sk_target_, sk_min_chunks_, &tile, &splits, &cps);
-                while (splits > 1 && (size_t)splits * p.M * p.CoutPad > partial_floats_) {
-                    --splits;
-                    cps = (p.nchunks + splits - 1) / splits;
-                    splits = (p.nchunks + cps - 1) / cps;
-                }
-                p.splits = splits; p.chunks_per_split = cps; p.partial = partial_;
-                launch_conv(p, tile, s);
-            } break;
-            case OP_MAXPOOL:
-                launch_maxpool3s2p1(op.a, op.out, batch, op.H, op.W, op.C, op.OH, op.OW, s);
-                break;
-            case OP_ADD:
-                launch_add(op.a, op.a_ld, op.b, op.b_ld, op.out, op.out_ld, (long long)batch * op.H * op.W, op.C, s);
-                break;
-            case OP_UPSAMPLE:
-                launch_upsample2(op.a, op.a_ld, op.out, op.out_ld, batch, op.H, op.W, op.C, s);
-                break;
-            case OP_COPYCH:
-                launch_copy_channels(op.a, op.a_ld, op.out, op.out_ld, (long long)batch * op.H * op.W, op.C, s);
-                break;
-            case OP_PIXSHUF:
-                launch_pixel_shuffle2(op.a, op.out, batch, op.H, op.W, op.C, s);
-                break;
-            case OP_AVGPOOL:
-                launch_avgpool(op.a, op.a_ld, op.out, batch, op.H * op.W, op.C, s);
-                break;
-            case OP_FC:
-                launch_fc(op.a, op.w, op.bias, op.out, batch, op.Cin, op.Cout, op.act, s);
-                break;
-            default:
-                throw Error("unknown op");
+    for (const Op& op : ops_) run_op(op, batch, s);
+    BP_HIP(hipGetLastError());
+}
+
+int Net::profile(int batch, int iters, float* ms, int* info, int cap, hipStream_t s) {
+    const int n = (int)ops_.size();
+    if (!ms || cap < n) return n;
+    BP_CHECK(batch >= 1 && batch <= max_batch_ && iters >= 1, "profile arguments");
+    std::vector<hipEvent_t> ev(2 * n);
+    for (auto& e : ev) BP_HIP(hipEventCreate(&e));
+    std::vector<double> acc(n, 0.0);
+    run_ops(batch, s);   // warm
+    for (int it = 0; it < iters; ++it) {
+        for (int i = 0; i < n; ++i) {
+            if (ops_[i].type == OP_CONV) {
+                ConvProfHook hook{ev[2 * i], ev[2 * i + 1]};
+                g_conv_prof = &hook;
+                try { run_op(ops_[i], batch, s); } catch (...) { g_conv_prof = nullptr; throw; }
+                g_conv_prof = nullptr;
+            } else {
+                BP_HIP(hipEventRecord(ev[2 * i], s));
+                run_op(ops_[i], batch, s);
+                BP_HIP(hipEventRecord(ev[2 * i + 1], s));
+            }
+        }
+        BP_HIP(hipStreamSynchronize(s));
+        for (int i = 0; i < n; ++i) {
+            float t = 0;
+            BP_HIP(hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]));
+            acc[i] += t;
         }
     }
-    BP_HIP(hipGetLastError());
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    for (int i = 0; i < n; ++i) {
+        ms[i] = (float)(acc[i] / iters);
+        if (info) {
+            int tile = 0, splits = 1, cps = 0, vec = 0, conv = ops_[i].type == OP_CONV;
+            if (conv) {
+                choose_launch(ops_[i], batch, force_tile_, sk_target_, sk_min_chunks_, &tile, &splits, &cps);
+                vec = (ops_[i].conv.Cin % 32 == 0) && (ops_[i].conv.in_ld % 4 == 0);
+            }
+            info[4 * i] = conv; info[4 * i + 1] = tile; info[4 * i + 2] = vec; info[4 * i + 3] = splits;
+        }
+    }
+    return n;
 }
 
 void Net::tap_copy(int i, int batch, float* d_out_nchw, hipStream_t s) const {

@@ -59,6 +59,9 @@ public:
     virtual ~Net() = default;
     int max_batch() const { return max_batch_; }
     void run_ops(int batch, hipStream_t s);
+    void run_op(const Op& op, int batch, hipStream_t s);
+    // eager profiling pass: mean device ms per op; info[i] = {is_conv, tile, vec, splits}
+    int profile(int batch, int iters, float* ms, int* info, int cap, hipStream_t s);
     size_t device_bytes() const { return arena_.total_bytes(); }
     const std::vector<Op>& ops() const { return ops_; }
     // test hook: copy a recorded intermediate (NHWC view) to a dense NCHW device buffer

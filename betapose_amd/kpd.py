@@ -140,6 +140,18 @@ class FastPoseHIP:
         self._ensure()
         _lib.lib().bp_kpd_set_policy(self._h, sk_target_blocks, sk_min_chunks, force_tile)
 
+    def profile(self, batch: int = 1, iters: int = 10):
+        """Eager pass with hipEvent pairs per op -> (ms[n_ops], info[n_ops,4] = is_conv, tile, vec, splits)."""
+        self._ensure()
+        L = _lib.lib()
+        n = L.bp_kpd_profile(self._h, batch, iters, None, None, 0, _lib.current_stream())
+        ms = (C.c_float * n)()
+        info = (C.c_int * (4 * n))()
+        rc = L.bp_kpd_profile(self._h, batch, iters, ms, info, n, _lib.current_stream())
+        if rc < 0:
+            _lib.check(rc)
+        return np.array(ms, dtype=np.float64), np.array(info, dtype=np.int64).reshape(n, 4)
+
     def op_stats(self):
         self._ensure()
         n = _lib.lib().bp_kpd_op_stats(self._h, None, None, 0)

@@ -1,0 +1,110 @@
+"""The fused per-frame path: frames resident in HBM -> 6D pose.
+
+Device part (one hipGraph, ``bp_pipeline_run``): Pillow-exact bicubic stretch ->
+YOLOv3 -> decode + arg-max objectness -> box rescale + crop -> FastPose -> heat-map
+arg-max; 316 floats per frame come back.  Host part (``finish_record``): key-point
+decoding, pPose-NMS (n = 1), key-point pruning, PnP.  Together they replace
+``DetectionLoader.update`` -> ``DetectionProcessor.update`` -> the KPD main loop ->
+``DataWriter.update`` of the reference (dataloader.py:330-401,438-457,678-741;
+betapose_evaluate.py:145-176) for the evaluation stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional
+
+import numpy as np
+
+from . import _lib
+from .eval import decode_keypoints
+from .ops import solve_pnp
+from .pPose_nms import pose_nms
+
+RESULT_FLOATS = _lib.RESULT_FLOATS
+
+
+class FramePipeline:
+    def __init__(self, det_model, pose_model, frame_h: int = 480, frame_w: int = 640, batch: int = 1,
+                 confidence: float = 0.01, num_classes: int = 80, use_graph: bool = True, keep_heatmaps: bool = False):
+        import torch
+        _lib.require_gpu()
+        self.det, self.pose = det_model, getattr(pose_model, "pyranet", pose_model)
+        self.H, self.W, self.batch = int(frame_h), int(frame_w), int(batch)
+        self.use_graph = bool(use_graph)
+        dev = "cuda:%d" % self.det._device if self.det._device is not None else "cuda"
+        self.det.cuda()
+        self.pose.cuda()
+        dev = "cuda:%d" % self.det._device
+        self.frames = torch.zeros((self.batch, self.H, self.W, 3), dtype=torch.uint8, device=dev)
+        self.results = torch.zeros((self.batch, RESULT_FLOATS), dtype=torch.float32, device=dev)
+        self.heatmaps = torch.zeros((self.batch, 50, 80, 64), dtype=torch.float32, device=dev) if keep_heatmaps else None
+        h = C.c_void_p()
+        _lib.check(_lib.lib().bp_pipeline_create(self.det.handle, self.pose.handle, self.H, self.W, self.batch,
+                                                 float(confidence), int(num_classes), self.frames.data_ptr(),
+                                                 self.results.data_ptr(),
+                                                 self.heatmaps.data_ptr() if keep_heatmaps else None, C.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) is not None:
+                _lib.lib().bp_pipeline_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def set_fixed_box(self, box_xyxy=None):
+        """Throughput runs with a deterministic crop: box in frame pixels, or None."""
+        if box_xyxy is None:
+            _lib.check(_lib.lib().bp_pipeline_set_fixed_box(self._h, None))
+        else:
+            b = np.ascontiguousarray(box_xyxy, dtype=np.float32)
+            _lib.check(_lib.lib().bp_pipeline_set_fixed_box(self._h, b.ctypes.data))
+
+    def enqueue(self, stream: Optional[int] = None):
+        """Launch the device part on ``stream`` (default: torch's current stream).  ``self.frames`` must
+        already hold the batch; ``self.results`` is valid once the stream reaches this point."""
+        _lib.check(_lib.lib().bp_pipeline_run(self._h, int(self.use_graph), stream if stream is not None else _lib.current_stream()))
+
+    def kernel_count(self) -> int:
+        return _lib.lib().bp_pipeline_kernel_count(self._h)
+
+    def run(self, frames_bgr_u8) -> np.ndarray:
+        """Convenience: upload frames (numpy [B,H,W,3] u8 or cuda tensor), run, return records [B,316] (host)."""
+        import torch
+        f = frames_bgr_u8 if hasattr(frames_bgr_u8, "device") else torch.from_numpy(np.ascontiguousarray(frames_bgr_u8))
+        if f.dim() == 3:
+            f = f.unsqueeze(0)
+        self.frames.copy_(f, non_blocking=True)
+        self.enqueue()
+        return self.results.cpu().numpy()
+
+
+def finish_record(rec: np.ndarray, imgname: str, kp_3d: np.ndarray, cam_K: np.ndarray, left_number: int = 50) -> dict:
+    """Host tail for one frame: 316-float record -> the dict ``DataWriter.update`` appends to
+    ``final_result`` (dataloader.py:704-727): {'imgname', 'result', 'cam_R', 'cam_t'} (+ the raw boxes)."""
+    rec = np.ascontiguousarray(rec, dtype=np.float32)
+    idx = int(rec[:1].view(np.int32)[0])
+    if idx < 0:     # no detection: the reference forwards the frame with boxes=None and records nothing
+        return {"imgname": imgname, "result": [], "cam_R": [], "cam_t": [], "boxes": None}
+    boxes = rec[12:16].reshape(1, 4).copy()
+    scores = rec[5:6].reshape(1, 1).copy()
+    pt1, pt2 = rec[8:10].reshape(1, 2), rec[10:12].reshape(1, 2)
+    kp = rec[16:].reshape(1, 50, 6)
+    _, preds_img, preds_scores = decode_keypoints(kp, pt1, pt2)
+    result = pose_nms(boxes, scores, preds_img, preds_scores)
+    out = {"imgname": imgname, "result": result, "boxes": boxes, "scores": scores, "yolo_index": idx}
+    if result:
+        kp_score = np.array(result[0]["kp_score"][:, 0])
+        kp_2d = np.array(result[0]["keypoints"])
+        k3 = np.array(kp_3d)
+        while len(kp_2d) > left_number:          # dataloader.py:718-722
+            d = int(np.argmin(kp_score, axis=0))
+            kp_score = np.delete(kp_score, d)
+            kp_2d = np.delete(kp_2d, d, axis=0)
+            k3 = np.delete(k3, d, axis=0)
+        R, t = solve_pnp(k3, kp_2d, cam_K)
+        out.update({"cam_R": R, "cam_t": t})
+    else:
+        out.update({"cam_R": [], "cam_t": []})
+    return out

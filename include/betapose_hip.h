@@ -22,7 +22,7 @@
  *   bp_resize_bicubic      transforms.Resize((416,416), 3) + ToTensor      dataloader.py:94-99,162
  *   bp_pipeline_*          DetectionLoader.update -> DetectionProcessor.update -> main loop
  *                          (dataloader.py:330-401,438-457; betapose_evaluate.py:145-176) fused on device
- *   bp_pose_nms1 / bp_solve_pnp   pose_nms (n = 1 fast path), pnp          pPose_nms.py:24-122; utils/utils.py:17-41
+ *   bp_solve_pnp           pnp (cv2.solvePnP + cv2.Rodrigues)                 utils/utils.py:17-41
  *
  * Weight streams.  "YOLO stream" = payload of a Darknet .weights file after its
  * header (train_YOLO/src/parser.c:1148-1174): per [convolutional] block in cfg order
@@ -93,6 +93,11 @@ int bp_kpd_set_policy(bp_kpd* k, int sk_target_blocks, int sk_min_chunks, int fo
 /* per-op static description: returns number of ops; fills up to cap entries of (flops, bytes) per image */
 int bp_yolo_op_stats(const bp_yolo* y, double* flops, double* bytes, int cap);
 int bp_kpd_op_stats(const bp_kpd* k, double* flops, double* bytes, int cap);
+/* eager run with hipEvent pairs around every fused-conv kernel (not its split-K reduce) and every other op:
+ * ms[i] = mean device time of op i over `iters` runs; info[i*4..] = (is_conv, tile id, vec path, splits).
+ * Returns the number of ops (arrays may be NULL to query). */
+int bp_yolo_profile(bp_yolo* y, int batch, int iters, float* ms, int* info, int cap, void* stream);
+int bp_kpd_profile(bp_kpd* k, int batch, int iters, float* ms, int* info, int cap, void* stream);
 size_t bp_yolo_device_bytes(const bp_yolo* y);
 size_t bp_kpd_device_bytes(const bp_kpd* k);
 
@@ -114,10 +119,13 @@ int bp_conv2d(const float* d_in, int N, int H, int W, int Cin, const float* h_w,
               float* d_out, int iters, float* ms_per_iter, void* stream);
 
 /* ---- whole frame on device: resize -> detector -> select -> crop -> KPD -> arg-max, optionally as one hipGraph ---- */
+/* d_frames [batch][H][W][3] u8 BGR, d_results [batch][BP_RESULT_FLOATS], d_hm [batch][50][80][64]: caller-owned
+ * device buffers (NULL -> allocated and owned by the pipeline). */
 int bp_pipeline_create(bp_yolo* y, bp_kpd* k, int frame_h, int frame_w, int batch, float conf, int num_classes,
-                       bp_pipeline** out);
+                       uint8_t* d_frames, float* d_results, float* d_hm, bp_pipeline** out);
 void bp_pipeline_destroy(bp_pipeline* p);
 uint8_t* bp_pipeline_frames(bp_pipeline* p);    /* device [batch][H][W][3] u8 BGR, caller fills */
+int bp_pipeline_kernel_count(bp_pipeline* p);   /* kernel launches per run (after the first graph capture) */
 float* bp_pipeline_results(bp_pipeline* p);     /* device [batch][BP_RESULT_FLOATS] */
 float* bp_pipeline_heatmaps(bp_pipeline* p);    /* device [batch][50][80][64] */
 int bp_pipeline_set_fixed_box(bp_pipeline* p, const float* box_xyxy_or_null);
