@@ -54,7 +54,9 @@ def cpu_baseline(seconds: float, kp3d, cam_K):
     from PIL import Image
     from betapose_amd import cfg as C, synth, weights as W
     from oracle import kpd_ref, post_ref, yolo_ref
-    torch.set_num_threads(os.cpu_count() or 1)
+    # torch-CPU conv scales to ~16 threads on this path and collapses beyond (256 threads: >100 s/frame on the
+    # EPYC 9575F box), so the baseline runs on min(16, cores) threads; that count is what "cores" reports
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     blocks = C.parse_cfg_text(C.yolov3_single_cfg_text())
     convs = W.split_darknet_stream(blocks, synth.synth_yolo_stream(1, blocks))
     sd = {k: torch.from_numpy(v) for k, v in synth.synth_fastpose_state_dict(2).items()}

@@ -79,6 +79,9 @@ def lib():
     with _lock:
         if _lib is not None:
             return _lib
+        # torch ships its own libamdhip64; load it FIRST so this library binds to the same HIP runtime
+        # (loading /opt/rocm's copy first leaves two runtimes in the process and ours then sees no device)
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             from .build import build
             build(verbose=False)

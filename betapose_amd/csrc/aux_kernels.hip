@@ -140,39 +140,54 @@ void launch_pixel_shuffle2(const float* in, float* out, int N, int H, int W, int
 }
 
 // ---------------------------------------------------------------- SE: global average pool + FC
-// grid (ceil(C/64), N), block 256 = 4 pixel-groups x 64 channels; lanes run over channels (coalesced NHWC)
-__global__ void avgpool_kernel(const float* __restrict__ in, int in_ld, float* __restrict__ out, int HW, int C) {
+// grid (ceil(C/64), P, N), block 256 = 4 pixel-groups x 64 channels; lanes run over channels (coalesced
+// NHWC).  Block (.,p,.) sums pixel slice p; out[(n*P + p)*C + c] holds the slice SUM (not mean): the first SE
+// linear layer adds the P partials and applies 1/HW, so the reduction order is fixed (deterministic).
+__global__ void avgpool_partial_kernel(const float* __restrict__ in, int in_ld, float* __restrict__ out, int HW, int C, int P) {
     __shared__ float red[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int g = threadIdx.x >> 6;
-    const int n = blockIdx.y;
+    const int p = blockIdx.y, n = blockIdx.z;
+    const int per = (HW + P - 1) / P;
+    const int lo = p * per, hi = min(HW, lo + per);
     float s = 0.f;
     if (c < C)
-        for (int p = g; p < HW; p += 4) s += in[((long long)n * HW + p) * in_ld + c];
+        for (int q = lo + g; q < hi; q += 4) s += in[((long long)n * HW + q) * in_ld + c];
     red[g][threadIdx.x & 63] = s;
     __syncthreads();
     if (g == 0 && c < C) {
         const float t = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-        out[(long long)n * C + c] = t / (float)HW;
+        out[((long long)n * P + p) * C + c] = t;
     }
 }
+int avgpool_parts(int HW) { return HW >= 2048 ? 64 : (HW >= 512 ? 32 : (HW >= 128 ? 8 : 2)); }
 void launch_avgpool(const float* in, int in_ld, float* out, int N, int HW, int C, hipStream_t s) {
-    hipLaunchKernelGGL(avgpool_kernel, dim3((C + 63) / 64, N), dim3(256), 0, s, in, in_ld, out, HW, C);
+    const int P = avgpool_parts(HW);
+    hipLaunchKernelGGL(avgpool_partial_kernel, dim3((C + 63) / 64, P, N), dim3(256), 0, s, in, in_ld, out, HW, C, P);
 }
 
 // one wavefront per output neuron; float4 weight stream (pure HBM-bound GEMV)
+// in_parts > 1: in is [N][in_parts][Cin] partial sums (see avgpool_partial_kernel), scaled by in_scale
 __global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                   const float* __restrict__ bias, float* __restrict__ out, int Cin,
-                                                  int Cout, int act) {
+                                                  int Cout, int act, int in_parts, float in_scale) {
     const int lane = threadIdx.x & 63;
     const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int n = blockIdx.y;
     if (o >= Cout) return;
     const float4* wr = reinterpret_cast<const float4*>(w + (long long)o * Cin);
-    const float4* xr = reinterpret_cast<const float4*>(in + (long long)n * Cin);
+    const float4* xr = reinterpret_cast<const float4*>(in + (long long)n * in_parts * Cin);
     float s = 0.f;
     for (int i = lane; i < (Cin >> 2); i += 64) {
-        const float4 a = wr[i], b = xr[i];
+        const float4 a = wr[i];
+        float4 b = xr[i];
+        if (in_parts > 1) {
+            for (int q = 1; q < in_parts; ++q) {
+                const float4 t = xr[(long long)q * (Cin >> 2) + i];
+                b.x += t.x; b.y += t.y; b.z += t.z; b.w += t.w;
+            }
+            b.x *= in_scale; b.y *= in_scale; b.z *= in_scale; b.w *= in_scale;
+        }
         s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
     }
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
@@ -184,9 +199,10 @@ __global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ in, c
     }
 }
 void launch_fc(const float* in, const float* w, const float* bias, float* out, int N, int Cin, int Cout, int act,
-               hipStream_t s) {
+               int in_parts, float in_scale, hipStream_t s) {
     BP_CHECK(Cin % 4 == 0, "fc: Cin % 4");
-    hipLaunchKernelGGL(fc_kernel, dim3((Cout + 3) / 4, N), dim3(256), 0, s, in, w, bias, out, Cin, Cout, act);
+    hipLaunchKernelGGL(fc_kernel, dim3((Cout + 3) / 4, N), dim3(256), 0, s, in, w, bias, out, Cin, Cout, act, in_parts,
+                       in_scale);
 }
 
 // ---------------------------------------------------------------- YOLO head decode (yolo/darknet.py:129-169)

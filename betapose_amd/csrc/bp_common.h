@@ -85,10 +85,13 @@ void launch_add(const float* a, int a_ld, const float* b, int b_ld, float* out, 
 void launch_upsample2(const float* in, int in_ld, float* out, int out_ld, int N, int H, int W, int C, hipStream_t s);
 void launch_copy_channels(const float* in, int in_ld, float* out, int out_ld, long long pixels, int C, hipStream_t s);
 void launch_pixel_shuffle2(const float* in, float* out, int N, int H, int W, int C, hipStream_t s);
+// out [N][P][C] per-slice sums, P = avgpool_parts(HW); the consumer (launch_fc, in_parts=P) finishes the mean
+int avgpool_parts(int HW);
 void launch_avgpool(const float* in, int in_ld, float* out, int N, int HW, int C, hipStream_t s);
-// out[b][o] = act(bias[o] + sum_i w[o][i]*in[b][i]);  act: 2 relu, 3 sigmoid
+// out[b][o] = act(bias[o] + sum_i w[o][i]*x[b][i]);  act: 2 relu, 3 sigmoid;
+// x = in (in_parts == 1) or in_scale * sum_p in[b][p][i]
 void launch_fc(const float* in, const float* w, const float* bias, float* out, int N, int Cin, int Cout,
-               int act, hipStream_t s);
+               int act, int in_parts, float in_scale, hipStream_t s);
 
 struct YoloHead {
     const float* t;  // NHWC [N][g][g][nA*attrs], ld = nA*attrs

@@ -23,6 +23,8 @@
 namespace bp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: stays in VGPRs (HIP's float4 struct
+                                                           // made hipcc park the prefetch registers in scratch)
 
 static constexpr int BK = 32;
 static constexpr int LDS_LD = 36;
@@ -79,16 +81,22 @@ __device__ __forceinline__ void epilogue_store(const ConvParams& p, int m, int n
 
 // one float4 (4 consecutive k) of im2col row for chunk c; zero outside the image / past Ktrue
 template <bool VEC>
-__device__ __forceinline__ float4 load_a_row(const ConvParams& p, int c, int cpt, int c4, int bh, int iy0, int ix0) {
-    float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+__device__ __forceinline__ f32x4 load_a_row(const ConvParams& p, int c, int cpt, int c4, int bh, int iy0, int ix0,
+                                             bool& ok_out) {
+    f32x4 out = {0.f, 0.f, 0.f, 0.f};
+    ok_out = true;
     if constexpr (VEC) {
         const int tap = c / cpt;
         const int ci0 = (c - tap * cpt) << 5;
         const int ky = tap / p.ksize;
         const int kx = tap - ky * p.ksize;
         const int iy = iy0 + ky, ix = ix0 + kx;
-        if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-            out = *reinterpret_cast<const float4*>(p.in + ((long long)(bh + iy) * p.W + ix) * p.in_ld + ci0 + c4 * 4);
+        // branch-free: out-of-image taps read a valid address and are zeroed by a select at LDS-store
+        // time, so the prefetch block is one basic block and nothing consumes the loads before the MFMAs
+        const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const long long off = ok ? ((long long)(bh + iy) * p.W + ix) * p.in_ld + ci0 + c4 * 4 : 0;
+        out = *reinterpret_cast<const f32x4*>(p.in + off);   // zeroed (if !ok) when parked in LDS, after the MFMAs
+        ok_out = ok;
     } else {
         float v[4];
 #pragma unroll
@@ -106,7 +114,7 @@ __device__ __forceinline__ float4 load_a_row(const ConvParams& p, int c, int cpt
             }
             v[e] = x;
         }
-        out = make_float4(v[0], v[1], v[2], v[3]);
+        out = f32x4{v[0], v[1], v[2], v[3]};
     }
     return out;
 }
@@ -148,24 +156,28 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         a_ix0[i] = ox * p.stride - p.pad;
     }
 
-    float4 ra[RA], rb[RB];
+    f32x4 ra[RA], rb[RB];
+    bool ra_ok[RA];
     const int cpt = VEC ? (p.Cin >> 5) : 1;  // chunks per filter tap
 
 #define BP_LOAD_CHUNK(c_)                                                                          \
     {                                                                                              \
         const int cc = (c_);                                                                       \
         _Pragma("unroll") for (int i = 0; i < RA; ++i)                                             \
-            ra[i] = load_a_row<VEC>(p, cc, cpt, c4, a_bh[i], a_iy0[i], a_ix0[i]);                  \
+            ra[i] = load_a_row<VEC>(p, cc, cpt, c4, a_bh[i], a_iy0[i], a_ix0[i], ra_ok[i]);        \
         _Pragma("unroll") for (int i = 0; i < RB; ++i)                                             \
-            rb[i] = *reinterpret_cast<const float4*>(p.w + (long long)(n0 + lr + 32 * i) * p.Kpad + \
+            rb[i] = *reinterpret_cast<const f32x4*>(p.w + (long long)(n0 + lr + 32 * i) * p.Kpad + \
                                                      cc * BK + c4 * 4);                            \
     }
 #define BP_STORE_LDS(buf_)                                                                         \
     {                                                                                              \
-        _Pragma("unroll") for (int i = 0; i < RA; ++i)                                             \
-            *reinterpret_cast<float4*>(&As[buf_][(lr + 32 * i) * LDS_LD + c4 * 4]) = ra[i];        \
+        _Pragma("unroll") for (int i = 0; i < RA; ++i) {                                           \
+            f32x4 v_ = ra[i];                                                                     \
+            if (!ra_ok[i]) v_ = f32x4{0.f, 0.f, 0.f, 0.f};                                       \
+            *reinterpret_cast<f32x4*>(&As[buf_][(lr + 32 * i) * LDS_LD + c4 * 4]) = v_;            \
+        }                                                                                          \
         _Pragma("unroll") for (int i = 0; i < RB; ++i)                                             \
-            *reinterpret_cast<float4*>(&Bs[buf_][(lr + 32 * i) * LDS_LD + c4 * 4]) = rb[i];        \
+            *reinterpret_cast<f32x4*>(&Bs[buf_][(lr + 32 * i) * LDS_LD + c4 * 4]) = rb[i];         \
     }
 
     f32x16 acc[TM][TN];
@@ -190,11 +202,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         const float* Ab = &As[buf_][a_off];                                                           \
         const float* Bb = &Bs[buf_][b_off];                                                           \
         _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                            \
-            float4 a[TM], b[TN];                                                                      \
+            f32x4 a[TM], b[TN];                                                                       \
             _Pragma("unroll") for (int i = 0; i < TM; ++i) a[i] =                                     \
-                *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_LD + ks * 8);                      \
+                *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDS_LD + ks * 8);                       \
             _Pragma("unroll") for (int j = 0; j < TN; ++j) b[j] =                                     \
-                *reinterpret_cast<const float4*>(Bb + j * 32 * LDS_LD + ks * 8);                      \
+                *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDS_LD + ks * 8);                       \
             _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) { \
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0); \
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0); \
@@ -209,7 +221,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     int buf = 0;
     for (int c = c_begin; c + 1 < c_end; ++c) {
         BP_LOAD_CHUNK(c + 1);
+        __builtin_amdgcn_sched_barrier(0);   // all global loads of chunk c+1 are issued before the MFMAs of chunk c
         BP_COMPUTE(buf);
+        __builtin_amdgcn_sched_barrier(0);
         BP_STORE_LDS(buf ^ 1);
         __syncthreads();
         buf ^= 1;

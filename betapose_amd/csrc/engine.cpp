@@ -150,7 +150,7 @@ void Net::run_op(const Op& op, int batch, hipStream_t s) {
             launch_avgpool(op.a, op.a_ld, op.out, batch, op.H * op.W, op.C, s);
             break;
         case OP_FC:
-            launch_fc(op.a, op.w, op.bias, op.out, batch, op.Cin, op.Cout, op.act, s);
+            launch_fc(op.a, op.w, op.bias, op.out, batch, op.Cin, op.Cout, op.act, op.in_parts, op.in_scale, s);
             break;
         default:
             throw Error("unknown op");
@@ -547,7 +547,8 @@ KpdNet::KpdNet(const float* stream, size_t n_floats, int n_classes, int max_batc
                 ConvWeights cd = take_conv_bn(C, inplanes, 1);
                 Tensor Tt = new_tensor(OH, OW, C);
                 add_conv(nm + ".conv3", t2, Tt, c3, C, 1, 1, 0, ACT_LINEAR, ST_NHWC, nullptr, nullptr, 0, 1e-5f, OH, OW);
-                float* pooled = arena_.alloc((size_t)max_batch * C);
+                const int parts = avgpool_parts(OH * OW);
+                float* pooled = arena_.alloc((size_t)max_batch * parts * C);
                 float* hid = arena_.alloc((size_t)max_batch * C);
                 float* y = arena_.alloc((size_t)max_batch * C);
                 Op ap; ap.type = OP_AVGPOOL; ap.name = nm + ".se.pool";
@@ -555,10 +556,12 @@ KpdNet::KpdNet(const float* stream, size_t n_floats, int n_classes, int max_batc
                 ops_.push_back(ap);
                 Op f0; f0.type = OP_FC; f0.name = nm + ".se.fc.0";
                 f0.a = pooled; f0.w = upload(w0, (size_t)C * C); f0.bias = upload(b0, C); f0.out = hid; f0.Cin = C; f0.Cout = C; f0.act = 2;
+                f0.in_parts = parts; f0.in_scale = 1.f / (float)(OH * OW);
                 f0.flops = 2.0 * C * C; f0.bytes = 4.0 * C * C;
                 ops_.push_back(f0);
                 Op f2 = f0; f2.name = nm + ".se.fc.2";
                 f2.a = hid; f2.w = upload(w2, (size_t)C * C); f2.bias = upload(b2, C); f2.out = y; f2.act = 3;
+                f2.in_parts = 1; f2.in_scale = 1.f;
                 ops_.push_back(f2);
                 add_conv(nm + ".downsample", x, out, cd, C, 1, st, 0, ACT_RELU, ST_NHWC, &Tt, y, 0, 1e-5f, OH, OW);
             }

@@ -42,6 +42,7 @@ struct Op {
     int H = 0, W = 0, C = 0, OH = 0, OW = 0;
     // fc
     const float* w = nullptr; const float* bias = nullptr; int Cin = 0, Cout = 0, act = 0;
+    int in_parts = 1; float in_scale = 1.f;
     std::string name;
     double flops = 0;    // per image
     double bytes = 0;    // algorithmic bytes per image (weights counted once per launch elsewhere)

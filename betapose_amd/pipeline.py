@@ -72,7 +72,7 @@ class FramePipeline:
     def run(self, frames_bgr_u8) -> np.ndarray:
         """Convenience: upload frames (numpy [B,H,W,3] u8 or cuda tensor), run, return records [B,316] (host)."""
         import torch
-        f = frames_bgr_u8 if hasattr(frames_bgr_u8, "device") else torch.from_numpy(np.ascontiguousarray(frames_bgr_u8))
+        f = frames_bgr_u8 if hasattr(frames_bgr_u8, "is_cuda") else torch.from_numpy(np.ascontiguousarray(frames_bgr_u8))
         if f.dim() == 3:
             f = f.unsqueeze(0)
         self.frames.copy_(f, non_blocking=True)

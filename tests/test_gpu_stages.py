@@ -1,0 +1,130 @@
+"""Device-side stages around the networks, through the C-ABI: Pillow-exact bicubic resize (a1),
+crop (a6/a7), the fused hipGraph pipeline (a1..a9) and its host tail (a9..a11), against the
+reference golden vectors and the oracle.  Integer results exact; floats within stated tolerance."""
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+pytestmark = pytest.mark.gpu
+
+import helpers  # noqa: E402
+from betapose_amd import ops, synth  # noqa: E402
+from betapose_amd.darknet import Darknet  # noqa: E402
+from betapose_amd.kpd import FastPoseHIP  # noqa: E402
+from betapose_amd.pipeline import FramePipeline, finish_record  # noqa: E402
+from oracle import post_ref  # noqa: E402
+
+
+@pytest.mark.parametrize("size", [(480, 640, 416, 416), (480, 640, 320, 256), (100, 37, 64, 80), (416, 416, 416, 416)])
+def test_resize_is_pillow_exact(cuda, size):
+    H, W, oh, ow = size
+    rng = np.random.Generator(np.random.PCG64(H * 1000 + W))
+    frames = rng.integers(0, 256, (2, H, W, 3), dtype=np.uint8)
+    got = ops.resize_bicubic(torch.from_numpy(frames).to(cuda), oh, ow, swap_rb=False, want="u8").cpu().numpy()
+    for b in range(2):
+        ref = np.asarray(Image.fromarray(frames[b]).resize((ow, oh), 3))
+        assert np.array_equal(got[b], ref), "max diff %d" % int(np.abs(got[b].astype(int) - ref.astype(int)).max())
+
+
+def test_resize_matches_reference_input_path(cuda):
+    """BGR frame -> RGB /255 NHWC == transforms.Resize((416,416), 3) + ToTensor of the reference (dataloader.py:94-99)."""
+    pipe = helpers.golden("pipeline.npz")
+    fr = helpers.frames()[0]
+    got = ops.resize_bicubic(torch.from_numpy(fr[None]).to(cuda), 416, 416, swap_rb=True, want="f32").cpu()
+    nchw = got.permute(0, 3, 1, 2).contiguous()
+    assert np.array_equal(nchw.numpy().ravel()[pipe["in_samp"]], pipe["f0_yolo_in_samp"])
+    assert int(torch.round(nchw * 255).long().sum()) == int(pipe["f0_yolo_in_u8sum"])
+
+
+def test_crop_matches_reference(cuda):
+    pipe = helpers.golden("pipeline.npz")
+    n = int(pipe["n_frames"])
+    frames = np.stack(helpers.frames(n))
+    boxes = np.concatenate([pipe["f%d_boxes" % i] for i in range(n)]).astype(np.float32)
+    inps, pts = ops.crop(torch.from_numpy(frames).to(cuda), boxes=torch.from_numpy(boxes).to(cuda))
+    inps, pts = inps.cpu(), pts.cpu().numpy()
+    for i in range(n):
+        k = "f%d_" % i
+        np.testing.assert_array_equal(pts[i, 0:2], pipe[k + "pt1"][0])      # float window, exact
+        np.testing.assert_array_equal(pts[i, 2:4], pipe[k + "pt2"][0])
+        np.testing.assert_allclose(inps[i].numpy().ravel()[pipe["crop_samp"]], pipe[k + "crop_samp"], atol=2e-6)
+        assert abs(float(inps[i].double().sum()) - float(pipe[k + "crop_sum"])) < 0.05
+
+
+@pytest.mark.parametrize("box", [(0.0, 0.0, 60.0, 50.0), (600.0, 430.0, 639.0, 479.0), (-20.0, 100.0, 700.0, 130.0),
+                                 (300.0, 200.0, 302.0, 203.0), (10.5, 20.25, 90.75, 260.5), (100.0, 50.0, 201.0, 400.0)])
+def test_crop_edge_boxes_vs_oracle(cuda, box):
+    """Borders, degenerate and clamped boxes (the cases crop_from_dets guards, dataloader.py:817-823)."""
+    fr = helpers.frames()[1]
+    b = torch.tensor([box], dtype=torch.float32)
+    ref, pt1, pt2 = post_ref.crop_from_dets_frame(fr, b)
+    got, pts = ops.crop(torch.from_numpy(fr[None]).to(cuda), boxes=b.to(cuda))
+    np.testing.assert_array_equal(pts.cpu().numpy()[0, :4], np.r_[pt1.numpy()[0], pt2.numpy()[0]])
+    assert float((got.cpu() - ref).abs().max()) <= 2e-6
+
+
+@pytest.fixture(scope="module")
+def engines(cuda):
+    det = Darknet("yolo/cfg/yolov3-single.cfg", reso=416, max_batch=4).load_stream(helpers.yolo_stream()).cuda()
+    pose = FastPoseHIP(helpers.kpd_state_dict(), max_batch=4).cuda()
+    return det, pose
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_pipeline_matches_reference_golden(engines, cuda, use_graph):
+    """Frame in -> record out, one launch sequence / one hipGraph; everything the reference's stage classes
+    produced for the same frames (tests/golden/pipeline.npz)."""
+    det, pose = engines
+    pipe = helpers.golden("pipeline.npz")
+    fp = FramePipeline(det, pose, 480, 640, batch=1, use_graph=use_graph, keep_heatmaps=True)
+    kp3d = synth.synth_kp3d(50)
+    for rep in range(2):   # second pass replays the captured graph
+        for i, fr in enumerate(helpers.frames(int(pipe["n_frames"]))):
+            k = "f%d_" % i
+            rec = fp.run(fr)[0]
+            out = finish_record(rec, "%04d.png" % i, kp3d, synth.CAM_K)
+            assert out["yolo_index"] == int(pipe[k + "obj_argmax"])
+            np.testing.assert_allclose(out["boxes"], pipe[k + "boxes"], rtol=3e-5, atol=2e-3)
+            np.testing.assert_allclose(out["scores"], pipe[k + "scores"], atol=2e-5)
+            np.testing.assert_allclose(rec[8:12], np.r_[pipe[k + "pt1"][0], pipe[k + "pt2"][0]], rtol=3e-5, atol=2e-3)
+            kp = rec[16:].reshape(50, 6)
+            assert np.array_equal(kp[:, 0].copy().view(np.int32), pipe[k + "kp_idx"])
+            assert np.abs(kp[:, 1] - pipe[k + "kp_max"]).max() <= 2e-4
+            hm = fp.heatmaps.cpu().numpy()
+            assert np.abs(hm.ravel()[pipe["hm_samp"]] - pipe[k + "hm_samp"]).max() <= 2e-4
+            assert len(out["result"]) == int(pipe[k + "nms_n"]) == 1
+            np.testing.assert_allclose(out["result"][0]["keypoints"], pipe[k + "nms_kp"], rtol=1e-4, atol=5e-3)
+            np.testing.assert_allclose(out["result"][0]["kp_score"], pipe[k + "nms_score"], atol=2e-4)
+            # pose: the solve must be a stationary point of the reprojection error (oracle LM from it does not move)
+            R, t = out["cam_R"], out["cam_t"]
+            assert abs(np.linalg.det(R) - 1) < 1e-9
+            R2, t2, _ = post_ref.pnp_least_squares(kp3d, out["result"][0]["keypoints"], synth.CAM_K, R, t)
+            assert np.abs(R2 - R).max() < 1e-5 and np.abs(t2 - t).max() < 1e-5
+    if use_graph:
+        assert fp.kernel_count() > 100
+
+
+def test_pipeline_batch_equals_single(engines, cuda):
+    det, pose = engines
+    frames = np.stack(helpers.frames(3))
+    fb = FramePipeline(det, pose, 480, 640, batch=3, use_graph=True)
+    recb = fb.run(frames)
+    f1 = FramePipeline(det, pose, 480, 640, batch=1, use_graph=True)
+    for i in range(3):
+        r1 = f1.run(frames[i])[0]
+        assert r1[:1].view(np.int32)[0] == recb[i, :1].view(np.int32)[0]
+        a, b = r1[16:].reshape(50, 6), recb[i, 16:].reshape(50, 6)
+        assert np.array_equal(a[:, 0].copy().view(np.int32), b[:, 0].copy().view(np.int32))
+        assert np.abs(a[:, 1:] - b[:, 1:]).max() <= 2e-4
+
+
+def test_pipeline_fixed_box(engines, cuda):
+    det, pose = engines
+    fp = FramePipeline(det, pose, 480, 640, batch=1, use_graph=True)
+    fp.set_fixed_box([220, 140, 420, 340])
+    rec = fp.run(helpers.frames()[0])[0]
+    np.testing.assert_allclose(rec[12:16], [220, 140, 420, 340])
+    fp.set_fixed_box(None)
+    rec2 = fp.run(helpers.frames()[0])[0]
+    assert not np.allclose(rec2[12:16], [220, 140, 420, 340])
