@@ -62,6 +62,7 @@ struct ConvParams {
     int splits;            // split-K factor (>=1)
     int chunks_per_split;
     float* partial;        // [splits][M][CoutPad] when splits > 1
+    int* tickets;          // [tiles] arrival counters (zero between launches) when splits > 1
     int CoutPad;
 };
 
@@ -73,6 +74,7 @@ struct ConvProfHook { hipEvent_t e0, e1; };
 extern thread_local ConvProfHook* g_conv_prof;
 
 void launch_conv(const ConvParams& p, int tile, hipStream_t s);
+int conv_tiles(const ConvParams& p, int tile);   // blocks per K-slice
 int conv_tile_bm(int tile);
 int conv_tile_bn(int tile);
 

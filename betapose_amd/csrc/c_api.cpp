@@ -306,7 +306,12 @@ int bp_conv2d(const float* d_in, int N, int H, int W, int Cin, const float* h_w,
     int per = (p.nchunks + sp - 1) / sp;
     sp = (p.nchunks + per - 1) / per;
     p.splits = sp; p.chunks_per_split = per;
-    if (sp > 1) p.partial = net.arena_.alloc((size_t)sp * p.M * p.CoutPad);
+    if (sp > 1) {
+        p.partial = net.arena_.alloc((size_t)sp * p.M * p.CoutPad);
+        const int tiles = bp::conv_tiles(p, t);
+        p.tickets = (int*)net.arena_.alloc_bytes((size_t)tiles * sizeof(int));
+        BP_HIP(hipMemset(p.tickets, 0, (size_t)tiles * sizeof(int)));
+    }
     bp::launch_conv(p, t, s);
     BP_HIP(hipStreamSynchronize(s));
     if (iters > 0 && ms_per_iter) {

@@ -18,6 +18,8 @@
 // Fragment trick: lane l reads A[row=l&31][4h..4h+3] (h=l>>5) as one b128 and feeds
 // component j to MFMA j, so MFMA j contracts k = {j, 4+j} of the 8-wide sub-chunk;
 // B uses the same k mapping, and the sum over k is order-free.
+#include <hip/hip_ext.h>
+
 #include "bp_common.h"
 
 namespace bp {
@@ -231,6 +233,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     if (c_begin < c_end) BP_COMPUTE(buf);
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    if (p.splits == 1) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (m < p.M && n < p.Cout) epilogue_store(p, m, n, acc[i][j][r]);
+                }
+            }
+        return;
+    }
+    // ---- split-K: every slice parks its fp32 slab; the LAST slice to arrive at the tile's ticket counter
+    // sums all slabs in slice order (deterministic, independent of arrival order) and runs the epilogue.
+    // Hand-off = agent-scope release by every producer, one agent-scope acquire by the reducer
+    // (cdna_hip_programming.md G16 counter form); placement independent.
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -238,30 +258,42 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             const int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int m = m0 + row;
-                if (m < p.M) {
-                    if (p.splits > 1) {
-                        p.partial[((long long)split * p.M + m) * p.CoutPad + n] = acc[i][j][r];
-                    } else if (n < p.Cout) {
-                        epilogue_store(p, m, n, acc[i][j][r]);
-                    }
+                const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < p.M) p.partial[((long long)split * p.M + m) * p.CoutPad + n] = acc[i][j][r];
+            }
+        }
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int ticket = __hip_atomic_fetch_add(&p.tickets[blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = ticket == p.splits - 1;
+        if (s_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(&p.tickets[blockIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+        }
+    }
+    __syncthreads();
+    if (!s_last) return;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < p.M && n < p.Cout) {
+                    const float* src = p.partial + (long long)m * p.CoutPad + n;
+                    const long long slab = (long long)p.M * p.CoutPad;
+                    float v = 0.f;
+                    for (int sidx = 0; sidx < p.splits; ++sidx) v += src[sidx * slab];
+                    epilogue_store(p, m, n, v);
                 }
             }
         }
-}
-
-// sum split-K partial slabs and run the fused epilogue
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ConvParams p) {
-    const long long total = (long long)p.M * p.Cout;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-         e += (long long)gridDim.x * blockDim.x) {
-        const int m = (int)(e / p.Cout);
-        const int n = (int)(e - (long long)m * p.Cout);
-        float v = 0.f;
-        for (int s = 0; s < p.splits; ++s) v += p.partial[((long long)s * p.M + m) * p.CoutPad + n];
-        epilogue_store(p, m, n, v);
-    }
 }
 
 thread_local ConvProfHook* g_conv_prof = nullptr;
@@ -274,29 +306,28 @@ static void launch_t(const ConvParams& p, hipStream_t s) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     dim3 grid(((p.M + BM - 1) / BM) * (p.CoutPad / BN), 1, p.splits);
     const bool vec = (p.Cin % 32 == 0) && (p.in_ld % 4 == 0);
+    hipEvent_t e0 = g_conv_prof ? g_conv_prof->e0 : nullptr, e1 = g_conv_prof ? g_conv_prof->e1 : nullptr;
+    // hipExtLaunchKernelGGL stamps e0/e1 with the kernel's own begin/end (no host-side event gap)
     if (vec)
-        hipLaunchKernelGGL((conv_igemm_kernel<TM, TN, true>), grid, dim3(256), 0, s, p);
+        hipExtLaunchKernelGGL((conv_igemm_kernel<TM, TN, true>), grid, dim3(256), 0, s, e0, e1, 0, p);
     else
-        hipLaunchKernelGGL((conv_igemm_kernel<TM, TN, false>), grid, dim3(256), 0, s, p);
+        hipExtLaunchKernelGGL((conv_igemm_kernel<TM, TN, false>), grid, dim3(256), 0, s, e0, e1, 0, p);
+}
+
+int conv_tiles(const ConvParams& p, int tile) {
+    const int bm = conv_tile_bm(tile);
+    return ((p.M + bm - 1) / bm) * (p.CoutPad / 64);
 }
 
 void launch_conv(const ConvParams& p, int tile, hipStream_t s) {
     BP_CHECK(p.CoutPad % 64 == 0, "CoutPad must be a multiple of 64");
     BP_CHECK(p.Kpad % BK == 0 && p.nchunks == p.Kpad / BK, "Kpad");
-    BP_CHECK(p.splits >= 1 && (p.splits == 1 || p.partial != nullptr), "split-K workspace");
-    if (g_conv_prof) BP_HIP(hipEventRecord(g_conv_prof->e0, s));
+    BP_CHECK(p.splits >= 1 && (p.splits == 1 || (p.partial != nullptr && p.tickets != nullptr)), "split-K workspace");
     switch (tile) {
         case TILE_128x64: launch_t<2, 1>(p, s); break;
         default: launch_t<1, 1>(p, s); break;
     }
-    if (g_conv_prof) BP_HIP(hipEventRecord(g_conv_prof->e1, s));
     BP_HIP(hipGetLastError());
-    if (p.splits > 1) {
-        const long long total = (long long)p.M * p.Cout;
-        int blocks = (int)std::min<long long>((total + 255) / 256, 2048);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, p);
-        BP_HIP(hipGetLastError());
-    }
 }
 
 }  // namespace bp

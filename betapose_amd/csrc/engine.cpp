@@ -35,8 +35,8 @@ Tensor Net::new_tensor(int H, int W, int C) {
 
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-static void choose_launch(const Op& op, int batch, int force_tile, int sk_target, int sk_min_chunks, int* tile,
-                          int* splits, int* cps) {
+static void choose_launch(const Op& op, int batch, int force_tile, int sk_target, int sk_min_chunks, int sk_max,
+                          int* tile, int* splits, int* cps) {
     const ConvParams& c = op.conv;
     const long long M = (long long)batch * c.OH * c.OW;
     const int nt = c.CoutPad / 64;
@@ -46,7 +46,7 @@ static void choose_launch(const Op& op, int batch, int force_tile, int sk_target
     const int bm = conv_tile_bm(t);
     const long long blocks = ((M + bm - 1) / bm) * nt;
     int s = 1;
-    while (blocks * s < sk_target && c.nchunks / (s + 1) >= sk_min_chunks && s < 64) ++s;
+    while (blocks * s < sk_target && c.nchunks / (s + 1) >= sk_min_chunks && s < sk_max) ++s;
     int per = (c.nchunks + s - 1) / s;
     s = (c.nchunks + per - 1) / per;
     *tile = t; *splits = s; *cps = per;
@@ -92,6 +92,7 @@ int Net::add_conv(const std::string& name, const Tensor& in, const Tensor& out_v
     c.res = res ? res->p : nullptr; c.res_ld = res ? res->ld : 0; c.res_scale = res_scale;
     c.res_after_act = res_after_act; c.store_mode = store_mode;
     c.M = OH * OW; c.nchunks = Kpad / 32; c.splits = 1; c.chunks_per_split = c.nchunks; c.partial = nullptr;
+    c.tickets = nullptr;
     c.CoutPad = CoutPad;
     op.flops = 2.0 * OH * OW * (double)Cout * K;
     op.bytes = 4.0 * ((double)Cout * K + (double)in.H * in.W * Cin + (double)OH * OW * Cout + (res ? (double)OH * OW * Cout : 0.0));
@@ -105,7 +106,7 @@ void Net::finalize() {
         if (op.type != OP_CONV) continue;
         for (int b = 1; b <= max_batch_; ++b) {
             int tile, splits, cps;
-            choose_launch(op, b, force_tile_, sk_target_, sk_min_chunks_, &tile, &splits, &cps);
+            choose_launch(op, b, force_tile_, sk_target_, sk_min_chunks_, 64, &tile, &splits, &cps);
             // worst case over policies that may be set later: allow up to 64 splits at batch 1
             if (splits > 1) need = std::max(need, (size_t)splits * b * op.conv.OH * op.conv.OW * op.conv.CoutPad);
         }
@@ -113,6 +114,14 @@ void Net::finalize() {
     need = std::max(need, (size_t)4 << 20);   // headroom so a later policy change can still split small layers
     partial_floats_ = need;
     partial_ = need ? arena_.alloc(need) : nullptr;
+    // arrival counters for the in-kernel split-K reduction: one per output tile of the widest layer
+    size_t tiles = 0;
+    for (const Op& op : ops_)
+        if (op.type == OP_CONV)
+            tiles = std::max(tiles, (size_t)(((size_t)max_batch_ * op.conv.OH * op.conv.OW + 63) / 64) * (op.conv.CoutPad / 64));
+    tickets_count_ = tiles;
+    tickets_ = (int*)arena_.alloc_bytes(tiles * sizeof(int));
+    BP_HIP(hipMemset(tickets_, 0, tiles * sizeof(int)));
 }
 
 void Net::run_op(const Op& op, int batch, hipStream_t s) {
@@ -122,13 +131,13 @@ void Net::run_op(const Op& op, int batch, hipStream_t s) {
             p.N = batch;
             p.M = batch * p.OH * p.OW;
             int tile, splits, cps;
-            choose_launch(op, batch, force_tile_, sk_target_, sk_min_chunks_, &tile, &splits, &cps);
+            choose_launch(op, batch, force_tile_, sk_target_, sk_min_chunks_, sk_max_splits_, &tile, &splits, &cps);
             while (splits > 1 && (size_t)splits * p.M * p.CoutPad > partial_floats_) {
                 --splits;
                 cps = (p.nchunks + splits - 1) / splits;
                 splits = (p.nchunks + cps - 1) / cps;
             }
-            p.splits = splits; p.chunks_per_split = cps; p.partial = partial_;
+            p.splits = splits; p.chunks_per_split = cps; p.partial = partial_; p.tickets = tickets_;
             launch_conv(p, tile, s);
         } break;
         case OP_MAXPOOL:
@@ -197,7 +206,7 @@ int Net::profile(int batch, int iters, float* ms, int* info, int cap, hipStream_
         if (info) {
             int tile = 0, splits = 1, cps = 0, vec = 0, conv = ops_[i].type == OP_CONV;
             if (conv) {
-                choose_launch(ops_[i], batch, force_tile_, sk_target_, sk_min_chunks_, &tile, &splits, &cps);
+                choose_launch(ops_[i], batch, force_tile_, sk_target_, sk_min_chunks_, sk_max_splits_, &tile, &splits, &cps);
                 vec = (ops_[i].conv.Cin % 32 == 0) && (ops_[i].conv.in_ld % 4 == 0);
             }
             info[4 * i] = conv; info[4 * i + 1] = tile; info[4 * i + 2] = vec; info[4 * i + 3] = splits;

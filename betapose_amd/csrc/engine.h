@@ -71,6 +71,7 @@ public:
     void tap_shape(int i, int* C, int* H, int* W) const { *C = taps_[i].C; *H = taps_[i].H; *W = taps_[i].W; }
     void tap_copy(int i, int batch, float* d_out_nchw, hipStream_t s) const;
     void set_splitk_policy(int target_blocks, int min_chunks) { sk_target_ = target_blocks; sk_min_chunks_ = min_chunks; }
+    void set_max_splits(int m) { sk_max_splits_ = m; }
     void set_force_tile(int t) { force_tile_ = t; }
 
 protected:
@@ -89,7 +90,9 @@ protected:
     std::vector<std::string> tap_names_;
     float* partial_ = nullptr;
     size_t partial_floats_ = 0;
-    int sk_target_ = 512, sk_min_chunks_ = 4;
+    int* tickets_ = nullptr;
+    size_t tickets_count_ = 0;
+    int sk_target_ = 512, sk_min_chunks_ = 4, sk_max_splits_ = 8;
     int force_tile_ = -1;
 };
 
