@@ -45,6 +45,13 @@ def parse_args():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--pool", type=int, default=8, help="distinct synthetic frames per rank")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="frames in flight per GPU: independent batch-1 passes on separate HIP streams (engine clones "
+                         "share the filters); 1 = strictly one frame at a time")
+    ap.add_argument("--sk-target", type=int, default=512)
+    ap.add_argument("--sk-min", type=int, default=4)
+    ap.add_argument("--sk-max", type=int, default=8)
+    ap.add_argument("--tile", type=int, default=-1)
     return ap.parse_args()
 
 
@@ -183,28 +190,44 @@ def main():
     det.cuda()
     pose.cuda()
 
-    pipe = FramePipeline(det, pose, 480, 640, batch=a.batch, confidence=0.01, num_classes=80, use_graph=not a.no_graph)
+    det.set_policy(a.sk_target, a.sk_min, a.sk_max, a.tile)
+    pose.set_policy(a.sk_target, a.sk_min, a.sk_max, a.tile)
+    S = max(1, a.streams)
+    dets = [det] + [det.clone() for _ in range(S - 1)]
+    poses = [pose] + [pose.clone() for _ in range(S - 1)]
+    for d, p_ in zip(dets[1:], poses[1:]):
+        d.set_policy(a.sk_target, a.sk_min, a.sk_max, a.tile)
+        p_.set_policy(a.sk_target, a.sk_min, a.sk_max, a.tile)
+    pipes = [FramePipeline(dets[k], poses[k], 480, 640, batch=a.batch, confidence=0.01, num_classes=80,
+                           use_graph=not a.no_graph) for k in range(S)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+    pipe = pipes[0]
     if a.fixed_box:
-        pipe.set_fixed_box([220, 140, 420, 340])
+        for p_ in pipes:
+            p_.set_fixed_box([220, 140, 420, 340])
     kp3d, cam_K = synth.synth_kp3d(50), synth.CAM_K
 
     # ---- inputs resident in HBM: a pool of distinct frames per rank
     pool = [torch.from_numpy(np.stack(synth.synth_frames(a.batch, 1234 + 1000 * rank + 37 * j))).to(dev)
             for j in range(a.pool)]
-    pinned = [torch.empty((a.batch, pipe.results.shape[1]), dtype=torch.float32).pin_memory() for _ in range(2)]
-    events = [torch.cuda.Event(), torch.cuda.Event()]
+    NS = 2 * S
+    pinned = [torch.empty((a.batch, pipe.results.shape[1]), dtype=torch.float32).pin_memory() for _ in range(NS)]
+    events = [torch.cuda.Event() for _ in range(NS)]
     records = np.zeros((a.steps, a.batch, pipe.results.shape[1]), np.float32)
     stats = {"det": 0, "pose": 0}
+    torch.cuda.synchronize()
 
     def issue(i):
-        pipe.frames.copy_(pool[i % a.pool], non_blocking=True)
-        pipe.enqueue()
-        pinned[i & 1].copy_(pipe.results, non_blocking=True)
-        events[i & 1].record()
+        k = i % S
+        with torch.cuda.stream(streams[k]):
+            pipes[k].frames.copy_(pool[i % a.pool], non_blocking=True)
+            pipes[k].enqueue(streams[k].cuda_stream)
+            pinned[i % NS].copy_(pipes[k].results, non_blocking=True)
+            events[i % NS].record(streams[k])
 
     def finish(i, keep):
-        events[i & 1].synchronize()
-        rec = pinned[i & 1].numpy()
+        events[i % NS].synchronize()
+        rec = pinned[i % NS].numpy()
         for b in range(a.batch):
             out = finish_record(rec[b], "%06d.png" % (i * a.batch + b), kp3d, cam_K)
             if keep:
@@ -216,9 +239,10 @@ def main():
     def run(nsteps, keep):
         for i in range(nsteps):
             issue(i)
-            if i:
-                finish(i - 1, keep)
-        finish(nsteps - 1, keep)
+            if i >= S:
+                finish(i - S, keep)
+        for i in range(max(0, nsteps - S), nsteps):
+            finish(i, keep)
 
     run(max(a.warmup, 1), False)
     torch.cuda.synchronize()
@@ -256,7 +280,7 @@ def main():
                                    "50 kp arg-max -> pPose-NMS -> PnP",
                        "batch": a.batch, "global_batch": a.batch * world, "frame": "640x480x3 u8",
                        "parallelism": "frames sharded by image, 1 process per GPU (dp%d)" % world,
-                       "hip_graph": not a.no_graph, "fixed_box": a.fixed_box,
+                       "hip_graph": not a.no_graph, "fixed_box": a.fixed_box, "frames_in_flight": S,
                        "graph_nodes": pipe.kernel_count()},
             "detections": stats["det"], "poses": stats["pose"],
         }

@@ -28,6 +28,8 @@ PROTOTYPES = {
     "bp_device_name": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     "bp_yolo_create": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
     "bp_yolo_create_from_memory": (C.c_int, [C.c_char_p, vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
+    "bp_yolo_clone": (C.c_int, [vp, C.POINTER(vp)]),
+    "bp_kpd_clone": (C.c_int, [vp, C.POINTER(vp)]),
     "bp_yolo_destroy": (None, [vp]),
     "bp_yolo_rows": (C.c_int, [vp]),
     "bp_yolo_attrs": (C.c_int, [vp]),
@@ -43,8 +45,8 @@ PROTOTYPES = {
     "bp_kpd_tap_count": (C.c_int, [vp]),
     "bp_kpd_tap_info": (C.c_int, [vp, C.c_int, C.c_char_p, C.c_int, c_int_p, c_int_p, c_int_p]),
     "bp_kpd_tap_copy": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),
-    "bp_yolo_set_policy": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
-    "bp_kpd_set_policy": (C.c_int, [vp, C.c_int, C.c_int, C.c_int]),
+    "bp_yolo_set_policy": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "bp_kpd_set_policy": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "bp_yolo_op_stats": (C.c_int, [vp, c_double_p, c_double_p, C.c_int]),
     "bp_kpd_op_stats": (C.c_int, [vp, c_double_p, c_double_p, C.c_int]),
     "bp_yolo_device_bytes": (C.c_size_t, [vp]),

@@ -61,7 +61,7 @@ struct ConvParams {
     int nchunks;           // Kpad/32
     int splits;            // split-K factor (>=1)
     int chunks_per_split;
-    float* partial;        // [splits][M][CoutPad] when splits > 1
+    float* partial;        // [splits][tiles][BM*64] fragment-order slabs when splits > 1
     int* tickets;          // [tiles] arrival counters (zero between launches) when splits > 1
     int CoutPad;
 };

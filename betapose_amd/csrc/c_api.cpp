@@ -126,6 +126,17 @@ int bp_yolo_create(const char* cfg_path, const char* weights_path, int reso, int
     BP_CATCH
 }
 
+int bp_yolo_clone(const bp_yolo* y, bp_yolo** out) {
+    BP_TRY
+    BP_CHECK(y && out, "null argument");
+    BP_HIP(hipSetDevice(y->device));
+    std::unique_ptr<bp_yolo> c(new bp_yolo);
+    c->device = y->device;
+    c->net.reset(y->net->clone());
+    *out = c.release();
+    return 0;
+    BP_CATCH
+}
 void bp_yolo_destroy(bp_yolo* y) { delete y; }
 int bp_yolo_rows(const bp_yolo* y) { return y ? y->net->rows() : -1; }
 int bp_yolo_attrs(const bp_yolo* y) { return y ? y->net->attrs() : -1; }
@@ -175,6 +186,17 @@ int bp_kpd_create(const float* stream, size_t n_floats, int n_classes, int max_b
     return 0;
     BP_CATCH
 }
+int bp_kpd_clone(const bp_kpd* k, bp_kpd** out) {
+    BP_TRY
+    BP_CHECK(k && out, "null argument");
+    BP_HIP(hipSetDevice(k->device));
+    std::unique_ptr<bp_kpd> c(new bp_kpd);
+    c->device = k->device;
+    c->net.reset(k->net->clone());
+    *out = c.release();
+    return 0;
+    BP_CATCH
+}
 void bp_kpd_destroy(bp_kpd* k) { delete k; }
 int bp_kpd_forward(bp_kpd* k, const float* d_inps, int batch, float* d_hm, void* stream) {
     BP_TRY
@@ -201,13 +223,15 @@ int bp_kpd_tap_copy(bp_kpd* k, int i, int batch, float* d_out, void* stream) {
     BP_CATCH
 }
 
-int bp_yolo_set_policy(bp_yolo* y, int t, int mc, int ft) {
+int bp_yolo_set_policy(bp_yolo* y, int t, int mc, int ms, int ft) {
     y->net->set_splitk_policy(t, mc);
+    y->net->set_max_splits(ms);
     y->net->set_force_tile(ft);
     return 0;
 }
-int bp_kpd_set_policy(bp_kpd* k, int t, int mc, int ft) {
+int bp_kpd_set_policy(bp_kpd* k, int t, int mc, int ms, int ft) {
     k->net->set_splitk_policy(t, mc);
+    k->net->set_max_splits(ms);
     k->net->set_force_tile(ft);
     return 0;
 }
@@ -307,8 +331,8 @@ int bp_conv2d(const float* d_in, int N, int H, int W, int Cin, const float* h_w,
     sp = (p.nchunks + per - 1) / per;
     p.splits = sp; p.chunks_per_split = per;
     if (sp > 1) {
-        p.partial = net.arena_.alloc((size_t)sp * p.M * p.CoutPad);
         const int tiles = bp::conv_tiles(p, t);
+        p.partial = net.arena_.alloc((size_t)sp * tiles * bp::conv_tile_bm(t) * 64);
         p.tickets = (int*)net.arena_.alloc_bytes((size_t)tiles * sizeof(int));
         BP_HIP(hipMemset(p.tickets, 0, (size_t)tiles * sizeof(int)));
     }

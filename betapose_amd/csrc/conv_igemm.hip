@@ -25,6 +25,7 @@
 namespace bp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: stays in VGPRs (HIP's float4 struct
                                                            // made hipcc park the prefetch registers in scratch)
 
@@ -133,10 +134,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int n_tiles_n = p.CoutPad / BN;
-    const int tile_n = blockIdx.x % n_tiles_n;
-    const int tile_m = blockIdx.x / n_tiles_n;
+    // 1-D grid, K-slice fastest: consecutive block ids (= consecutive XCDs) take different K-slices of the same
+    // output tile, so with 8 slices every XCD streams its own 1/8 of the filters through its private L2
+    const int split = (int)blockIdx.x % p.splits;
+    const int tile_id = (int)blockIdx.x / p.splits;
+    const int tile_n = tile_id % n_tiles_n;
+    const int tile_m = tile_id / n_tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int split = blockIdx.z;
     const int c_begin = split * p.chunks_per_split;
     const int c_end = min(p.nchunks, c_begin + p.chunks_per_split);
 
@@ -247,50 +251,60 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             }
         return;
     }
-    // ---- split-K: every slice parks its fp32 slab; the LAST slice to arrive at the tile's ticket counter
-    // sums all slabs in slice order (deterministic, independent of arrival order) and runs the epilogue.
-    // Hand-off = agent-scope release by every producer, one agent-scope acquire by the reducer
-    // (cdna_hip_programming.md G16 counter form); placement independent.
+    // ---- split-K: every slice parks its fp32 accumulators in a slab laid out in FRAGMENT order
+    // (slice, tile, wave, quad, lane) so each lane moves 16 B per instruction, fully coalesced; the LAST slice
+    // to arrive at the tile's ticket counter sums all slabs in slice order (deterministic, independent of arrival
+    // order) and runs the epilogue.  Hand-off without fences (cdna_hip_programming.md G16 "R1"): write-through
+    // (sc1) slab stores, every storing wave drains vmcnt, one relaxed agent-scope ticket, sc1 loads by the reducer.
+    const int tiles = (int)gridDim.x / p.splits;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        p.partial, 0, (int)((long long)p.splits * tiles * (TM * TN * 4096) * 4), 0x00020000);
+    constexpr int TILE_FLOATS = TM * TN * 4096;
+    const int my_off = ((split * tiles + tile_id) * TILE_FLOATS + wave * (TM * TN * 1024) + lane * 4) * 4;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m < p.M) p.partial[((long long)split * p.M + m) * p.CoutPad + n] = acc[i][j][r];
+            for (int q = 0; q < 4; ++q) {
+                u32x4 v;
+                v.x = __float_as_uint(acc[i][j][4 * q]);
+                v.y = __float_as_uint(acc[i][j][4 * q + 1]);
+                v.z = __float_as_uint(acc[i][j][4 * q + 2]);
+                v.w = __float_as_uint(acc[i][j][4 * q + 3]);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, my_off + (((i * TN + j) * 4 + q) * 256) * 4, 0, 16 /*sc1*/);
             }
-        }
     __shared__ int s_last;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const int ticket = __hip_atomic_fetch_add(&p.tickets[blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int ticket = __hip_atomic_fetch_add(&p.tickets[tile_id], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = ticket == p.splits - 1;
-        if (s_last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            __hip_atomic_store(&p.tickets[blockIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
-        }
+        if (s_last) __hip_atomic_store(&p.tickets[tile_id], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
     }
     __syncthreads();
     if (!s_last) return;
+    const int base_off = ((tile_id) * TILE_FLOATS + wave * (TM * TN * 1024) + lane * 4) * 4;
+    const int slice_stride = tiles * TILE_FLOATS * 4;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (m < p.M && n < p.Cout) {
-                    const float* src = p.partial + (long long)m * p.CoutPad + n;
-                    const long long slab = (long long)p.M * p.CoutPad;
-                    float v = 0.f;
-                    for (int sidx = 0; sidx < p.splits; ++sidx) v += src[sidx * slab];
-                    epilogue_store(p, m, n, v);
+            for (int q = 0; q < 4; ++q) {
+                float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+                const int off = base_off + (((i * TN + j) * 4 + q) * 256) * 4;
+                for (int sidx = 0; sidx < p.splits; ++sidx) {
+                    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + sidx * slice_stride, 0, 16 /*sc1*/);
+                    v0 += __uint_as_float(t.x); v1 += __uint_as_float(t.y);
+                    v2 += __uint_as_float(t.z); v3 += __uint_as_float(t.w);
+                }
+                const float vv[4] = {v0, v1, v2, v3};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int m = m0 + wm * (BM / 2) + i * 32 + e + 8 * q + 4 * (lane >> 5);
+                    if (m < p.M && n < p.Cout) epilogue_store(p, m, n, vv[e]);
                 }
             }
         }
@@ -304,7 +318,7 @@ int conv_tile_bn(int tile) { return 64; }
 template <int TM, int TN>
 static void launch_t(const ConvParams& p, hipStream_t s) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
-    dim3 grid(((p.M + BM - 1) / BM) * (p.CoutPad / BN), 1, p.splits);
+    dim3 grid(((p.M + BM - 1) / BM) * (p.CoutPad / BN) * p.splits);
     const bool vec = (p.Cin % 32 == 0) && (p.in_ld % 4 == 0);
     hipEvent_t e0 = g_conv_prof ? g_conv_prof->e0 : nullptr, e1 = g_conv_prof ? g_conv_prof->e1 : nullptr;
     // hipExtLaunchKernelGGL stamps e0/e1 with the kernel's own begin/end (no host-side event gap)

@@ -35,6 +35,17 @@ Tensor Net::new_tensor(int H, int W, int C) {
 
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+float* Net::upload_weights(const float* host, size_t count) {
+    if (reuse_) {
+        BP_CHECK(store_cursor_ < store_->ptrs.size(), "weight store exhausted (clone of a different network?)");
+        return store_->ptrs[store_cursor_++];
+    }
+    float* d = store_->arena.alloc(count);
+    BP_HIP(hipMemcpy(d, host, count * sizeof(float), hipMemcpyHostToDevice));
+    store_->ptrs.push_back(d);
+    return d;
+}
+
 static void choose_launch(const Op& op, int batch, int force_tile, int sk_target, int sk_min_chunks, int sk_max,
                           int* tile, int* splits, int* cps) {
     const ConvParams& c = op.conv;
@@ -59,27 +70,31 @@ int Net::add_conv(const std::string& name, const Tensor& in, const Tensor& out_v
     const int K = k * k * Cin;
     const int Kpad = round_up(K, 32);
     const int CoutPad = round_up(Cout, 64);
-    std::vector<float> W((size_t)CoutPad * Kpad, 0.f), B(CoutPad, 0.f);
-    for (int co = 0; co < Cout; ++co) {
-        double s = 1.0, b = 0.0;
-        if (cw.bn_scale) {
-            s = (double)cw.bn_scale[co] / std::sqrt((double)cw.bn_var[co] + (double)bn_eps);
-            b = (double)cw.bn_bias[co] - (double)cw.bn_mean[co] * s;
-        } else if (cw.bias) {
-            b = cw.bias[co];
+    float *dW, *dB;
+    if (reuse_) {
+        dW = upload_weights(nullptr, 0);
+        dB = upload_weights(nullptr, 0);
+    } else {
+        std::vector<float> W((size_t)CoutPad * Kpad, 0.f), B(CoutPad, 0.f);
+        for (int co = 0; co < Cout; ++co) {
+            double s = 1.0, b = 0.0;
+            if (cw.bn_scale) {
+                s = (double)cw.bn_scale[co] / std::sqrt((double)cw.bn_var[co] + (double)bn_eps);
+                b = (double)cw.bn_bias[co] - (double)cw.bn_mean[co] * s;
+            } else if (cw.bias) {
+                b = cw.bias[co];
+            }
+            int n = co;
+            if (store_mode == ST_PIXSHUF) n = (co & 3) * (Cout / 4) + (co >> 2);
+            B[n] = (float)b;
+            float* dst = W.data() + (size_t)n * Kpad;
+            const float* src = cw.w + (size_t)co * Cin * k * k;
+            for (int ci = 0; ci < Cin; ++ci)
+                for (int t = 0; t < k * k; ++t) dst[(size_t)t * Cin + ci] = (float)((double)src[(size_t)ci * k * k + t] * s);
         }
-        int n = co;
-        if (store_mode == ST_PIXSHUF) n = (co & 3) * (Cout / 4) + (co >> 2);
-        B[n] = (float)b;
-        float* dst = W.data() + (size_t)n * Kpad;
-        const float* src = cw.w + (size_t)co * Cin * k * k;
-        for (int ci = 0; ci < Cin; ++ci)
-            for (int t = 0; t < k * k; ++t) dst[(size_t)t * Cin + ci] = (float)((double)src[(size_t)ci * k * k + t] * s);
+        dW = upload_weights(W.data(), W.size());
+        dB = upload_weights(B.data(), B.size());
     }
-    float* dW = arena_.alloc(W.size());
-    float* dB = arena_.alloc(B.size());
-    BP_HIP(hipMemcpy(dW, W.data(), W.size() * sizeof(float), hipMemcpyHostToDevice));
-    BP_HIP(hipMemcpy(dB, B.data(), B.size() * sizeof(float), hipMemcpyHostToDevice));
 
     Op op;
     op.type = OP_CONV;
@@ -108,7 +123,10 @@ void Net::finalize() {
             int tile, splits, cps;
             choose_launch(op, b, force_tile_, sk_target_, sk_min_chunks_, 64, &tile, &splits, &cps);
             // worst case over policies that may be set later: allow up to 64 splits at batch 1
-            if (splits > 1) need = std::max(need, (size_t)splits * b * op.conv.OH * op.conv.OW * op.conv.CoutPad);
+            if (splits > 1) {
+                ConvParams q = op.conv; q.M = b * q.OH * q.OW;
+                need = std::max(need, (size_t)splits * conv_tiles(q, tile) * conv_tile_bm(tile) * 64);
+            }
         }
     }
     need = std::max(need, (size_t)4 << 20);   // headroom so a later policy change can still split small layers
@@ -132,7 +150,7 @@ void Net::run_op(const Op& op, int batch, hipStream_t s) {
             p.M = batch * p.OH * p.OW;
             int tile, splits, cps;
             choose_launch(op, batch, force_tile_, sk_target_, sk_min_chunks_, sk_max_splits_, &tile, &splits, &cps);
-            while (splits > 1 && (size_t)splits * p.M * p.CoutPad > partial_floats_) {
+            while (splits > 1 && (size_t)splits * conv_tiles(p, tile) * conv_tile_bm(tile) * 64 > partial_floats_) {
                 --splits;
                 cps = (p.nchunks + splits - 1) / splits;
                 splits = (p.nchunks + cps - 1) / cps;
@@ -273,8 +291,9 @@ static std::vector<int> parse_ints(const std::string& s) {
 }
 
 // ------------------------------------------------------------------ YoloNet
-YoloNet::YoloNet(const std::string& cfg_text, const float* stream, size_t n_floats, int reso, int max_batch)
-    : Net(max_batch), reso_(reso) {
+YoloNet::YoloNet(const std::string& cfg_text, const float* stream, size_t n_floats, int reso, int max_batch,
+                 std::shared_ptr<WeightStore> store)
+    : Net(max_batch, store), cfg_text_(cfg_text), n_floats_(n_floats), reso_(reso) {
     BP_CHECK(reso % 32 == 0 && reso > 32, "reso must be a multiple of 32 and > 32 (dataloader.py:298-299)");
     const std::vector<CfgBlock> L = parse_cfg(cfg_text);
     const int n = (int)L.size();
@@ -490,8 +509,9 @@ void YoloNet::forward(const float* d_img, bool nhwc_input, int batch, float* d_p
 }
 
 // ------------------------------------------------------------------ KpdNet (FastPose)
-KpdNet::KpdNet(const float* stream, size_t n_floats, int n_classes, int max_batch, int inH, int inW)
-    : Net(max_batch), inH_(inH), inW_(inW) {
+KpdNet::KpdNet(const float* stream, size_t n_floats, int n_classes, int max_batch, int inH, int inW,
+               std::shared_ptr<WeightStore> store)
+    : Net(max_batch, store), n_floats_(n_floats), n_classes_(n_classes), inH_(inH), inW_(inW) {
     BP_CHECK(inH % 32 == 0 && inW % 32 == 0, "KPD input must be a multiple of 32");
     BP_CHECK(n_classes >= 1, "n_classes");
     outC_ = std::min(n_classes, 50);   // InferenNet_fast narrows to the first 50 maps (main_fast_inference.py:44)
@@ -508,11 +528,7 @@ KpdNet::KpdNet(const float* stream, size_t n_floats, int n_classes, int max_batc
         cw.w = take((size_t)cout * cin * k * k);
         return cw;
     };
-    auto upload = [&](const float* h, size_t cnt) {
-        float* d = arena_.alloc(cnt);
-        BP_HIP(hipMemcpy(d, h, cnt * sizeof(float), hipMemcpyHostToDevice));
-        return d;
-    };
+    auto upload = [&](const float* h, size_t cnt) { return upload_weights(h, cnt); };
     in_nhwc_ = arena_.alloc((size_t)max_batch * inH * inW * 3);
     Tensor x;
     x.p = in_nhwc_; x.H = inH; x.W = inW; x.C = 3; x.ld = 3;

@@ -54,9 +54,17 @@ struct ConvWeights {   // one conv as it arrives in the stream (un-folded)
     const float* bias = nullptr;
 };
 
+// packed (BN-folded) filters on the device, shared by every engine clone that serves another stream
+struct WeightStore {
+    Arena arena;
+    std::vector<float*> ptrs;
+};
+
 class Net {
 public:
-    explicit Net(int max_batch) : max_batch_(max_batch) {}
+    explicit Net(int max_batch, std::shared_ptr<WeightStore> store = nullptr)
+        : max_batch_(max_batch), store_(store ? store : std::make_shared<WeightStore>()), reuse_(store != nullptr) {}
+    std::shared_ptr<WeightStore> weight_store() const { return store_; }
     virtual ~Net() = default;
     int max_batch() const { return max_batch_; }
     void run_ops(int batch, hipStream_t s);
@@ -83,7 +91,11 @@ protected:
     Tensor new_tensor(int H, int W, int C);
     void finalize();   // allocate split-K workspace
 
+    float* upload_weights(const float* host, size_t count);   // through the shared store (reused by clones)
     int max_batch_;
+    std::shared_ptr<WeightStore> store_;
+    bool reuse_;
+    size_t store_cursor_ = 0;
     Arena arena_;
     std::vector<Op> ops_;
     std::vector<Tensor> taps_;
@@ -98,7 +110,9 @@ protected:
 
 class YoloNet : public Net {
 public:
-    YoloNet(const std::string& cfg_text, const float* stream, size_t n_floats, int reso, int max_batch);
+    YoloNet(const std::string& cfg_text, const float* stream, size_t n_floats, int reso, int max_batch,
+            std::shared_ptr<WeightStore> store = nullptr);
+    YoloNet* clone() const { return new YoloNet(cfg_text_, nullptr, n_floats_, reso_, max_batch_, store_); }
     int rows() const { return rows_; }
     int attrs() const { return attrs_; }
     int reso() const { return reso_; }
@@ -108,6 +122,8 @@ public:
     float* input_nhwc() { return in_nhwc_; }
     float* pred_buffer() { return pred_; }
 private:
+    std::string cfg_text_;
+    size_t n_floats_ = 0;
     int reso_, rows_ = 0, attrs_ = 0;
     float* in_nhwc_ = nullptr;
     float* pred_ = nullptr;
@@ -116,7 +132,9 @@ private:
 
 class KpdNet : public Net {
 public:
-    KpdNet(const float* stream, size_t n_floats, int n_classes, int max_batch, int inH = 320, int inW = 256);
+    KpdNet(const float* stream, size_t n_floats, int n_classes, int max_batch, int inH = 320, int inW = 256,
+           std::shared_ptr<WeightStore> store = nullptr);
+    KpdNet* clone() const { return new KpdNet(nullptr, n_floats_, n_classes_, max_batch_, inH_, inW_, store_); }
     int out_c() const { return outC_; }
     int out_h() const { return inH_ / 4; }
     int out_w() const { return inW_ / 4; }
@@ -126,6 +144,8 @@ public:
     void forward(const float* d_inps, bool nhwc_input, int batch, float* d_hm, float* d_kp, hipStream_t s);
     float* input_nhwc() { return in_nhwc_; }
 private:
+    size_t n_floats_ = 0;
+    int n_classes_ = 0;
     int inH_, inW_, outC_;
     float* in_nhwc_ = nullptr;
     float* hm_ = nullptr;

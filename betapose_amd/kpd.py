@@ -136,9 +136,20 @@ class FastPoseHIP:
         _lib.check(_lib.lib().bp_kpd_tap_copy(self._h, i, batch, t.data_ptr(), _lib.current_stream()))
         return t
 
-    def set_policy(self, sk_target_blocks: int = 512, sk_min_chunks: int = 4, force_tile: int = -1):
+    def set_policy(self, sk_target_blocks: int = 512, sk_min_chunks: int = 4, sk_max_splits: int = 8,
+                   force_tile: int = -1):
         self._ensure()
-        _lib.lib().bp_kpd_set_policy(self._h, sk_target_blocks, sk_min_chunks, force_tile)
+        _lib.lib().bp_kpd_set_policy(self._h, sk_target_blocks, sk_min_chunks, sk_max_splits, force_tile)
+
+    def clone(self):
+        """Second engine over the same device filters (own activations): one per concurrent stream."""
+        import copy
+        self._ensure()
+        other = copy.copy(self)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().bp_kpd_clone(self._h, C.byref(h)))
+        other._h = h
+        return other
 
     def profile(self, batch: int = 1, iters: int = 10):
         """Eager pass with hipEvent pairs per op -> (ms[n_ops], info[n_ops,4] = is_conv, tile, vec, splits)."""

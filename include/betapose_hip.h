@@ -65,6 +65,8 @@ int bp_device_name(int device, char* out, int cap);
 int bp_yolo_create(const char* cfg_path, const char* weights_path, int reso, int max_batch, int device, bp_yolo** out);
 int bp_yolo_create_from_memory(const char* cfg_text, const float* stream, size_t n_floats, int reso, int max_batch,
                                int device, bp_yolo** out);
+/* second engine over the SAME device filters (own activations/workspace): one per concurrent stream */
+int bp_yolo_clone(const bp_yolo* y, bp_yolo** out);
 void bp_yolo_destroy(bp_yolo* y);
 int bp_yolo_rows(const bp_yolo* y);             /* 10647 at reso 416 */
 int bp_yolo_attrs(const bp_yolo* y);            /* 5 + classes */
@@ -79,6 +81,7 @@ int bp_yolo_tap_copy(bp_yolo* y, int i, int batch, float* d_out_nchw, void* stre
 
 /* ---- key-point detector ---- */
 int bp_kpd_create(const float* stream, size_t n_floats, int n_classes, int max_batch, int device, bp_kpd** out);
+int bp_kpd_clone(const bp_kpd* k, bp_kpd** out);
 void bp_kpd_destroy(bp_kpd* k);
 int bp_kpd_forward(bp_kpd* k, const float* d_inps_nchw, int batch, float* d_hm, void* stream);
 /* d_hm may be NULL; d_kp: [batch][50][6] */
@@ -87,9 +90,10 @@ int bp_kpd_tap_count(const bp_kpd* k);
 int bp_kpd_tap_info(const bp_kpd* k, int i, char* name, int cap, int* C, int* H, int* W);
 int bp_kpd_tap_copy(bp_kpd* k, int i, int batch, float* d_out_nchw, void* stream);
 
-/* launch-policy knobs (tuning / tests): split-K target block count, minimum chunks per split, forced tile (-1 auto) */
-int bp_yolo_set_policy(bp_yolo* y, int sk_target_blocks, int sk_min_chunks, int force_tile);
-int bp_kpd_set_policy(bp_kpd* k, int sk_target_blocks, int sk_min_chunks, int force_tile);
+/* launch-policy knobs (tuning / tests): split-K target block count, minimum K-chunks (of 32) per slice, maximum
+ * slices, forced tile (-1 auto) */
+int bp_yolo_set_policy(bp_yolo* y, int sk_target_blocks, int sk_min_chunks, int sk_max_splits, int force_tile);
+int bp_kpd_set_policy(bp_kpd* k, int sk_target_blocks, int sk_min_chunks, int sk_max_splits, int force_tile);
 /* per-op static description: returns number of ops; fills up to cap entries of (flops, bytes) per image */
 int bp_yolo_op_stats(const bp_yolo* y, double* flops, double* bytes, int cap);
 int bp_kpd_op_stats(const bp_kpd* k, double* flops, double* bytes, int cap);
