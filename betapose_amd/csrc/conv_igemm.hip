@@ -11,10 +11,17 @@
 // yolo/darknet.py:240-259 and KPD/src/models/layers/{SE_Resnet,DUC}.py.
 //
 // Block = 256 threads = 4 waves (one per SIMD), 2x2 over a (64*TM)x(64*TN) output
-// tile; K is walked in chunks of 32 (one filter tap slice: ci0..ci0+31 are
-// contiguous in NHWC), global -> registers -> LDS double buffer, one barrier per
-// chunk.  LDS rows are padded to 36 floats so the ds_read_b128 fragment reads are
-// bank-conflict free (row stride 144 B covers all 64 banks over 16 rows).
+// tile; K is walked in chunks of 32 (one filter-tap slice: ci0..ci0+31 are
+// contiguous in NHWC).  global -> registers -> LDS, register prefetch TWO chunks
+// ahead (two register sets, loop unrolled by two), LDS double buffer, one barrier
+// per chunk.  Main-loop instruction diet (rocprofv3: the first version spent 29 %
+// of wave cycles issuing non-MFMA instructions): the chunk -> (tap, ci0) walk is
+// wave-uniform scalar state advanced by increments (no divisions); every lane
+// keeps one 32-bit byte offset per tile row plus a bit-mask of which filter taps
+// fall inside the image; loads go through raw buffer descriptors, so an
+// out-of-image tap is just an out-of-range offset that the hardware zero-fills.
+// LDS rows are padded to 36 floats: the ds_read_b128 fragment reads are bank-
+// conflict free (row stride 144 B covers all 64 banks over 16 rows).
 // Fragment trick: lane l reads A[row=l&31][4h..4h+3] (h=l>>5) as one b128 and feeds
 // component j to MFMA j, so MFMA j contracts k = {j, 4+j} of the 8-wide sub-chunk;
 // B uses the same k mapping, and the sum over k is order-free.
@@ -26,11 +33,12 @@ namespace bp {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: stays in VGPRs (HIP's float4 struct
-                                                           // made hipcc park the prefetch registers in scratch)
+// native vector types: they stay in VGPRs (HIP's float4 struct made hipcc park the prefetch registers in scratch)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 static constexpr int BK = 32;
 static constexpr int LDS_LD = 36;
+static constexpr unsigned OOB = 0x7fffff00u;   // byte offset beyond any descriptor's num_records -> load returns 0
 
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == ACT_LEAKY) return v > 0.f ? v : 0.1f * v;
@@ -38,9 +46,11 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v;
 }
 
-// v = raw accumulator for output element (m, n)
-__device__ __forceinline__ void epilogue_store(const ConvParams& p, int m, int n, float v) {
-    v += p.bias[n];
+// v = raw accumulator for output element (m, n); bias = p.bias[n] (loaded once per lane by the caller: the
+// epilogue's stores may alias p.bias as far as the compiler knows, so an in-loop load is re-issued and waited
+// for after every store -- 16 serialized L2 round trips per tile, measured as the dominant cost of short layers)
+__device__ __forceinline__ void epilogue_store(const ConvParams& p, int m, int n, float v, float bias) {
+    v += bias;
     int b = 0, pix = m;
     const int hw = p.OH * p.OW;
     const bool need_pix = p.store_mode != ST_NHWC || p.res_scale != nullptr;
@@ -82,44 +92,39 @@ __device__ __forceinline__ void epilogue_store(const ConvParams& p, int m, int n
     }
 }
 
-// one float4 (4 consecutive k) of im2col row for chunk c; zero outside the image / past Ktrue
-template <bool VEC>
-__device__ __forceinline__ f32x4 load_a_row(const ConvParams& p, int c, int cpt, int c4, int bh, int iy0, int ix0,
-                                             bool& ok_out) {
-    f32x4 out = {0.f, 0.f, 0.f, 0.f};
-    ok_out = true;
-    if constexpr (VEC) {
-        const int tap = c / cpt;
-        const int ci0 = (c - tap * cpt) << 5;
-        const int ky = tap / p.ksize;
-        const int kx = tap - ky * p.ksize;
-        const int iy = iy0 + ky, ix = ix0 + kx;
-        // branch-free: out-of-image taps read a valid address and are zeroed by a select at LDS-store
-        // time, so the prefetch block is one basic block and nothing consumes the loads before the MFMAs
-        const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        const long long off = ok ? ((long long)(bh + iy) * p.W + ix) * p.in_ld + ci0 + c4 * 4 : 0;
-        out = *reinterpret_cast<const f32x4*>(p.in + off);   // zeroed (if !ok) when parked in LDS, after the MFMAs
-        ok_out = ok;
-    } else {
-        float v[4];
+// 16 accumulators of one lane: column n, rows m_base + (r&3) + 8*(r>>2).  Fast path (plain NHWC store, optional
+// residual): all residual loads are issued before the first store.
+__device__ __forceinline__ void epilogue_tile(const ConvParams& p, const float* v, int m_base, int n) {
+    if (n >= p.Cout) return;
+    const float bias = p.bias[n];
+    if (p.store_mode == ST_NHWC && p.res_scale == nullptr) {
+        float r[16];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int k = c * BK + c4 * 4 + e;
-            float x = 0.f;
-            if (k < p.Ktrue) {
-                const int tap = k / p.Cin;
-                const int ci = k - tap * p.Cin;
-                const int ky = tap / p.ksize;
-                const int kx = tap - ky * p.ksize;
-                const int iy = iy0 + ky, ix = ix0 + kx;
-                if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-                    x = p.in[((long long)(bh + iy) * p.W + ix) * p.in_ld + ci];
-            }
-            v[e] = x;
+        for (int e = 0; e < 16; ++e) {
+            const int m = m_base + (e & 3) + 8 * (e >> 2);
+            r[e] = (p.res && m < p.M) ? p.res[m * p.res_ld + n] : 0.f;
         }
-        out = f32x4{v[0], v[1], v[2], v[3]};
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = m_base + (e & 3) + 8 * (e >> 2);
+            float x = v[e] + bias;
+            if (!p.res_after_act) x += r[e];
+            x = apply_act(x, p.act);
+            if (p.res_after_act) x += r[e];
+            if (m < p.M) p.out[m * p.out_ld + n] = x;
+        }
+        return;
     }
-    return out;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int m = m_base + (e & 3) + 8 * (e >> 2);
+        if (m < p.M) epilogue_store(p, m, n, v[e], bias);
+    }
+}
+
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, int soff) {
+    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, soff, 0);
+    return f32x4{__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w)};
 }
 
 template <int TM, int TN, bool VEC>
@@ -147,7 +152,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     const int lr = tid >> 3, c4 = tid & 7;
     const int hw = p.OH * p.OW;
 
-    int a_bh[RA], a_iy0[RA], a_ix0[RA];
+    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.in), 0, (int)min((long long)p.N * p.H * p.W * p.in_ld * 4, (long long)OOB), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcB =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, p.CoutPad * p.Kpad * 4, 0x00020000);
+
+    // per tile row: byte offset of the (ky=0,kx=0,ci=c4*4) element (may be "negative" = before the image: wraps,
+    // only ever used added to a tap delta that brings it back in range) and the in-image tap mask
+    unsigned a_base[RA];
+    unsigned long long a_mask[RA];
+    int a_iy0[RA], a_ix0[RA], a_bh[RA];   // scalar-gather path only
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
         const int m = m0 + lr + 32 * i;
@@ -157,33 +171,82 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         const int rem = mm - b * hw;
         const int oy = rem / p.OW;
         const int ox = rem - oy * p.OW;
+        const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+        a_base[i] = (unsigned)((((b * p.H + iy0) * p.W + ix0) * p.in_ld + c4 * 4) * 4);
+        unsigned long long mask = 0;
+        if (ok)
+            for (int ky = 0; ky < p.ksize; ++ky)
+                for (int kx = 0; kx < p.ksize; ++kx)
+                    if ((unsigned)(iy0 + ky) < (unsigned)p.H && (unsigned)(ix0 + kx) < (unsigned)p.W)
+                        mask |= 1ull << (ky * p.ksize + kx);
+        a_mask[i] = mask;
         a_bh[i] = b * p.H;
-        a_iy0[i] = ok ? oy * p.stride - p.pad : -(1 << 20);
-        a_ix0[i] = ox * p.stride - p.pad;
+        a_iy0[i] = ok ? iy0 : -(1 << 20);
+        a_ix0[i] = ix0;
     }
+    unsigned b_base[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) b_base[i] = (unsigned)(((n0 + lr + 32 * i) * p.Kpad + c4 * 4) * 4);
 
-    f32x4 ra[RA], rb[RB];
-    bool ra_ok[RA];
+    // wave-uniform walk over K: chunk -> (tap, ky, kx, ci0); one division here, increments afterwards
     const int cpt = VEC ? (p.Cin >> 5) : 1;  // chunks per filter tap
+    int w_c = c_begin;                        // next chunk to load
+    int w_tap = VEC ? c_begin / cpt : 0;
+    int w_ci = VEC ? (c_begin - w_tap * cpt) << 5 : 0;
+    int w_ky = VEC ? w_tap / p.ksize : 0;
+    int w_kx = VEC ? w_tap - w_ky * p.ksize : 0;
 
-#define BP_LOAD_CHUNK(c_)                                                                          \
-    {                                                                                              \
-        const int cc = (c_);                                                                       \
-        _Pragma("unroll") for (int i = 0; i < RA; ++i)                                             \
-            ra[i] = load_a_row<VEC>(p, cc, cpt, c4, a_bh[i], a_iy0[i], a_ix0[i], ra_ok[i]);        \
-        _Pragma("unroll") for (int i = 0; i < RB; ++i)                                             \
-            rb[i] = *reinterpret_cast<const f32x4*>(p.w + (long long)(n0 + lr + 32 * i) * p.Kpad + \
-                                                     cc * BK + c4 * 4);                            \
+    f32x4 ra0[RA], rb0[RB], ra1[RA], rb1[RB];
+
+    // issue the loads of chunk w_c into (ra_, rb_) and advance the walk (clamped at the last chunk: the two
+    // speculative loads past the end re-read it and are never used)
+#define BP_LOAD_CHUNK(ra_, rb_)                                                                        \
+    {                                                                                                  \
+        if constexpr (VEC) {                                                                           \
+            const unsigned delta = (unsigned)(((w_ky * p.W + w_kx) * p.in_ld + w_ci) * 4);            \
+            _Pragma("unroll") for (int i = 0; i < RA; ++i) {                                           \
+                const bool ok = (a_mask[i] >> w_tap) & 1ull;                                           \
+                ra_[i] = buf_load4(rsrcA, ok ? a_base[i] + delta : OOB, 0);                            \
+            }                                                                                          \
+        } else {                                                                                       \
+            _Pragma("unroll") for (int i = 0; i < RA; ++i) {                                           \
+                float v_[4];                                                                           \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                        \
+                    const int k = w_c * BK + c4 * 4 + e;                                               \
+                    float x = 0.f;                                                                     \
+                    if (k < p.Ktrue) {                                                                 \
+                        const int tap = k / p.Cin;                                                     \
+                        const int ci = k - tap * p.Cin;                                                \
+                        const int ky = tap / p.ksize;                                                  \
+                        const int kx = tap - ky * p.ksize;                                             \
+                        const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;                              \
+                        if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)              \
+                            x = p.in[((long long)(a_bh[i] + iy) * p.W + ix) * p.in_ld + ci];           \
+                    }                                                                                  \
+                    v_[e] = x;                                                                         \
+                }                                                                                      \
+                ra_[i] = f32x4{v_[0], v_[1], v_[2], v_[3]};                                            \
+            }                                                                                          \
+        }                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < RB; ++i) rb_[i] = buf_load4(rsrcB, b_base[i], w_c * (BK * 4)); \
+        if (w_c + 1 < c_end) {                                                                         \
+            ++w_c;                                                                                     \
+            if constexpr (VEC) {                                                                       \
+                w_ci += 32;                                                                            \
+                if (w_ci == p.Cin) {                                                                   \
+                    w_ci = 0;                                                                          \
+                    ++w_tap;                                                                           \
+                    if (++w_kx == p.ksize) { w_kx = 0; ++w_ky; }                                       \
+                }                                                                                      \
+            }                                                                                          \
+        }                                                                                              \
     }
-#define BP_STORE_LDS(buf_)                                                                         \
-    {                                                                                              \
-        _Pragma("unroll") for (int i = 0; i < RA; ++i) {                                           \
-            f32x4 v_ = ra[i];                                                                     \
-            if (!ra_ok[i]) v_ = f32x4{0.f, 0.f, 0.f, 0.f};                                       \
-            *reinterpret_cast<f32x4*>(&As[buf_][(lr + 32 * i) * LDS_LD + c4 * 4]) = v_;            \
-        }                                                                                          \
-        _Pragma("unroll") for (int i = 0; i < RB; ++i)                                             \
-            *reinterpret_cast<f32x4*>(&Bs[buf_][(lr + 32 * i) * LDS_LD + c4 * 4]) = rb[i];         \
+#define BP_STORE_LDS(buf_, ra_, rb_)                                                                   \
+    {                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < RA; ++i)                                                 \
+            *reinterpret_cast<f32x4*>(&As[buf_][(lr + 32 * i) * LDS_LD + c4 * 4]) = ra_[i];            \
+        _Pragma("unroll") for (int i = 0; i < RB; ++i)                                                 \
+            *reinterpret_cast<f32x4*>(&Bs[buf_][(lr + 32 * i) * LDS_LD + c4 * 4]) = rb_[i];            \
     }
 
     f32x16 acc[TM][TN];
@@ -198,11 +261,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     const int a_off = wm * (BM / 2) * LDS_LD + frag_off;
     const int b_off = wn * (BN / 2) * LDS_LD + frag_off;
 
-    if (c_begin < c_end) {
-        BP_LOAD_CHUNK(c_begin);
-        BP_STORE_LDS(0);
-    }
-    __syncthreads();
 #define BP_COMPUTE(buf_)                                                                              \
     {                                                                                                 \
         const float* Ab = &As[buf_][a_off];                                                           \
@@ -221,20 +279,32 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             }                                                                                         \
         }                                                                                             \
     }
-    // steady state: prefetch chunk c+1 into registers, contract chunk c from LDS, park c+1 in the
-    // other LDS buffer, one barrier.  The last chunk is peeled so the loop body has no conditionals
-    // (a conditional prefetch makes hipcc park the prefetch registers in scratch behind a vmcnt(0)).
-    int buf = 0;
-    for (int c = c_begin; c + 1 < c_end; ++c) {
-        BP_LOAD_CHUNK(c + 1);
-        __builtin_amdgcn_sched_barrier(0);   // all global loads of chunk c+1 are issued before the MFMAs of chunk c
-        BP_COMPUTE(buf);
-        __builtin_amdgcn_sched_barrier(0);
-        BP_STORE_LDS(buf ^ 1);
+
+    if (c_begin < c_end) {
+        // prologue: chunks c, c+1 in flight; park c in LDS[0]
+        BP_LOAD_CHUNK(ra0, rb0);
+        BP_LOAD_CHUNK(ra1, rb1);
+        BP_STORE_LDS(0, ra0, rb0);
         __syncthreads();
-        buf ^= 1;
+        // steady state, two chunks per trip: while LDS[0] (chunk c) feeds the MFMAs, chunk c+1 sits in set 1
+        // and chunk c+2 is being fetched into set 0 -- every load has ~2 chunk times (~2k cycles) to land
+        for (int c = c_begin;; c += 2) {
+            BP_LOAD_CHUNK(ra0, rb0);
+            __builtin_amdgcn_sched_barrier(0);
+            BP_COMPUTE(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 1 >= c_end) break;
+            BP_STORE_LDS(1, ra1, rb1);
+            __syncthreads();
+            BP_LOAD_CHUNK(ra1, rb1);
+            __builtin_amdgcn_sched_barrier(0);
+            BP_COMPUTE(1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (c + 2 >= c_end) break;
+            BP_STORE_LDS(0, ra0, rb0);
+            __syncthreads();
+        }
     }
-    if (c_begin < c_end) BP_COMPUTE(buf);
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     if (p.splits == 1) {
@@ -243,11 +313,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+                float v[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    if (m < p.M && n < p.Cout) epilogue_store(p, m, n, acc[i][j][r]);
-                }
+                for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r];
+                epilogue_tile(p, v, m0 + wm * (BM / 2) + i * 32 + 4 * (lane >> 5), n);
             }
         return;
     }
@@ -257,9 +326,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     // order) and runs the epilogue.  Hand-off without fences (cdna_hip_programming.md G16 "R1"): write-through
     // (sc1) slab stores, every storing wave drains vmcnt, one relaxed agent-scope ticket, sc1 loads by the reducer.
     const int tiles = (int)gridDim.x / p.splits;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        p.partial, 0, (int)((long long)p.splits * tiles * (TM * TN * 4096) * 4), 0x00020000);
     constexpr int TILE_FLOATS = TM * TN * 4096;
+    const __amdgpu_buffer_rsrc_t rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(p.partial, 0, (int)((long long)p.splits * tiles * TILE_FLOATS * 4), 0x00020000);
     const int my_off = ((split * tiles + tile_id) * TILE_FLOATS + wave * (TM * TN * 1024) + lane * 4) * 4;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -284,29 +353,31 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     }
     __syncthreads();
     if (!s_last) return;
-    const int base_off = ((tile_id) * TILE_FLOATS + wave * (TM * TN * 1024) + lane * 4) * 4;
+    const int base_off = (tile_id * TILE_FLOATS + wave * (TM * TN * 1024) + lane * 4) * 4;
     const int slice_stride = tiles * TILE_FLOATS * 4;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+            float v[16];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-                const int off = base_off + (((i * TN + j) * 4 + q) * 256) * 4;
-                for (int sidx = 0; sidx < p.splits; ++sidx) {
-                    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off + sidx * slice_stride, 0, 16 /*sc1*/);
-                    v0 += __uint_as_float(t.x); v1 += __uint_as_float(t.y);
-                    v2 += __uint_as_float(t.z); v3 += __uint_as_float(t.w);
-                }
-                const float vv[4] = {v0, v1, v2, v3};
+            for (int e = 0; e < 16; ++e) v[e] = 0.f;
+            for (int sidx = 0; sidx < p.splits; ++sidx) {   // slice order: deterministic sum
+                u32x4 t[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int m = m0 + wm * (BM / 2) + i * 32 + e + 8 * q + 4 * (lane >> 5);
-                    if (m < p.M && n < p.Cout) epilogue_store(p, m, n, vv[e]);
+                for (int q = 0; q < 4; ++q)
+                    t[q] = __builtin_amdgcn_raw_buffer_load_b128(
+                        rsrc, base_off + (((i * TN + j) * 4 + q) * 256) * 4 + sidx * slice_stride, 0, 16 /*sc1*/);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v[4 * q] += __uint_as_float(t[q].x);
+                    v[4 * q + 1] += __uint_as_float(t[q].y);
+                    v[4 * q + 2] += __uint_as_float(t[q].z);
+                    v[4 * q + 3] += __uint_as_float(t[q].w);
                 }
             }
+            epilogue_tile(p, v, m0 + wm * (BM / 2) + i * 32 + 4 * (lane >> 5), n);
         }
 }
 
@@ -319,13 +390,21 @@ template <int TM, int TN>
 static void launch_t(const ConvParams& p, hipStream_t s) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     dim3 grid(((p.M + BM - 1) / BM) * (p.CoutPad / BN) * p.splits);
-    const bool vec = (p.Cin % 32 == 0) && (p.in_ld % 4 == 0);
-    hipEvent_t e0 = g_conv_prof ? g_conv_prof->e0 : nullptr, e1 = g_conv_prof ? g_conv_prof->e1 : nullptr;
-    // hipExtLaunchKernelGGL stamps e0/e1 with the kernel's own begin/end (no host-side event gap)
-    if (vec)
-        hipExtLaunchKernelGGL((conv_igemm_kernel<TM, TN, true>), grid, dim3(256), 0, s, e0, e1, 0, p);
-    else
-        hipExtLaunchKernelGGL((conv_igemm_kernel<TM, TN, false>), grid, dim3(256), 0, s, e0, e1, 0, p);
+    // vector path: whole 32-channel chunks inside one filter tap, taps addressable by a 64-bit mask
+    const bool vec = (p.Cin % 32 == 0) && (p.in_ld % 4 == 0) && p.ksize <= 8;
+    if (g_conv_prof) {
+        // hipExtLaunchKernelGGL stamps the events with the kernel's own begin/end (no host-side event gap)
+        if (vec)
+            hipExtLaunchKernelGGL((conv_igemm_kernel<TM, TN, true>), grid, dim3(256), 0, s, g_conv_prof->e0,
+                                  g_conv_prof->e1, 0, p);
+        else
+            hipExtLaunchKernelGGL((conv_igemm_kernel<TM, TN, false>), grid, dim3(256), 0, s, g_conv_prof->e0,
+                                  g_conv_prof->e1, 0, p);
+    } else if (vec) {
+        hipLaunchKernelGGL((conv_igemm_kernel<TM, TN, true>), grid, dim3(256), 0, s, p);
+    } else {
+        hipLaunchKernelGGL((conv_igemm_kernel<TM, TN, false>), grid, dim3(256), 0, s, p);
+    }
 }
 
 int conv_tiles(const ConvParams& p, int tile) {
@@ -337,6 +416,7 @@ void launch_conv(const ConvParams& p, int tile, hipStream_t s) {
     BP_CHECK(p.CoutPad % 64 == 0, "CoutPad must be a multiple of 64");
     BP_CHECK(p.Kpad % BK == 0 && p.nchunks == p.Kpad / BK, "Kpad");
     BP_CHECK(p.splits >= 1 && (p.splits == 1 || (p.partial != nullptr && p.tickets != nullptr)), "split-K workspace");
+    BP_CHECK((long long)p.N * p.H * p.W * p.in_ld * 4 < (long long)OOB, "activation tensor too large for 32-bit offsets");
     switch (tile) {
         case TILE_128x64: launch_t<2, 1>(p, s); break;
         default: launch_t<1, 1>(p, s); break;
