@@ -14,7 +14,14 @@
 // tile; K is walked in chunks of 32 (one filter-tap slice: ci0..ci0+31 are
 // contiguous in NHWC).  global -> registers -> LDS, register prefetch TWO chunks
 // ahead (two register sets, loop unrolled by two), LDS double buffer, one barrier
-// per chunk.  Main-loop instruction diet (rocprofv3: the first version spent 29 %
+// per chunk.  The chunk phase is an explicit software pipeline (ablation on MI355X: with
+// MFMAs, loads and stores all disabled the first version still took 60 % of its time --
+// per chunk ~550 cycles of instruction issue and ~480 cycles parked at waits/barrier ran
+// back-to-back with the 1024 MFMA cycles): the prefetch loads, their address math and the
+// LDS stores of the NEXT chunk are issued between the MFMAs of the current one (an MFMA
+// occupies the matrix pipe for 64 cycles after a ~8-cycle issue), and the one barrier sits
+// BEFORE the last MFMA group, so the next chunk's first fragments are read from LDS under
+// those MFMAs.  Main-loop instruction diet (rocprofv3: the first version spent 29 %
 // of wave cycles issuing non-MFMA instructions): the chunk -> (tap, ci0) walk is
 // wave-uniform scalar state advanced by increments (no divisions); every lane
 // keeps one 32-bit byte offset per tile row plus a bit-mask of which filter taps
@@ -127,6 +134,16 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned
     return f32x4{__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w)};
 }
 
+// exact for 0 <= m < 2^24, d > 0: quotient by float reciprocal + one correction step (a 32-bit integer division
+// costs ~40 VALU instructions; the tile prologue needs 2 per row)
+__device__ __forceinline__ int fast_div(int m, int d, float rcp) {
+    int q = (int)((float)m * rcp);
+    const int r = m - q * d;
+    if (r < 0) --q;
+    else if (r >= d) ++q;
+    return q;
+}
+
 template <int TM, int TN, bool VEC>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
@@ -162,23 +179,26 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     unsigned a_base[RA];
     unsigned long long a_mask[RA];
     int a_iy0[RA], a_ix0[RA], a_bh[RA];   // scalar-gather path only
+    const float rcp_hw = 1.0f / (float)hw, rcp_ow = 1.0f / (float)p.OW;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
         const int m = m0 + lr + 32 * i;
         const bool ok = m < p.M;
         const int mm = ok ? m : 0;
-        const int b = mm / hw;
+        const int b = fast_div(mm, hw, rcp_hw);
         const int rem = mm - b * hw;
-        const int oy = rem / p.OW;
+        const int oy = fast_div(rem, p.OW, rcp_ow);
         const int ox = rem - oy * p.OW;
         const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
         a_base[i] = (unsigned)((((b * p.H + iy0) * p.W + ix0) * p.in_ld + c4 * 4) * 4);
+        // taps inside the image: kx in [kx_lo, kx_hi), ky in [ky_lo, ky_hi)
+        const int kx_lo = max(0, -ix0), kx_hi = min(p.ksize, p.W - ix0);
+        const int ky_lo = max(0, -iy0), ky_hi = min(p.ksize, p.H - iy0);
         unsigned long long mask = 0;
-        if (ok)
-            for (int ky = 0; ky < p.ksize; ++ky)
-                for (int kx = 0; kx < p.ksize; ++kx)
-                    if ((unsigned)(iy0 + ky) < (unsigned)p.H && (unsigned)(ix0 + kx) < (unsigned)p.W)
-                        mask |= 1ull << (ky * p.ksize + kx);
+        if (ok && kx_hi > kx_lo) {
+            const unsigned long long rowbits = ((1ull << kx_hi) - 1ull) & ~((1ull << kx_lo) - 1ull);
+            for (int ky = ky_lo; ky < ky_hi; ++ky) mask |= rowbits << (ky * p.ksize);
+        }
         a_mask[i] = mask;
         a_bh[i] = b * p.H;
         a_iy0[i] = ok ? iy0 : -(1 << 20);
@@ -198,9 +218,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 
     f32x4 ra0[RA], rb0[RB], ra1[RA], rb1[RB];
 
-    // issue the loads of chunk w_c into (ra_, rb_) and advance the walk (clamped at the last chunk: the two
-    // speculative loads past the end re-read it and are never used)
-#define BP_LOAD_CHUNK(ra_, rb_)                                                                        \
+    // loads of chunk w_c (A rows, then filter rows), then the walk advances (clamped at the last chunk: the
+    // two speculative loads past the end re-read it and are never used)
+#define BP_LOAD_A(ra_)                                                                                 \
     {                                                                                                  \
         if constexpr (VEC) {                                                                           \
             const unsigned delta = (unsigned)(((w_ky * p.W + w_kx) * p.in_ld + w_ci) * 4);            \
@@ -228,6 +248,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                 ra_[i] = f32x4{v_[0], v_[1], v_[2], v_[3]};                                            \
             }                                                                                          \
         }                                                                                              \
+    }
+#define BP_LOAD_B(rb_)                                                                                 \
+    {                                                                                                  \
         _Pragma("unroll") for (int i = 0; i < RB; ++i) rb_[i] = buf_load4(rsrcB, b_base[i], w_c * (BK * 4)); \
         if (w_c + 1 < c_end) {                                                                         \
             ++w_c;                                                                                     \
@@ -241,6 +264,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             }                                                                                          \
         }                                                                                              \
     }
+#define BP_LOAD_CHUNK(ra_, rb_) { BP_LOAD_A(ra_); BP_LOAD_B(rb_); }
+#define BP_STORE_A(buf_, ra_)                                                                          \
+    _Pragma("unroll") for (int i = 0; i < RA; ++i)                                                     \
+        *reinterpret_cast<f32x4*>(&As[buf_][(lr + 32 * i) * LDS_LD + c4 * 4]) = ra_[i];
+#define BP_STORE_B(buf_, rb_)                                                                          \
+    _Pragma("unroll") for (int i = 0; i < RB; ++i)                                                     \
+        *reinterpret_cast<f32x4*>(&Bs[buf_][(lr + 32 * i) * LDS_LD + c4 * 4]) = rb_[i];
 #define BP_STORE_LDS(buf_, ra_, rb_)                                                                   \
     {                                                                                                  \
         _Pragma("unroll") for (int i = 0; i < RA; ++i)                                                 \
@@ -261,50 +291,66 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     const int a_off = wm * (BM / 2) * LDS_LD + frag_off;
     const int b_off = wn * (BN / 2) * LDS_LD + frag_off;
 
-#define BP_COMPUTE(buf_)                                                                              \
-    {                                                                                                 \
-        const float* Ab = &As[buf_][a_off];                                                           \
-        const float* Bb = &Bs[buf_][b_off];                                                           \
-        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                            \
-            f32x4 a[TM], b[TN];                                                                       \
-            _Pragma("unroll") for (int i = 0; i < TM; ++i) a[i] =                                     \
-                *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDS_LD + ks * 8);                       \
-            _Pragma("unroll") for (int j = 0; j < TN; ++j) b[j] =                                     \
-                *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDS_LD + ks * 8);                       \
-            _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) { \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0); \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0); \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0); \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0); \
-            }                                                                                         \
-        }                                                                                             \
+    // fragment registers for two consecutive 8-wide sub-chunks
+    f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+#define BP_RD(buf_, ks_, fa_, fb_)                                                                     \
+    {                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) fa_[i] =                                        \
+            *reinterpret_cast<const f32x4*>(&As[buf_][a_off + i * 32 * LDS_LD + (ks_) * 8]);           \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) fb_[j] =                                        \
+            *reinterpret_cast<const f32x4*>(&Bs[buf_][b_off + j * 32 * LDS_LD + (ks_) * 8]);           \
+    }
+#define BP_MF(fa_, fb_, comp_)                                                                         \
+    _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j)      \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[i].comp_, fb_[j].comp_, acc[i][j], 0, 0, 0);
+#define BP_SB() __builtin_amdgcn_sched_barrier(0)
+    // One chunk phase.  On entry: LDS[cur_] holds chunk c and (fa0, fb0) its sub-chunk 0; (rna_, rnb_) hold chunk
+    // c+1 (in flight since the previous phase); (rfa_, rfb_) receive chunk c+2.  The barrier guarantees both
+    // "everybody's chunk c+1 is in LDS[cur_^1]" and "everybody is done reading LDS[cur_]".
+#define BP_PHASE(cur_, rna_, rnb_, rfa_, rfb_)                                                         \
+    {                                                                                                  \
+        BP_RD(cur_, 1, fa1, fb1);                    BP_SB();                                          \
+        BP_MF(fa0, fb0, x);  BP_LOAD_A(rfa_);        BP_SB();                                          \
+        BP_MF(fa0, fb0, y);  BP_LOAD_B(rfb_);        BP_SB();                                          \
+        BP_MF(fa0, fb0, z);                                                                            \
+        BP_MF(fa0, fb0, w);                          BP_SB();                                          \
+        BP_RD(cur_, 2, fa0, fb0);                    BP_SB();                                          \
+        BP_MF(fa1, fb1, x);  BP_STORE_A((cur_) ^ 1, rna_);  BP_SB();                                   \
+        BP_MF(fa1, fb1, y);  BP_STORE_B((cur_) ^ 1, rnb_);  BP_SB();                                   \
+        BP_MF(fa1, fb1, z);                                                                            \
+        BP_MF(fa1, fb1, w);                          BP_SB();                                          \
+        BP_RD(cur_, 3, fa1, fb1);                    BP_SB();                                          \
+        BP_MF(fa0, fb0, x);                                                                            \
+        BP_MF(fa0, fb0, y);                                                                            \
+        BP_MF(fa0, fb0, z);                                                                            \
+        BP_MF(fa0, fb0, w);                          BP_SB();                                          \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                             \
+        __syncthreads();                             BP_SB();                                          \
+        BP_RD((cur_) ^ 1, 0, fa0, fb0);              BP_SB();                                          \
+        BP_MF(fa1, fb1, x);                                                                            \
+        BP_MF(fa1, fb1, y);                                                                            \
+        BP_MF(fa1, fb1, z);                                                                            \
+        BP_MF(fa1, fb1, w);                          BP_SB();                                          \
     }
 
     if (c_begin < c_end) {
-        // prologue: chunks c, c+1 in flight; park c in LDS[0]
+        // prologue: chunks c, c+1 in flight; park c in LDS[0]; first fragments
         BP_LOAD_CHUNK(ra0, rb0);
         BP_LOAD_CHUNK(ra1, rb1);
-        BP_STORE_LDS(0, ra0, rb0);
+        BP_STORE_A(0, ra0);
+        BP_STORE_B(0, rb0);
         __syncthreads();
-        // steady state, two chunks per trip: while LDS[0] (chunk c) feeds the MFMAs, chunk c+1 sits in set 1
-        // and chunk c+2 is being fetched into set 0 -- every load has ~2 chunk times (~2k cycles) to land
+        BP_RD(0, 0, fa0, fb0);
+        // two chunks per trip (the register sets swap roles).  Past the last chunk the pipeline keeps loading /
+        // parking / reading the clamped last chunk into buffers nobody consumes -- no conditionals in the phase.
         for (int c = c_begin;; c += 2) {
-            BP_LOAD_CHUNK(ra0, rb0);
-            __builtin_amdgcn_sched_barrier(0);
-            BP_COMPUTE(0);
-            __builtin_amdgcn_sched_barrier(0);
+            BP_PHASE(0, ra1, rb1, ra0, rb0);
             if (c + 1 >= c_end) break;
-            BP_STORE_LDS(1, ra1, rb1);
-            __syncthreads();
-            BP_LOAD_CHUNK(ra1, rb1);
-            __builtin_amdgcn_sched_barrier(0);
-            BP_COMPUTE(1);
-            __builtin_amdgcn_sched_barrier(0);
+            BP_PHASE(1, ra0, rb0, ra1, rb1);
             if (c + 2 >= c_end) break;
-            BP_STORE_LDS(0, ra0, rb0);
-            __syncthreads();
         }
     }
+    __syncthreads();
 
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     if (p.splits == 1) {
