@@ -218,21 +218,43 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 
     f32x4 ra0[RA], rb0[RB], ra1[RA], rb1[RB];
 
-    // loads of chunk w_c (A rows, then filter rows), then the walk advances (clamped at the last chunk: the
-    // two speculative loads past the end re-read it and are never used)
-#define BP_LOAD_A(ra_)                                                                                 \
+    // address registers for the NEXT prefetch: computed one phase ahead (under the last MFMAs of a phase), so
+    // issuing the loads is 4 instructions.  BP_ADDR also advances the walk (clamped at the last chunk: the
+    // speculative loads past the end re-read it and are never used).
+    unsigned va[RA];
+    int sb = 0, ld_c = 0;
+#define BP_ADDR()                                                                                      \
     {                                                                                                  \
         if constexpr (VEC) {                                                                           \
             const unsigned delta = (unsigned)(((w_ky * p.W + w_kx) * p.in_ld + w_ci) * 4);            \
             _Pragma("unroll") for (int i = 0; i < RA; ++i) {                                           \
                 const bool ok = (a_mask[i] >> w_tap) & 1ull;                                           \
-                ra_[i] = buf_load4(rsrcA, ok ? a_base[i] + delta : OOB, 0);                            \
+                va[i] = ok ? a_base[i] + delta : OOB;                                                  \
             }                                                                                          \
+        }                                                                                              \
+        ld_c = w_c;                                                                                    \
+        sb = w_c * (BK * 4);                                                                           \
+        if (w_c + 1 < c_end) {                                                                         \
+            ++w_c;                                                                                     \
+            if constexpr (VEC) {                                                                       \
+                w_ci += 32;                                                                            \
+                if (w_ci == p.Cin) {                                                                   \
+                    w_ci = 0;                                                                          \
+                    ++w_tap;                                                                           \
+                    if (++w_kx == p.ksize) { w_kx = 0; ++w_ky; }                                       \
+                }                                                                                      \
+            }                                                                                          \
+        }                                                                                              \
+    }
+#define BP_LOAD_A(ra_)                                                                                 \
+    {                                                                                                  \
+        if constexpr (VEC) {                                                                           \
+            _Pragma("unroll") for (int i = 0; i < RA; ++i) ra_[i] = buf_load4(rsrcA, va[i], 0);        \
         } else {                                                                                       \
             _Pragma("unroll") for (int i = 0; i < RA; ++i) {                                           \
                 float v_[4];                                                                           \
                 _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                        \
-                    const int k = w_c * BK + c4 * 4 + e;                                               \
+                    const int k = ld_c * BK + c4 * 4 + e;                                              \
                     float x = 0.f;                                                                     \
                     if (k < p.Ktrue) {                                                                 \
                         const int tap = k / p.Cin;                                                     \
@@ -250,21 +272,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         }                                                                                              \
     }
 #define BP_LOAD_B(rb_)                                                                                 \
-    {                                                                                                  \
-        _Pragma("unroll") for (int i = 0; i < RB; ++i) rb_[i] = buf_load4(rsrcB, b_base[i], w_c * (BK * 4)); \
-        if (w_c + 1 < c_end) {                                                                         \
-            ++w_c;                                                                                     \
-            if constexpr (VEC) {                                                                       \
-                w_ci += 32;                                                                            \
-                if (w_ci == p.Cin) {                                                                   \
-                    w_ci = 0;                                                                          \
-                    ++w_tap;                                                                           \
-                    if (++w_kx == p.ksize) { w_kx = 0; ++w_ky; }                                       \
-                }                                                                                      \
-            }                                                                                          \
-        }                                                                                              \
-    }
-#define BP_LOAD_CHUNK(ra_, rb_) { BP_LOAD_A(ra_); BP_LOAD_B(rb_); }
+    _Pragma("unroll") for (int i = 0; i < RB; ++i) rb_[i] = buf_load4(rsrcB, b_base[i], sb);
 #define BP_STORE_A(buf_, ra_)                                                                          \
     _Pragma("unroll") for (int i = 0; i < RA; ++i)                                                     \
         *reinterpret_cast<f32x4*>(&As[buf_][(lr + 32 * i) * LDS_LD + c4 * 4]) = ra_[i];
@@ -305,21 +313,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa_[i].comp_, fb_[j].comp_, acc[i][j], 0, 0, 0);
 #define BP_SB() __builtin_amdgcn_sched_barrier(0)
     // One chunk phase.  On entry: LDS[cur_] holds chunk c and (fa0, fb0) its sub-chunk 0; (rna_, rnb_) hold chunk
-    // c+1 (in flight since the previous phase); (rfa_, rfb_) receive chunk c+2.  The barrier guarantees both
-    // "everybody's chunk c+1 is in LDS[cur_^1]" and "everybody is done reading LDS[cur_]".
+    // c+1 (in flight since the previous phase); (rfa_, rfb_) receive chunk c+2, whose addresses (va, sb) were
+    // computed under the previous phase's last MFMAs.  The barrier guarantees both "everybody's chunk c+1 is in
+    // LDS[cur_^1]" and "everybody is done reading LDS[cur_]".  Every non-MFMA group is small enough for the
+    // 64-cycle shadow of the MFMA issued just before it.
 #define BP_PHASE(cur_, rna_, rnb_, rfa_, rfb_)                                                         \
     {                                                                                                  \
         BP_RD(cur_, 1, fa1, fb1);                    BP_SB();                                          \
         BP_MF(fa0, fb0, x);  BP_LOAD_A(rfa_);        BP_SB();                                          \
         BP_MF(fa0, fb0, y);  BP_LOAD_B(rfb_);        BP_SB();                                          \
-        BP_MF(fa0, fb0, z);                                                                            \
-        BP_MF(fa0, fb0, w);                          BP_SB();                                          \
-        BP_RD(cur_, 2, fa0, fb0);                    BP_SB();                                          \
+        BP_MF(fa0, fb0, z);                          BP_SB();                                          \
+        BP_MF(fa0, fb0, w);  BP_RD(cur_, 2, fa0, fb0);  BP_SB();                                       \
         BP_MF(fa1, fb1, x);  BP_STORE_A((cur_) ^ 1, rna_);  BP_SB();                                   \
         BP_MF(fa1, fb1, y);  BP_STORE_B((cur_) ^ 1, rnb_);  BP_SB();                                   \
-        BP_MF(fa1, fb1, z);                                                                            \
-        BP_MF(fa1, fb1, w);                          BP_SB();                                          \
-        BP_RD(cur_, 3, fa1, fb1);                    BP_SB();                                          \
+        BP_MF(fa1, fb1, z);                          BP_SB();                                          \
+        BP_MF(fa1, fb1, w);  BP_RD(cur_, 3, fa1, fb1);  BP_SB();                                       \
         BP_MF(fa0, fb0, x);                                                                            \
         BP_MF(fa0, fb0, y);                                                                            \
         BP_MF(fa0, fb0, z);                                                                            \
@@ -327,28 +335,31 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                             \
         __syncthreads();                             BP_SB();                                          \
         BP_RD((cur_) ^ 1, 0, fa0, fb0);              BP_SB();                                          \
-        BP_MF(fa1, fb1, x);                                                                            \
+        BP_MF(fa1, fb1, x);  BP_ADDR();              BP_SB();                                          \
         BP_MF(fa1, fb1, y);                                                                            \
         BP_MF(fa1, fb1, z);                                                                            \
         BP_MF(fa1, fb1, w);                          BP_SB();                                          \
     }
 
     if (c_begin < c_end) {
-        // prologue: chunks c, c+1 in flight; park c in LDS[0]; first fragments
-        BP_LOAD_CHUNK(ra0, rb0);
-        BP_LOAD_CHUNK(ra1, rb1);
+        // prologue: chunks c, c+1 in flight; park c in LDS[0]; first fragments; addresses of chunk c+2
+        BP_ADDR(); BP_LOAD_A(ra0); BP_LOAD_B(rb0);
+        BP_ADDR(); BP_LOAD_A(ra1); BP_LOAD_B(rb1);
+        BP_ADDR();
         BP_STORE_A(0, ra0);
         BP_STORE_B(0, rb0);
         __syncthreads();
         BP_RD(0, 0, fa0, fb0);
-        // two chunks per trip (the register sets swap roles).  Past the last chunk the pipeline keeps loading /
-        // parking / reading the clamped last chunk into buffers nobody consumes -- no conditionals in the phase.
-        for (int c = c_begin;; c += 2) {
+        // two chunks per trip (the register sets swap roles; after a pair everything is back in place), then an
+        // odd tail.  Past the last chunk the pipeline keeps loading / parking / reading the clamped last chunk
+        // into buffers nobody consumes -- no conditionals inside a phase, one loop exit (a mid-body exit made
+        // hipcc ping-pong the 16 accumulator registers through v_accvgpr_mov every phase).
+        const int nch = c_end - c_begin;
+        for (int it = 0; it < (nch >> 1); ++it) {
             BP_PHASE(0, ra1, rb1, ra0, rb0);
-            if (c + 1 >= c_end) break;
             BP_PHASE(1, ra0, rb0, ra1, rb1);
-            if (c + 2 >= c_end) break;
         }
+        if (nch & 1) BP_PHASE(0, ra1, rb1, ra0, rb0);
     }
     __syncthreads();
 
