@@ -1,0 +1,81 @@
+"""Multi-GPU driver pieces: one process per GPU, frames sharded by image.
+
+There is no cross-frame state on the path, so the only communication is
+  * a broadcast of the two fp32 weight streams from rank 0 at start-up (RCCL on GPUs, gloo in CPU tests),
+  * a gather of the fixed-size per-frame result records (316 floats) at the end of the stream,
+  * barriers around timed regions.
+Frame i of the (sorted) list goes to rank ``i % world`` -- round-robin keeps ranks balanced on a streamed
+split.  Metrics are computed on rank 0 from the gathered records, so they are identical to a 1-GPU run.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+
+def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
+    """Indices (into the sorted frame list) this rank processes."""
+    if not (0 <= rank < world):
+        raise ValueError("rank %d not in [0, %d)" % (rank, world))
+    return list(range(rank, n_items, world))
+
+
+def owner_of(index: int, world: int) -> int:
+    return index % world
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+def is_dist() -> bool:
+    dist = _dist()
+    return dist.is_available() and dist.is_initialized()
+
+
+def broadcast_stream(stream: Optional[np.ndarray], src: int = 0, device=None) -> np.ndarray:
+    """Broadcast a flat fp32 weight stream (rank ``src`` passes the array, others ``None``)."""
+    import torch
+    dist = _dist()
+    if not is_dist() or dist.get_world_size() == 1:
+        return np.ascontiguousarray(stream, dtype=np.float32)
+    rank = dist.get_rank()
+    dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+    n = torch.tensor([stream.size if rank == src else 0], dtype=torch.long, device=dev)
+    dist.broadcast(n, src)
+    t = torch.from_numpy(np.ascontiguousarray(stream, dtype=np.float32)).to(dev) if rank == src \
+        else torch.empty(int(n[0]), dtype=torch.float32, device=dev)
+    dist.broadcast(t, src)
+    return t.cpu().numpy()
+
+
+def gather_records(local_records: np.ndarray, local_indices: Sequence[int], n_total: int, dst: int = 0, device=None):
+    """Gather per-frame records [n_local, R] to ``dst`` and put them back in global frame order.
+    Returns [n_total, R] on ``dst`` (None elsewhere)."""
+    import torch
+    dist = _dist()
+    local_records = np.ascontiguousarray(local_records, dtype=np.float32)
+    if not is_dist() or dist.get_world_size() == 1:
+        out = np.zeros((n_total, local_records.shape[1]), np.float32)
+        out[list(local_indices)] = local_records
+        return out
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+    R = local_records.shape[1]
+    per = (n_total + world - 1) // world           # pad every rank to the same count
+    buf = torch.zeros((per, R + 1), dtype=torch.float32, device=dev)
+    if len(local_indices):
+        buf[:len(local_indices), :R] = torch.from_numpy(local_records).to(dev)
+        buf[:len(local_indices), R] = torch.tensor(list(local_indices), dtype=torch.float32, device=dev) + 1.0
+    bufs = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(bufs, buf)
+    if rank != dst:
+        return None
+    out = np.zeros((n_total, R), np.float32)
+    for b in bufs:
+        b = b.cpu().numpy()
+        valid = b[:, R] > 0
+        out[(b[valid, R] - 1).astype(np.int64)] = b[valid, :R]
+    return out

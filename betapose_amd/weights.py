@@ -37,6 +37,8 @@ def read_darknet_weights(path: str) -> Tuple[np.ndarray, int, np.ndarray]:
         raise ValueError("%s: truncated .weights header" % path)
     major, minor, revision = struct.unpack_from("<iii", raw, 0)
     if major * 10 + minor >= 2:
+        if len(raw) < 20:
+            raise ValueError("%s: truncated .weights header" % path)
         (seen,) = struct.unpack_from("<Q", raw, 12)
         off = 20
     else:

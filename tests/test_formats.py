@@ -1,0 +1,148 @@
+"""Weight/cfg formats and the C-ABI surface.  CPU only."""
+import ctypes
+import hashlib
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import helpers
+from betapose_amd import _lib, cfg as C, weights as W, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_generated_cfg_equals_reference_cfg():
+    fmt = helpers.golden("formats.npz")
+    blocks = C.parse_cfg_text(C.yolov3_single_cfg_text())
+    digest = hashlib.sha256(json.dumps(blocks, sort_keys=True).encode()).hexdigest()
+    assert digest == str(fmt["cfg_sha256"])          # digest of the REFERENCE's parse of its own cfg
+    kinds = [b["type"] for b in blocks]
+    assert kinds.count("convolutional") == 75 and kinds.count("shortcut") == 23
+    assert kinds.count("route") == 4 and kinds.count("upsample") == 2 and kinds.count("yolo") == 3
+
+
+def test_cfg_parser_edge_cases():
+    blocks = C.parse_cfg_text("# c\n\n[net]\nwidth = 416 \n[convolutional]\nfilters=8\nsize = 3\n  stride=1\npad=1\nactivation=leaky\n")
+    assert blocks[0] == {"type": "net", "width": "416"}
+    assert blocks[1]["size"] == "3" and blocks[1]["activation"] == "leaky"
+    with pytest.raises(ValueError):
+        C.parse_cfg_text("[convolutional]\nbroken line\n")
+    assert C.parse_cfg("yolo/cfg/yolov3-single.cfg") == C.parse_cfg_text(C.yolov3_single_cfg_text())
+    with pytest.raises(FileNotFoundError):
+        C.parse_cfg("/nonexistent/other.cfg")
+
+
+def test_synthetic_stream_is_reproducible():
+    fmt = helpers.golden("formats.npz")
+    stream = helpers.yolo_stream()
+    assert stream.size == int(fmt["stream_size"]) == W.darknet_stream_size(helpers.yolo_blocks())
+    assert hashlib.sha256(stream.tobytes()).hexdigest() == str(fmt["stream_sha256"])
+    # values the REFERENCE loader placed into its conv modules from the file we wrote
+    convs = {c["index"]: c for c in W.split_darknet_stream(helpers.yolo_blocks(), stream)}
+    probed = sorted(int(k[1:-7]) for k in fmt.files if k.endswith("_first8"))
+    assert len(probed) >= 5
+    for i in probed:
+        np.testing.assert_array_equal(convs[i]["weight"].ravel()[:8], fmt["w%d_first8" % i])
+        assert abs(float(convs[i]["weight"].astype(np.float64).sum()) - float(fmt["w%d_sum" % i])) < 1e-6
+
+
+def test_weights_file_round_trip(tmp_path):
+    fmt = helpers.golden("formats.npz")
+    raw = fmt["tiny_weights_bytes"].tobytes()
+    path = tmp_path / "tiny.weights"
+    path.write_bytes(raw)
+    ver, seen, flat = W.read_darknet_weights(str(path))
+    assert list(ver) == [0, 1, 0] and seen == 7
+    blocks = C.parse_cfg_text(str(fmt["tiny_cfg"]))
+    assert flat.size == W.darknet_stream_size(blocks)
+    out = tmp_path / "again.weights"
+    W.write_darknet_weights(str(out), flat, seen=7)
+    assert out.read_bytes() == raw
+    # 20-byte header variant (major*10+minor >= 2 -> 64-bit seen; parser.c:1161-1174): same payload
+    out2 = tmp_path / "v2.weights"
+    W.write_darknet_weights(str(out2), flat, seen=123456789012, version=(0, 2, 0))
+    assert out2.stat().st_size == len(raw) + 4
+    ver2, seen2, flat2 = W.read_darknet_weights(str(out2))
+    assert list(ver2) == [0, 2, 0] and seen2 == 123456789012 and np.array_equal(flat2, flat)
+    with pytest.raises(ValueError):
+        (tmp_path / "bad.weights").write_bytes(b"\0" * 8)
+        W.read_darknet_weights(str(tmp_path / "bad.weights"))
+    with pytest.raises(ValueError):
+        W.split_darknet_stream(blocks, flat[:-1])
+
+
+def test_fastpose_stream_layout():
+    sd = helpers.kpd_state_dict()
+    keys = W.fastpose_state_dict_keys(50)
+    assert len(keys) == 654 - 106      # 654 tensors in the reference state dict, 106 of them num_batches_tracked
+    assert sum(int(np.prod(s)) for _, s in keys) == W.fastpose_stream_size(50) == 59716338
+    assert set(sd) == {k for k, _ in keys}
+    for k, shape in keys:
+        assert sd[k].shape == shape, k
+    stream = W.fastpose_stream_from_state_dict(sd)
+    assert stream.size == W.fastpose_stream_size(50)
+    # first conv: bn.bias, bn.weight, mean, var, then the 7x7 filter
+    np.testing.assert_array_equal(stream[:64], sd["preact.bn1.bias"])
+    np.testing.assert_array_equal(stream[64:128], sd["preact.bn1.weight"])
+    np.testing.assert_array_equal(stream[256:256 + 64 * 3 * 49], sd["preact.conv1.weight"].ravel())
+    np.testing.assert_array_equal(stream[-128 * 9 * 50:], sd["conv_out.weight"].ravel())
+    bad = dict(sd)
+    bad["conv_out.weight"] = bad["conv_out.weight"][:10]
+    with pytest.raises(ValueError):
+        W.fastpose_stream_from_state_dict(bad)
+
+
+def test_bn_folding_matches_torch():
+    import torch
+    import torch.nn.functional as F
+    g = np.random.Generator(np.random.PCG64(3))
+    w = g.normal(size=(6, 4, 3, 3)).astype(np.float32)
+    gamma, beta = g.uniform(0.5, 1.5, 6).astype(np.float32), g.normal(size=6).astype(np.float32)
+    mean, var = g.normal(size=6).astype(np.float32), g.uniform(0.5, 2, 6).astype(np.float32)
+    x = torch.from_numpy(g.normal(size=(1, 4, 8, 8)).astype(np.float32))
+    ref = F.batch_norm(F.conv2d(x, torch.from_numpy(w), padding=1), torch.from_numpy(mean), torch.from_numpy(var),
+                       torch.from_numpy(gamma), torch.from_numpy(beta), False, 0.1, 1e-5)
+    wf, bf = W.fold_bn(w, gamma, beta, mean, var)
+    got = F.conv2d(x, torch.from_numpy(wf), torch.from_numpy(bf), padding=1)
+    assert float((got - ref).abs().max()) < 1e-5
+    wd, bd = W.fold_bn(w, gamma, beta, mean, var, darknet_eps=True)   # (x-mean)/(sqrt(var)+1e-6), blas.c:136
+    assert not np.array_equal(wd, wf)
+
+
+def test_library_exports_every_declared_symbol():
+    """The C-ABI library loads (no GPU needed) and exports exactly what include/betapose_hip.h declares."""
+    header = open(os.path.join(ROOT, "include", "betapose_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(bp_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 35
+    lib = _lib.lib()
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libbetapose_hip.so does not export %s" % name
+    assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+    assert lib.bp_version() >= 100
+    assert isinstance(lib.bp_last_error(), bytes)
+
+
+def test_product_path_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from betapose_amd.darknet import Darknet
+    net = Darknet("yolo/cfg/yolov3-single.cfg").load_stream(helpers.yolo_stream())
+    with pytest.raises(_lib.BetaposeHipError):
+        net.cuda()
+    with pytest.raises(_lib.BetaposeHipError):
+        net(torch.zeros(1, 3, 416, 416))
+
+
+def test_product_package_does_not_import_oracle():
+    """The oracle is test infrastructure: nothing under betapose_amd/ may import it."""
+    pkg = os.path.join(ROOT, "betapose_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
