@@ -35,6 +35,7 @@ PROTOTYPES = {
     "bp_yolo_attrs": (C.c_int, [vp]),
     "bp_yolo_forward": (C.c_int, [vp, vp, C.c_int, vp, vp]),
     "bp_yolo_forward_select": (C.c_int, [vp, vp, C.c_int, C.c_float, C.c_int, vp, vp, vp]),
+    "bp_yolo_select": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, vp, vp]),
     "bp_yolo_tap_count": (C.c_int, [vp]),
     "bp_yolo_tap_info": (C.c_int, [vp, C.c_int, C.c_char_p, C.c_int, c_int_p, c_int_p, c_int_p]),
     "bp_yolo_tap_copy": (C.c_int, [vp, C.c_int, C.c_int, vp, vp]),

@@ -157,6 +157,16 @@ int bp_yolo_forward_select(bp_yolo* y, const float* d_img, int batch, float conf
     BP_CATCH
 }
 
+int bp_yolo_select(const float* d_pred, int batch, int rows, int attrs, float conf, int num_classes, float* d_sel,
+                   void* stream) {
+    BP_TRY
+    BP_CHECK(d_pred && d_sel && batch >= 1 && rows >= 1 && attrs >= 6, "bad argument");
+    bp::launch_yolo_select(d_pred, batch, rows, attrs, conf, num_classes, d_sel, (hipStream_t)stream);
+    BP_HIP(hipGetLastError());
+    return 0;
+    BP_CATCH
+}
+
 static int tap_info(const bp::Net& n, int i, char* name, int cap, int* C, int* H, int* W) {
     if (i < 0 || i >= n.tap_count()) { g_err = "tap index"; return -1; }
     if (name && cap > 0) std::snprintf(name, cap, "%s", n.tap_name(i));

@@ -1,0 +1,38 @@
+"""Image helpers with the reference's names (KPD/src/utils/img.py:13-18,242-262; dataloader.py:794-835).
+The crop itself runs in the HIP crop kernel (``bp_crop``); these are the host-facing wrappers."""
+from __future__ import annotations
+
+import numpy as np
+
+from . import ops
+
+
+def im_to_torch(img):
+    """HWC u8/float -> CHW float 0..1 (img.py:13-18)."""
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(np.transpose(img, (2, 0, 1)))).float()
+    if t.max() > 1:
+        t /= 255
+    return t
+
+
+def load_frame_bgr(path: str) -> np.ndarray:
+    """cv2.imread replacement: BGR u8 HWC (8-bit PNG/JPEG decode via Pillow is bit-identical)."""
+    from PIL import Image
+    return np.ascontiguousarray(np.asarray(Image.open(path).convert("RGB"))[:, :, ::-1])
+
+
+def crop_from_dets_frame(frame_bgr_u8, boxes, inputResH: int = 320, inputResW: int = 256):
+    """``crop_from_dets`` (dataloader.py:794-835) on the original BGR u8 frame: mean-subtracted RGB crop(s) resized to
+    inputResH x inputResW.  frame: numpy [H,W,3] or cuda u8 tensor; boxes: [n,4] frame pixels.
+    Returns (inps cuda [n,3,H,W], pt1 cpu [n,2], pt2 cpu [n,2])."""
+    import torch
+    f = frame_bgr_u8 if hasattr(frame_bgr_u8, "is_cuda") else torch.from_numpy(np.ascontiguousarray(frame_bgr_u8))
+    f = f.cuda()
+    b = boxes if hasattr(boxes, "is_cuda") else torch.as_tensor(np.asarray(boxes), dtype=torch.float32)
+    b = b.float().cuda().reshape(-1, 4)
+    n = b.shape[0]
+    frames = f.unsqueeze(0).expand(n, -1, -1, -1).contiguous()
+    inps, pts = ops.crop(frames, boxes=b, oh=inputResH, ow=inputResW)
+    pts = pts.cpu()
+    return inps, pts[:, 0:2].clone(), pts[:, 2:4].clone()

@@ -1,0 +1,94 @@
+"""Evaluation metrics and ground-truth helpers of the harness (utils/metrics.py:10-22,77-127;
+utils/model.py:29-46,79-85; utils/sixd.py:60-111), numpy f64."""
+from __future__ import annotations
+
+import os
+from typing import Dict, List
+
+import numpy as np
+
+
+def add_err(gt_pose, est_pose, model):
+    a = model @ gt_pose[:3, :3].T + gt_pose[:3, 3]
+    b = model @ est_pose[:3, :3].T + est_pose[:3, 3]
+    return float(np.mean(np.linalg.norm(a - b, axis=1)))
+
+
+def projection_error_2d(gt_pose, est_pose, model, cam):
+    m = np.concatenate((model, np.ones((model.shape[0], 1))), axis=1)
+    g = cam @ gt_pose[:3] @ m.T
+    e = cam @ est_pose[:3] @ m.T
+    g, e = g / g[2], e / e[2]
+    return float(np.mean(np.linalg.norm(g[:2].T - e[:2].T, axis=1)))
+
+
+def iou(gt_box, est_box):
+    xA, yA = max(gt_box[0], est_box[0]), max(gt_box[1], est_box[1])
+    xB, yB = min(gt_box[2], est_box[2]), min(gt_box[3], est_box[3])
+    if xB <= xA or yB <= yA:
+        return 0.0
+    inter = (xB - xA) * (yB - yA)
+    A = (gt_box[2] - gt_box[0]) * (gt_box[3] - gt_box[1])
+    B = (est_box[2] - est_box[0]) * (est_box[3] - est_box[1])
+    return inter / float(A + B - inter)
+
+
+def load_ply_vertices(path: str) -> np.ndarray:
+    """ASCII PLY vertex x,y,z (the designated key-point / model files are ASCII)."""
+    with open(path, "rb") as f:
+        head = b""
+        while not head.endswith(b"end_header\n"):
+            line = f.readline()
+            if not line:
+                raise ValueError("%s: no end_header" % path)
+            head += line
+        text = head.decode("ascii", "replace")
+        if "format ascii" not in text:
+            raise NotImplementedError("%s: only ASCII PLY is supported" % path)
+        n = 0
+        for ln in text.split("\n"):
+            if ln.startswith("element vertex"):
+                n = int(ln.split()[2])
+        rows = [f.readline().split()[:3] for _ in range(n)]
+    return np.array(rows, dtype=np.float64)
+
+
+def refine_keypoints(vertices: np.ndarray, keep: int) -> np.ndarray:
+    """``Model3D.refine`` (utils/model.py:29-46): repeatedly delete one point of the globally closest pair
+    until ``keep`` points are left."""
+    v = np.array(vertices, dtype=np.float64)
+    while len(v) > keep:
+        d = np.linalg.norm(v[:, None, :] - v[None, :, :], axis=2)
+        d[np.diag_indices(len(v))] = np.inf
+        i, _ = np.unravel_index(np.argmin(d), d.shape)
+        v = np.delete(v, i, axis=0)
+    return v
+
+
+def evaluate_results(final_result: List[dict], gt_frames: Dict[int, dict], model_vertices, cam_K, diameter_mm,
+                     pixel_thresh: float = 5.0):
+    """The metric loop of betapose_evaluate.py:204-266.  ``gt_frames[nr] = {'pose': 4x4, 'bbox': [x, y, w, h]}``.
+    Returns dict(mean_add, mean_2d_acc, mean_iou, n)."""
+    add_errs, adds, proj, ious = [], [], [], []
+    for f in final_result:
+        nr = int(os.path.basename(f["imgname"])[0:-4])
+        if nr not in gt_frames or len(f["result"]) < 1:
+            continue
+        gt = gt_frames[nr]
+        x, y, w, h = gt["bbox"]
+        gt_box = [x, y, x + w, y + h]
+        pred_box = np.asarray(f["result"][0]["bbox"]).tolist()
+        i = iou(gt_box, pred_box)
+        ious.append(i)
+        pose = np.eye(4)
+        pose[:3, :3] = f["cam_R"]
+        pose[:3, 3] = np.asarray(f["cam_t"])[:, 0]
+        if i >= 0.5:
+            a = add_err(gt["pose"], pose, model_vertices) * 1000
+            add_errs.append(a)
+            adds.append(a < diameter_mm / 10)
+            proj.append(projection_error_2d(gt["pose"], pose, model_vertices, cam_K))
+    return {"mean_add": float(np.mean(adds)) if adds else float("nan"),
+            "mean_2d_acc": float(np.mean(np.array(proj) < pixel_thresh)) if proj else float("nan"),
+            "mean_iou": float(np.mean(np.array(ious) > 0.5)) if ious else float("nan"),
+            "mean_add_err_mm": float(np.mean(add_errs)) if add_errs else float("nan"), "n": len(ious)}

@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""LineMod single-object evaluation harness on the HIP engines -- the counterpart of the reference's
+``betapose_evaluate.py`` (3_6Dpose_estimator/betapose_evaluate.py:86-266) with the same flags (betapose_amd/opt.py):
+
+    python evaluate.py --nClasses 50 --indir <frames> --outdir <out> --sp [--profile] [--obj_id N]
+    python evaluate.py --synthetic 16 --outdir /tmp/out [--fused]          # no LineMod needed
+    python -m torch.distributed.run --nproc-per-node 8 evaluate.py --fused ...   # frames sharded over GPUs
+
+Default = the reference's staged pipeline (ImageLoader -> DetectionLoader -> DetectionProcessor -> KPD main loop ->
+DataWriter, threads + queues).  ``--fused`` = one hipGraph per frame (betapose_amd/pipeline.py), frames round-robined
+over ranks, records gathered to rank 0.  Both write ``Betapose-results.json`` and, when LineMod ground truth is
+available under --sixd_base, print the reference's three numbers (ADD accuracy, 2-D reprojection accuracy, IoU).
+"""
+from __future__ import annotations
+
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from betapose_amd import dist as bpd, metrics, synth  # noqa: E402
+from betapose_amd.opt import parse_args  # noqa: E402
+
+
+def load_sixd_gt(base, obj_id):
+    """Minimal ``load_sixd`` (utils/sixd.py:60-111): camera, model, key-point model, per-frame GT of sequence obj_id."""
+    import yaml
+    seq = os.path.join(base, "test", "%02d" % obj_id)
+    gt = yaml.safe_load(open(os.path.join(seq, "gt.yml")))
+    info = yaml.safe_load(open(os.path.join(base, "models", "models_info.yml")))
+    frames = {}
+    for nr, objs in gt.items():
+        for o in objs:
+            if o["obj_id"] == obj_id:
+                pose = np.eye(4)
+                pose[:3, :3] = np.array(o["cam_R_m2c"]).reshape(3, 3)
+                pose[:3, 3] = np.array(o["cam_t_m2c"]) / 1000.0
+                frames[int(nr)] = {"pose": pose, "bbox": list(o["obj_bb"])}
+                break
+    model = metrics.load_ply_vertices(os.path.join(base, "models", "obj_%02d.ply" % obj_id)) / 1000.0
+    kp = metrics.load_ply_vertices(os.path.join(base, "kpmodels", "obj_%02d.ply" % obj_id)) / 1000.0
+    return frames, model, kp, float(info[obj_id]["diameter"])
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+    from betapose_amd import _lib, cfg as C
+    from betapose_amd.darknet import Darknet
+    from betapose_amd.kpd import ALLPATHS, FastPoseHIP
+    from betapose_amd.pPose_nms import write_json
+    from betapose_amd.weights import fastpose_stream_from_state_dict, load_kpd_pkl, read_darknet_weights
+
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    _lib.require_gpu()
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    obj_id = args.obj_id
+    print("Betapose begin running now.  Test seq", obj_id)
+    os.makedirs(args.outputpath, exist_ok=True)
+
+    # ---- inputs
+    gt_frames, model_vertices, diameter = None, None, None
+    if args.synthetic:
+        from PIL import Image
+        args.inputpath = tempfile.mkdtemp(prefix="bp_frames_")
+        im_names = []
+        if rank == 0 or True:
+            for i, fr in enumerate(synth.synth_frames(args.synthetic, 1234)):
+                name = "%04d.png" % i
+                Image.fromarray(fr[:, :, ::-1].copy()).save(os.path.join(args.inputpath, name))
+                im_names.append(name)
+        cam_K, kp3d = synth.CAM_K, synth.synth_kp3d(50)
+    else:
+        if len(args.inputlist):
+            im_names = [l.strip() for l in open(args.inputlist)]
+        elif len(args.inputpath) and args.inputpath != '/':
+            im_names = sorted(f for f in os.listdir(args.inputpath) if f.lower().endswith((".png", ".jpg")))
+        else:
+            raise IOError('Error: must contain either --indir/--list')
+        cam_K = synth.CAM_K
+        gt_frames, model_vertices, kp3d, diameter = load_sixd_gt(args.sixd_base, obj_id)
+        kp3d = metrics.refine_keypoints(kp3d, 50) if len(kp3d) > 50 else kp3d
+
+    # ---- weights: rank 0 reads the files, the fp32 streams are broadcast (RCCL)
+    ys = ks = None
+    if rank == 0:
+        if args.synthetic and not args.yolo_weights:
+            ys = synth.synth_yolo_stream(1)
+            ks = fastpose_stream_from_state_dict(synth.synth_fastpose_state_dict(2, args.nClasses), args.nClasses)
+        else:
+            ys = read_darknet_weights(args.yolo_weights or 'models/yolo/{:02d}.weights'.format(obj_id))[2]
+            ks = fastpose_stream_from_state_dict(
+                load_kpd_pkl(args.kpd_weights or './exp/final_model/' + ALLPATHS[obj_id] + '.pkl'), args.nClasses)
+    ys, ks = bpd.broadcast_stream(ys), bpd.broadcast_stream(ks)
+    det = Darknet("yolo/cfg/yolov3-single.cfg", reso=int(args.inp_dim), max_batch=max(1, args.detbatch), device=local)
+    det.load_stream(ys).cuda()
+    pose_model = FastPoseHIP.from_stream(ks, n_classes=args.nClasses, max_batch=1, device=local).cuda()
+
+    t0 = time.time()
+    if args.fused:
+        from betapose_amd.img import load_frame_bgr
+        from betapose_amd.pipeline import FramePipeline, finish_record
+        mine = bpd.shard_indices(len(im_names), rank, world)
+        first = load_frame_bgr(os.path.join(args.inputpath, im_names[0]))
+        pipe = FramePipeline(det, pose_model, first.shape[0], first.shape[1], batch=1, confidence=args.confidence,
+                             num_classes=args.num_classes)
+        recs = np.zeros((len(mine), pipe.results.shape[1]), np.float32)
+        for j, i in enumerate(mine):
+            recs[j] = pipe.run(load_frame_bgr(os.path.join(args.inputpath, im_names[i])))[0]
+        allrec = bpd.gather_records(recs, mine, len(im_names))
+        final_result = []
+        if rank == 0:
+            for i, name in enumerate(im_names):
+                out = finish_record(allrec[i], name, kp3d, cam_K, 50)
+                if out["boxes"] is not None:
+                    final_result.append(out)
+    else:
+        assert world == 1, "the staged pipeline is single-GPU; use --fused to shard frames over ranks"
+        from betapose_amd.dataloader import DataWriter, DetectionLoader, DetectionProcessor, ImageLoader
+        data_loader = ImageLoader(im_names, batchSize=args.detbatch, format='yolo', reso=int(args.inp_dim)).start()
+        det_loader = DetectionLoader(data_loader, obj_id, batchSize=args.detbatch, det_model=det).start()
+        det_processor = DetectionProcessor(det_loader).start()
+        writer = DataWriter(cam_K, 50, kp3d).start()
+        prof = {'dt': [], 'pt': [], 'pn': []}
+        for i in range(data_loader.length()):
+            t_s = time.time()
+            (inps, orig_img, im_name, boxes, scores, pt1, pt2) = det_processor.read()
+            if boxes is None or boxes.nelement() == 0:
+                writer.save(None, None, None, None, None, orig_img, im_name.split('/')[-1])
+                continue
+            t_d = time.time()
+            hm = pose_model(inps.cuda()).cpu()
+            t_p = time.time()
+            writer.save(boxes, scores, hm, pt1, pt2, orig_img, im_name.split('/')[-1])
+            prof['dt'].append(t_d - t_s); prof['pt'].append(t_p - t_d); prof['pn'].append(time.time() - t_p)
+        while writer.running():
+            pass
+        writer.stop()
+        final_result = writer.results()
+        if args.profile:
+            print('det time: {:.4f} | pose time: {:.4f} | post processing: {:.5f}'.format(
+                np.mean(prof['dt']), np.mean(prof['pt']), np.mean(prof['pn'])))
+    if rank == 0:
+        print('===========================> Finish Model Running: %d frames, %d with a pose, %.2f s' % (
+            len(im_names), sum(len(f['result']) > 0 for f in final_result), time.time() - t0))
+        write_json(final_result, args.outputpath)
+        if gt_frames is not None:
+            m = metrics.evaluate_results(final_result, gt_frames, model_vertices, cam_K, diameter)
+            print("Mean add accuracy for seq %02d is: %.3f" % (obj_id, m["mean_add"]))
+            print("2d reprojection accuracy for seq %02d is: %.3f" % (obj_id, m["mean_2d_acc"]))
+            print("Mean IoU for seq %02d is: %.3f" % (obj_id, m["mean_iou"]))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -74,6 +74,10 @@ int bp_yolo_forward(bp_yolo* y, const float* d_img_nchw, int batch, float* d_pre
 /* d_pred may be NULL; d_sel: [batch][8] */
 int bp_yolo_forward_select(bp_yolo* y, const float* d_img_nchw, int batch, float conf, int num_classes, float* d_pred,
                            float* d_sel, void* stream);
+/* dynamic_write_results on an existing prediction tensor (yolo/util.py:104-223, NMS hard-wired off):
+ * d_pred [batch][rows][attrs] -> d_sel [batch][8] */
+int bp_yolo_select(const float* d_pred, int batch, int rows, int attrs, float conf, int num_classes, float* d_sel,
+                   void* stream);
 /* test/inspection hooks: intermediate layer outputs (dense NCHW copies) */
 int bp_yolo_tap_count(const bp_yolo* y);
 int bp_yolo_tap_info(const bp_yolo* y, int i, char* name, int cap, int* C, int* H, int* W);
