@@ -45,7 +45,7 @@ def parse_args():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--pool", type=int, default=8, help="distinct synthetic frames per rank")
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--streams", type=int, default=4,
                     help="frames in flight per GPU: independent batch-1 passes on separate HIP streams (engine clones "
                          "share the filters); 1 = strictly one frame at a time")
     ap.add_argument("--sk-target", type=int, default=512)
@@ -96,7 +96,7 @@ def cpu_baseline(seconds: float, kp3d, cam_K):
         one(frames[n % len(frames)])
         n += 1
         el = time.perf_counter() - t0
-        if el >= seconds or n >= 64:
+        if el >= seconds or n >= 400:
             break
     return {"value": n / el, "unit": "frames/sec", "cores": torch.get_num_threads(), "kind": "port",
             "sample": "%d synthetic 640x480 frames through oracle/ (PIL resize, torch-CPU fp32 YOLOv3+FastPose, "
