@@ -1,0 +1,89 @@
+"""Oracle (test infrastructure, see oracle/__init__.py): the reference's OWN Darknet-C inference path, compiled from
+its sources by oracle/Makefile into oracle/_ref/libdarknet_ref.so, driven through ctypes.
+
+Entry points used (3_6Dpose_estimator/train_YOLO/src): ``load_network_custom`` network.c:34, ``network_predict_image``
+network.c:652 (-> ``network_predict`` :534 -> ``forward_network`` :193), ``get_network_boxes`` network.c:635,
+``free_detections`` :642.  Darknet-C emits detections cell-major / anchor-minor with boxes relative to the image
+(0..1) and folds BN with ``sqrt(var)+1e-6``; ``predict_rows`` converts to the Python path's layout
+(head -> anchor -> gy -> gx, centre-size pixels) so the two can be compared row by row.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "_ref", "libdarknet_ref.so")
+
+NET_BLOCK = ("[net]\nbatch=1\nsubdivisions=1\nwidth=%d\nheight=%d\nchannels=3\nmomentum=0.9\ndecay=0.0005\n"
+             "learning_rate=0.001\nburn_in=1000\nmax_batches=500200\npolicy=steps\nsteps=400000,450000\nscales=.1,.1\n\n")
+
+
+class _Box(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("w", C.c_float), ("h", C.c_float)]
+
+
+class _Detection(C.Structure):      # box.h:26-33
+    _fields_ = [("bbox", _Box), ("classes", C.c_int), ("prob", C.POINTER(C.c_float)), ("mask", C.POINTER(C.c_float)),
+                ("objectness", C.c_float), ("sort_class", C.c_int)]
+
+
+class _Image(C.Structure):          # image.h
+    _fields_ = [("w", C.c_int), ("h", C.c_int), ("c", C.c_int), ("data", C.POINTER(C.c_float))]
+
+
+def available() -> bool:
+    return os.path.exists(LIB)
+
+
+class DarknetC:
+    def __init__(self, cfg_text_without_net: str, weights_path: str, reso: int = 416):
+        self.lib = C.CDLL(LIB)
+        L = self.lib
+        L.load_network_custom.restype = C.c_void_p
+        L.load_network_custom.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int]
+        L.network_predict_image.restype = C.POINTER(C.c_float)
+        L.network_predict_image.argtypes = [C.c_void_p, _Image]
+        L.get_network_boxes.restype = C.POINTER(_Detection)
+        L.get_network_boxes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_int,
+                                        C.POINTER(C.c_int), C.c_int]
+        L.free_detections.argtypes = [C.POINTER(_Detection), C.c_int]
+        self.reso = reso
+        self._tmp = tempfile.mkdtemp(prefix="dkref_")
+        cfg_path = os.path.join(self._tmp, "net.cfg")
+        with open(cfg_path, "w") as f:
+            f.write(NET_BLOCK % (reso, reso) + cfg_text_without_net)
+        self.net = L.load_network_custom(cfg_path.encode(), weights_path.encode(), 0, 1)
+        if not self.net:
+            raise RuntimeError("load_network_custom failed")
+
+    def predict_rows(self, img_chw: np.ndarray, grids=(13, 26, 52), n_anchor: int = 3) -> np.ndarray:
+        """img_chw: f32 [3,R,R] RGB 0..1 (planar, what ``load_image`` produces).  Returns [sum 3 g^2, 5+C] rows in the
+        PYTHON path's order and units (cx, cy, w, h in input pixels, objectness, class probabilities)."""
+        img = np.ascontiguousarray(img_chw, dtype=np.float32)
+        im = _Image(self.reso, self.reso, 3, img.ctypes.data_as(C.POINTER(C.c_float)))
+        self.lib.network_predict_image(self.net, im)
+        num = C.c_int(0)
+        dets = self.lib.get_network_boxes(self.net, self.reso, self.reso, -1.0, 0.0, None, 1, C.byref(num), 0)
+        n = num.value
+        classes = dets[0].classes
+        out = np.zeros((n, 5 + classes), np.float32)
+        for i in range(n):
+            d = dets[i]
+            out[i, 0:4] = (d.bbox.x * self.reso, d.bbox.y * self.reso, d.bbox.w * self.reso, d.bbox.h * self.reso)
+            out[i, 4] = d.objectness
+            for c in range(classes):
+                # yolo_layer.c:get_yolo_detections stores prob = objectness * class_prob
+                out[i, 5 + c] = d.prob[c] / d.objectness if d.objectness > 0 else 0.0
+        self.lib.free_detections(dets, n)
+        # cell-major/anchor-minor per head -> anchor-major
+        rows, off = [], 0
+        for g in grids:
+            blk = out[off:off + g * g * n_anchor].reshape(g * g, n_anchor, -1).transpose(1, 0, 2).reshape(g * g * n_anchor, -1)
+            rows.append(blk)
+            off += g * g * n_anchor
+        assert off == n
+        return np.concatenate(rows)

@@ -1,0 +1,30 @@
+"""Cross-oracle: the reference's own Darknet-C (compiled into oracle/_ref by oracle/Makefile) against the torch-CPU
+oracle of the Python path, on the same seeded .weights.  CPU only; skipped where oracle/_ref is absent."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import helpers
+from betapose_amd import cfg as C, weights as W
+from oracle import darknet_c_ref, yolo_ref
+
+pytestmark = pytest.mark.skipif(not darknet_c_ref.available(), reason="oracle/_ref/libdarknet_ref.so not built")
+
+
+def test_darknet_c_agrees_with_python_path(tmp_path):
+    wpath = tmp_path / "01.weights"
+    W.write_darknet_weights(str(wpath), helpers.yolo_stream())
+    net = darknet_c_ref.DarknetC(C.yolov3_single_cfg_text(), str(wpath), 416)
+    blocks = helpers.yolo_blocks()
+    convs = W.split_darknet_stream(blocks, helpers.yolo_stream())
+    x = helpers.yolo_input_from_frame(helpers.frames()[0])
+    py = yolo_ref.darknet_forward(blocks, convs, x)[0].numpy()
+    c_rows = net.predict_rows(x[0].numpy())
+    assert c_rows.shape == py.shape == (10647, 6)
+    # BN epsilon differs (sqrt(var)+1e-6 vs sqrt(var+1e-5)), so agreement is to ~1e-4, not bitwise
+    assert np.abs(c_rows[:, :2] - py[:, :2]).max() < 2e-3
+    assert bool((np.abs(c_rows[:, 2:4] - py[:, 2:4]) <= 2e-3 + 2e-4 * np.abs(py[:, 2:4])).all())   # w,h = exp(t)*anchor
+    assert np.abs(c_rows[:, 4] - py[:, 4]).max() < 2e-5
+    assert int(c_rows[:, 4].argmax()) == int(py[:, 4].argmax())      # the "YOLO box index"
