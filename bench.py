@@ -137,9 +137,22 @@ def roofline(det, pose, batch):
     conv_ms = sum(v["ms"] for v in groups.values())
     conv_flops = sum(v["flops"] for v in groups.values())
     achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12
+    # HBM traffic per launch of that kernel: not measurable from inside the process -- taken from the committed
+    # rocprofv3 PMC passes (profiles/*_pmc_traffic.json, collected with tools/pmc_traffic.sh, corrections inside)
+    traffic, traffic_src = None, None
+    try:
+        import glob
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[::-1]:
+            t = json.load(open(f))
+            if t.get("kernel", "").startswith("bp::conv_igemm_kernel<%s" % TILE_NAMES.get(key[0], "?")):
+                traffic, traffic_src = t["traffic_bytes_per_launch"], os.path.relpath(f, ROOT)
+                break
+    except Exception:
+        pass
     return {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+        "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+        "algorithmic_bytes_per_launch": g["bytes"] / g["launches"],
         "kernel": "bp::conv_igemm_kernel<%s, %s>" % (TILE_NAMES.get(key[0], "?"), "true" if key[1] else "false"),
         "launches_per_step": g["launches"], "avg_launch_us": round(g["ms"] / g["launches"] * 1e3, 2),
         "flops_per_launch": g["flops"] / g["launches"],
@@ -290,6 +303,12 @@ def main():
         out["host_post_ms_per_frame"] = round((time.perf_counter() - t1) / 200 * 1e3, 4)
     if rank == 0 and not a.no_roofline:
         out["roofline"] = roofline(det, pose, a.batch)
+        # the same FLOPs over the wall clock of the timed region (all frames in flight, all GPUs): what the chip
+        # sustains on the whole path, as opposed to one kernel running alone
+        gf = out["roofline"]["all_conv"]["gflop_per_step"]
+        agg = gf * a.steps * world / el / 1e3 / world
+        out["roofline"]["timed_region"] = {"achieved_per_gpu": round(agg, 2), "frac": round(agg / PEAK_FP32_MFMA_TFLOPS, 4),
+                                           "unit": "TFLOP/s"}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.cpu_seconds, kp3d, cam_K)
     if rank == 0:
