@@ -436,6 +436,23 @@ void launch_crop(const uint8_t* frames, int batch, int H, int W, const float* se
                        sel, reso, boxes, out_nhwc, out_nchw, pts, oh, ow);
 }
 
+// ---------------------------------------------------------------- per-frame result record (one launch instead of 3 copies)
+__global__ void pack_records_kernel(const float* __restrict__ sel, const float* __restrict__ pts,
+                                    const float* __restrict__ kp, float* __restrict__ out, int kp_floats, int rec_floats) {
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < rec_floats; i += blockDim.x) {
+        float v;
+        if (i < 8) v = sel[b * 8 + i];
+        else if (i < 16) v = pts[b * 8 + i - 8];
+        else v = kp[(long long)b * kp_floats + i - 16];
+        out[(long long)b * rec_floats + i] = v;
+    }
+}
+void launch_pack_records(const float* sel, const float* pts, const float* kp, float* out, int batch, int kp_floats,
+                         int rec_floats, hipStream_t s) {
+    hipLaunchKernelGGL(pack_records_kernel, dim3(batch), dim3(128), 0, s, sel, pts, kp, out, kp_floats, rec_floats);
+}
+
 // ---------------------------------------------------------------- Pillow-exact bicubic resize (u8, two passes)
 // Pillow's ImagingResample for 8-bit: per output pixel a window [xmin, xmin+xsize) with integer
 // coefficients (PRECISION_BITS = 22), accumulate ss = 1<<21 + sum(pix*k), result = clip8(ss >> 22);

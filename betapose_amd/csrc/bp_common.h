@@ -110,6 +110,10 @@ void launch_yolo_select(const float* pred, int N, int rows, int attrs, float con
 // hm NCHW [N][C][H*W] -> out [N][C][6] = (idx as int bits, max, left, right, up, down)
 void launch_heatmap_argmax(const float* hm, int N, int C, int H, int W, float* out, hipStream_t s);
 
+// [batch][rec_floats] rows = sel[8] | pts[8] | kp[kp_floats]
+void launch_pack_records(const float* sel, const float* pts, const float* kp, float* out, int batch, int kp_floats,
+                         int rec_floats, hipStream_t s);
+
 // crop stage (dataloader.py:794-835 + img.py:242-262) on device.
 //  frames: BGR u8 [batch][H][W][3]; sel: [batch][8] select records (box in YOLO-input pixels) or boxes [batch][4];
 //  out_nhwc [oh][ow][3] (engine input) and/or out_nchw [3][oh][ow]; pts: (ul.x, ul.y, br.x, br.y)

@@ -382,12 +382,8 @@ static void pipeline_enqueue(bp_pipeline* p, hipStream_t s) {
     // a8-a9: KPD + heat-map arg-max
     kn.forward(kn.input_nhwc(), true, p->batch, p->hm, p->kp, s);
     // gather the three small records into one result row per frame
-    for (int b = 0; b < p->batch; ++b) {
-        float* r = p->results + (size_t)b * BP_RESULT_FLOATS;
-        BP_HIP(hipMemcpyAsync(r, p->sel + b * 8, 8 * sizeof(float), hipMemcpyDeviceToDevice, s));
-        BP_HIP(hipMemcpyAsync(r + 8, p->pts + b * 8, 8 * sizeof(float), hipMemcpyDeviceToDevice, s));
-        BP_HIP(hipMemcpyAsync(r + 16, p->kp + (size_t)b * 300, 300 * sizeof(float), hipMemcpyDeviceToDevice, s));
-    }
+    bp::launch_pack_records(p->sel, p->pts, p->kp, p->results, p->batch, 300, BP_RESULT_FLOATS, s);
+    BP_HIP(hipGetLastError());
 }
 
 int bp_pipeline_create(bp_yolo* y, bp_kpd* k, int frame_h, int frame_w, int batch, float conf, int num_classes,

@@ -46,6 +46,51 @@ float* Net::upload_weights(const float* host, size_t count) {
     return d;
 }
 
+// Split-K slice counts measured on MI355X for every batch-1 conv shape of the two networks, one kernel at a time
+// (tools/tune_conv.py, 64x64 tile): {M, CoutPad, K-chunks, slices}.  Other shapes use the heuristic below.
+struct SplitEntry { int M, CoutPad, nchunks, splits; };
+static const SplitEntry kSplitTable[] = {
+    {80, 512, 64, 6},
+    {80, 512, 144, 10},
+    {80, 2048, 16, 3},
+    {80, 2048, 32, 4},
+    {169, 64, 32, 8},
+    {169, 256, 16, 5},
+    {169, 512, 32, 5},
+    {169, 1024, 144, 5},
+    {320, 256, 32, 5},
+    {320, 256, 72, 6},
+    {320, 512, 32, 5},
+    {320, 1024, 8, 1},
+    {320, 1024, 16, 3},
+    {320, 1024, 144, 6},
+    {676, 64, 16, 4},
+    {676, 128, 8, 3},
+    {676, 256, 16, 3},
+    {676, 256, 24, 5},
+    {676, 512, 72, 5},
+    {1280, 128, 16, 4},
+    {1280, 128, 36, 5},
+    {1280, 256, 16, 3},
+    {1280, 512, 4, 1},
+    {1280, 512, 8, 1},
+    {1280, 512, 72, 3},
+    {2704, 64, 8, 1},
+    {2704, 128, 8, 1},
+    {2704, 128, 12, 2},
+    {2704, 256, 36, 4},
+    {5120, 64, 2, 1},
+    {5120, 64, 8, 1},
+    {5120, 64, 18, 3},
+    {5120, 64, 36, 3},
+    {5120, 128, 8, 1},
+    {5120, 256, 2, 1},
+    {10816, 64, 4, 1},
+    {10816, 128, 18, 3},
+    {43264, 64, 2, 1},
+    {43264, 64, 9, 1}
+};
+
 static void choose_launch(const Op& op, int batch, int force_tile, int sk_target, int sk_min_chunks, int sk_max,
                           int* tile, int* splits, int* cps) {
     const ConvParams& c = op.conv;
@@ -58,6 +103,9 @@ static void choose_launch(const Op& op, int batch, int force_tile, int sk_target
     const long long blocks = ((M + bm - 1) / bm) * nt;
     int s = 1;
     while (blocks * s < sk_target && c.nchunks / (s + 1) >= sk_min_chunks && s < sk_max) ++s;
+    if (t == TILE_64x64 && sk_target == 512 && sk_min_chunks == 4 && sk_max == 8)   // default policy: measured table
+        for (const SplitEntry& e : kSplitTable)
+            if (e.M == (int)M && e.CoutPad == c.CoutPad && e.nchunks == c.nchunks) { s = e.splits; break; }
     int per = (c.nchunks + s - 1) / s;
     s = (c.nchunks + per - 1) / per;
     *tile = t; *splits = s; *cps = per;

@@ -32,6 +32,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument('--posebatch', type=int, default=80)
     p.add_argument('--save_video', dest='save_video', default=False, action='store_true')
     # additions of this implementation
+    p.add_argument('--occlusion', default=False, action='store_true',
+                   help='Occlusion-LineMod protocol (occlusion_betapose_evaluate.py): GT sequence 02, every GT object of a '
+                        'frame, --left_keypoints for PnP, 20 px reprojection threshold')
     p.add_argument('--fused', default=False, action='store_true', help='one hipGraph per frame instead of stage threads')
     p.add_argument('--synthetic', type=int, default=0, help='run on N seeded synthetic frames / weights')
     p.add_argument('--sixd_base', default='/media/data_2/SIXD/hinterstoisser')

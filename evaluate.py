@@ -27,10 +27,12 @@ from betapose_amd import dist as bpd, metrics, synth  # noqa: E402
 from betapose_amd.opt import parse_args  # noqa: E402
 
 
-def load_sixd_gt(base, obj_id):
-    """Minimal ``load_sixd`` (utils/sixd.py:60-111): camera, model, key-point model, per-frame GT of sequence obj_id."""
+def load_sixd_gt(base, obj_id, seq_id=None):
+    """Minimal ``load_sixd`` (utils/sixd.py:60-111): camera, model, key-point model, per-frame GT of object ``obj_id``
+    in sequence ``seq_id`` (LineMod: the object's own sequence; Occlusion-LineMod: always sequence 02, where every
+    frame lists several objects -- occlusion_betapose_evaluate.py:204,218-220)."""
     import yaml
-    seq = os.path.join(base, "test", "%02d" % obj_id)
+    seq = os.path.join(base, "test", "%02d" % (obj_id if seq_id is None else seq_id))
     gt = yaml.safe_load(open(os.path.join(seq, "gt.yml")))
     info = yaml.safe_load(open(os.path.join(base, "models", "models_info.yml")))
     frames = {}
@@ -64,7 +66,10 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     obj_id = args.obj_id
-    print("Betapose begin running now.  Test seq", obj_id)
+    # key points handed to PnP: all 50 on LineMod (betapose_evaluate.py:139), the --left_keypoints best on Occlusion
+    left_number = args.left_keypoints if args.occlusion else 50
+    pixel_thresh = 20.0 if args.occlusion else 5.0          # occlusion_betapose_evaluate.py:255 vs betapose_evaluate.py:257
+    print("Betapose begin running now.  Test object", obj_id, "| key points for PnP:", left_number)
     os.makedirs(args.outputpath, exist_ok=True)
 
     # ---- inputs
@@ -87,7 +92,7 @@ def main():
         else:
             raise IOError('Error: must contain either --indir/--list')
         cam_K = synth.CAM_K
-        gt_frames, model_vertices, kp3d, diameter = load_sixd_gt(args.sixd_base, obj_id)
+        gt_frames, model_vertices, kp3d, diameter = load_sixd_gt(args.sixd_base, obj_id, 2 if args.occlusion else None)
         kp3d = metrics.refine_keypoints(kp3d, 50) if len(kp3d) > 50 else kp3d
 
     # ---- weights: rank 0 reads the files, the fp32 streams are broadcast (RCCL)
@@ -120,7 +125,7 @@ def main():
         final_result = []
         if rank == 0:
             for i, name in enumerate(im_names):
-                out = finish_record(allrec[i], name, kp3d, cam_K, 50)
+                out = finish_record(allrec[i], name, kp3d, cam_K, left_number)
                 if out["boxes"] is not None:
                     final_result.append(out)
     else:
@@ -129,7 +134,7 @@ def main():
         data_loader = ImageLoader(im_names, batchSize=args.detbatch, format='yolo', reso=int(args.inp_dim)).start()
         det_loader = DetectionLoader(data_loader, obj_id, batchSize=args.detbatch, det_model=det).start()
         det_processor = DetectionProcessor(det_loader).start()
-        writer = DataWriter(cam_K, 50, kp3d).start()
+        writer = DataWriter(cam_K, left_number, kp3d).start()
         prof = {'dt': [], 'pt': [], 'pn': []}
         for i in range(data_loader.length()):
             t_s = time.time()
@@ -154,7 +159,7 @@ def main():
             len(im_names), sum(len(f['result']) > 0 for f in final_result), time.time() - t0))
         write_json(final_result, args.outputpath)
         if gt_frames is not None:
-            m = metrics.evaluate_results(final_result, gt_frames, model_vertices, cam_K, diameter)
+            m = metrics.evaluate_results(final_result, gt_frames, model_vertices, cam_K, diameter, pixel_thresh)
             print("Mean add accuracy for seq %02d is: %.3f" % (obj_id, m["mean_add"]))
             print("2d reprojection accuracy for seq %02d is: %.3f" % (obj_id, m["mean_2d_acc"]))
             print("Mean IoU for seq %02d is: %.3f" % (obj_id, m["mean_iou"]))
