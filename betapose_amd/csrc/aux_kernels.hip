@@ -7,6 +7,7 @@
 namespace bp {
 
 static inline int grid_for(long long n, int block = 256, int cap = 4096) {
+    BP_CHECK(n < (1ll << 31), "tensor too large for 32-bit indexing");
     long long g = (n + block - 1) / block;
     return (int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
@@ -14,11 +15,13 @@ static inline int grid_for(long long n, int block = 256, int cap = 4096) {
 // ---------------------------------------------------------------- layout
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int C, int HW) {
     const long long total = (long long)N * C * HW;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    // 32-bit index math: every tensor on this path has < 2^31 elements (checked by the launchers), and 64-bit
+    // div/mod costs ~100 instructions on gfx950
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < (int)total; e += gridDim.x * blockDim.x) {
         const int c = (int)(e % C);
-        const long long t = e / C;
-        const int p = (int)(t % HW);
-        const int n = (int)(t / HW);
+        const int t = e / C;
+        const int p = t % HW;
+        const int n = t / HW;
         out[e] = in[((long long)n * C + c) * HW + p];
     }
 }
@@ -29,11 +32,13 @@ void launch_nchw_to_nhwc(const float* in, float* out, int N, int C, int H, int W
 
 __global__ void nhwc_to_nchw_kernel(const float* __restrict__ in, int in_ld, float* __restrict__ out, int N, int C, int HW) {
     const long long total = (long long)N * C * HW;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    // 32-bit index math: every tensor on this path has < 2^31 elements (checked by the launchers), and 64-bit
+    // div/mod costs ~100 instructions on gfx950
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < (int)total; e += gridDim.x * blockDim.x) {
         const int p = (int)(e % HW);
-        const long long t = e / HW;
-        const int c = (int)(t % C);
-        const int n = (int)(t / C);
+        const int t = e / HW;
+        const int c = t % C;
+        const int n = t / C;
         out[e] = in[((long long)n * HW + p) * in_ld + c];
     }
 }
@@ -47,9 +52,11 @@ __global__ void maxpool3s2p1_kernel(const float* __restrict__ in, float* __restr
                                     int OH, int OW) {
     const int C4 = C >> 2;
     const long long total = (long long)N * OH * OW * C4;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    // 32-bit index math: every tensor on this path has < 2^31 elements (checked by the launchers), and 64-bit
+    // div/mod costs ~100 instructions on gfx950
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < (int)total; e += gridDim.x * blockDim.x) {
         const int c4 = (int)(e % C4);
-        long long t = e / C4;
+        int t = e / C4;
         const int ox = (int)(t % OW);
         t /= OW;
         const int oy = (int)(t % OH);
@@ -78,9 +85,11 @@ void launch_maxpool3s2p1(const float* in, float* out, int N, int H, int W, int C
 __global__ void add_kernel(const float* __restrict__ a, int a_ld, const float* __restrict__ b, int b_ld,
                            float* __restrict__ out, int out_ld, long long pixels, int C) {
     const long long total = pixels * C;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    // 32-bit index math: every tensor on this path has < 2^31 elements (checked by the launchers), and 64-bit
+    // div/mod costs ~100 instructions on gfx950
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < (int)total; e += gridDim.x * blockDim.x) {
         const int c = (int)(e % C);
-        const long long p = e / C;
+        const int p = e / C;
         out[p * out_ld + c] = a[p * a_ld + c] + b[p * b_ld + c];
     }
 }
@@ -92,9 +101,11 @@ void launch_add(const float* a, int a_ld, const float* b, int b_ld, float* out, 
 __global__ void copy_channels_kernel(const float* __restrict__ in, int in_ld, float* __restrict__ out, int out_ld,
                                      long long pixels, int C) {
     const long long total = pixels * C;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    // 32-bit index math: every tensor on this path has < 2^31 elements (checked by the launchers), and 64-bit
+    // div/mod costs ~100 instructions on gfx950
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < (int)total; e += gridDim.x * blockDim.x) {
         const int c = (int)(e % C);
-        const long long p = e / C;
+        const int p = e / C;
         out[p * out_ld + c] = in[p * in_ld + c];
     }
 }
@@ -105,9 +116,11 @@ void launch_copy_channels(const float* in, int in_ld, float* out, int out_ld, lo
 __global__ void upsample2_kernel(const float* __restrict__ in, int in_ld, float* __restrict__ out, int out_ld, int N,
                                  int H, int W, int C) {
     const long long total = (long long)N * 2 * H * 2 * W * C;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    // 32-bit index math: every tensor on this path has < 2^31 elements (checked by the launchers), and 64-bit
+    // div/mod costs ~100 instructions on gfx950
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < (int)total; e += gridDim.x * blockDim.x) {
         const int c = (int)(e % C);
-        long long t = e / C;
+        int t = e / C;
         const int x = (int)(t % (2 * W));
         t /= 2 * W;
         const int y = (int)(t % (2 * H));
@@ -124,9 +137,11 @@ void launch_upsample2(const float* in, int in_ld, float* out, int out_ld, int N,
 __global__ void pixel_shuffle2_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int H, int W, int C) {
     const int Co = C >> 2;
     const long long total = (long long)N * H * W * C;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    // 32-bit index math: every tensor on this path has < 2^31 elements (checked by the launchers), and 64-bit
+    // div/mod costs ~100 instructions on gfx950
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < (int)total; e += gridDim.x * blockDim.x) {
         const int co = (int)(e % Co);
-        long long t = e / Co;
+        int t = e / Co;
         const int x = (int)(t % (2 * W));
         t /= 2 * W;
         const int y = (int)(t % (2 * H));
@@ -214,7 +229,9 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-
 
 __global__ void yolo_decode_kernel(YoloHeads hs, int N, int reso, int attrs, int rows, float* __restrict__ pred) {
     const long long total = (long long)N * rows;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    // 32-bit index math: every tensor on this path has < 2^31 elements (checked by the launchers), and 64-bit
+    // div/mod costs ~100 instructions on gfx950
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < (int)total; e += gridDim.x * blockDim.x) {
         const int row = (int)(e % rows);
         const int n = (int)(e / rows);
         int hi = 0;

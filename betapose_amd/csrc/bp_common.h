@@ -64,6 +64,7 @@ struct ConvParams {
     float* partial;        // [splits][tiles][BM*64] fragment-order slabs when splits > 1
     int* tickets;          // [tiles] arrival counters (zero between launches) when splits > 1
     int CoutPad;
+    unsigned long long* stamps;   // debug (tools/bench_conv.py --stamps): per-block s_memtime marks, null in production
 };
 
 // tile configuration ids for launch_conv

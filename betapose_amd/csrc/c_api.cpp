@@ -1,6 +1,8 @@
 // extern "C" boundary of libbetapose_hip.so -- see include/betapose_hip.h.
 #include "../../include/betapose_hip.h"
 
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <memory>
@@ -348,6 +350,32 @@ int bp_conv2d(const float* d_in, int N, int H, int W, int Cin, const float* h_w,
     }
     bp::launch_conv(p, t, s);
     BP_HIP(hipStreamSynchronize(s));
+    if (const char* e = std::getenv("BP_CONV_STAMPS")) {   // debug: per-block s_memtime marks of one extra launch
+        const int nb = bp::conv_tiles(p, t) * p.splits;
+        unsigned long long* d = (unsigned long long*)net.arena_.alloc_bytes((size_t)nb * 8 * 8);
+        BP_HIP(hipMemset(d, 0, (size_t)nb * 64));
+        bp::ConvParams q = p; q.stamps = d;
+        bp::launch_conv(q, t, s);
+        BP_HIP(hipStreamSynchronize(s));
+        std::vector<unsigned long long> h((size_t)nb * 8);
+        BP_HIP(hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull;
+        for (int b = 0; b < nb; ++b)
+            if (h[(size_t)b * 8]) t0 = std::min(t0, h[(size_t)b * 8]);
+        double acc[5] = {0, 0, 0, 0, 0}, last = 0;
+        int cnt[5] = {0, 0, 0, 0, 0};
+        for (int b = 0; b < nb; ++b)
+            for (int k = 0; k < 5; ++k) {
+                const unsigned long long v = h[(size_t)b * 8 + k];
+                if (!v) continue;
+                acc[k] += (double)(v - t0); ++cnt[k];
+                last = std::max(last, (double)(v - t0));
+            }
+        std::fprintf(stderr, "[stamps] blocks=%d  mean cycles after the first block entered: entry %.0f | index math done %.0f | "
+                     "chunk 0 in LDS %.0f | K loop done %.0f | stores done %.0f (unsplit only) | last mark %.0f\n", nb,
+                     cnt[0] ? acc[0] / cnt[0] : 0, cnt[1] ? acc[1] / cnt[1] : 0, cnt[2] ? acc[2] / cnt[2] : 0,
+                     cnt[3] ? acc[3] / cnt[3] : 0, cnt[4] ? acc[4] / cnt[4] : 0, last);
+    }
     if (iters > 0 && ms_per_iter) {
         hipEvent_t e0, e1;
         BP_HIP(hipEventCreate(&e0));

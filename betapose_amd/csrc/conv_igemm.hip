@@ -99,29 +99,11 @@ __device__ __forceinline__ void epilogue_store(const ConvParams& p, int m, int n
     }
 }
 
-// 16 accumulators of one lane: column n, rows m_base + (r&3) + 8*(r>>2).  Fast path (plain NHWC store, optional
-// residual): all residual loads are issued before the first store.
+// 16 accumulators of one lane: column n, rows m_base + (r&3) + 8*(r>>2) -- element-wise epilogue for the store
+// modes / alignments the staged float4 path does not cover (heads with 18 channels, upsample, PixelShuffle, NCHW)
 __device__ __forceinline__ void epilogue_tile(const ConvParams& p, const float* v, int m_base, int n) {
     if (n >= p.Cout) return;
     const float bias = p.bias[n];
-    if (p.store_mode == ST_NHWC && p.res_scale == nullptr) {
-        float r[16];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int m = m_base + (e & 3) + 8 * (e >> 2);
-            r[e] = (p.res && m < p.M) ? p.res[m * p.res_ld + n] : 0.f;
-        }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int m = m_base + (e & 3) + 8 * (e >> 2);
-            float x = v[e] + bias;
-            if (!p.res_after_act) x += r[e];
-            x = apply_act(x, p.act);
-            if (p.res_after_act) x += r[e];
-            if (m < p.M) p.out[m * p.out_ld + n] = x;
-        }
-        return;
-    }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int m = m_base + (e & 3) + 8 * (e >> 2);
@@ -148,9 +130,13 @@ template <int TM, int TN, bool VEC>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int RA = BM / 32, RB = BN / 32;
-    __shared__ __attribute__((aligned(16))) float As[2][BM * LDS_LD];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDS_LD];
+    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDS_LD];
+    float (*As)[BM * LDS_LD] = reinterpret_cast<float (*)[BM * LDS_LD]>(smem);
+    float (*Bs)[BN * LDS_LD] = reinterpret_cast<float (*)[BN * LDS_LD]>(smem + 2 * BM * LDS_LD);
+    constexpr int LDT = BN + 4;                 // row stride of the output tile staged through LDS in the epilogue
+    static_assert(BM * LDT <= 2 * (BM + BN) * LDS_LD, "LDS too small for the staged epilogue");
 
+    const unsigned long long t_entry = p.stamps ? __builtin_readcyclecounter() : 0ull;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -341,6 +327,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         BP_MF(fa1, fb1, w);                          BP_SB();                                          \
     }
 
+#define BP_STAMP(k_) if (p.stamps && tid == 0) p.stamps[(long long)blockIdx.x * 8 + (k_)] = __builtin_readcyclecounter();
+    if (p.stamps && tid == 0) p.stamps[(long long)blockIdx.x * 8 + 0] = t_entry;
+    BP_STAMP(1);   // index math done
     if (c_begin < c_end) {
         // prologue: chunks c, c+1 in flight; park c in LDS[0]; first fragments; addresses of chunk c+2
         BP_ADDR(); BP_LOAD_A(ra0); BP_LOAD_B(rb0);
@@ -349,6 +338,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         BP_STORE_A(0, ra0);
         BP_STORE_B(0, rb0);
         __syncthreads();
+        BP_STAMP(2);   // first chunk landed in LDS
         BP_RD(0, 0, fa0, fb0);
         // two chunks per trip (the register sets swap roles; after a pair everything is back in place), then an
         // odd tail.  Past the last chunk the pipeline keeps loading / parking / reading the clamped last chunk
@@ -362,9 +352,110 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         if (nch & 1) BP_PHASE(0, ra1, rb1, ra0, rb0);
     }
     __syncthreads();
+    BP_STAMP(3);   // K loop done
 
-    // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    if (p.splits == 1) {
+    // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    if (p.splits > 1) {
+        // ---- split-K: every slice parks its fp32 accumulators in a slab laid out in FRAGMENT order
+        // (slice, tile, wave, quad, lane) so each lane moves 16 B per instruction, fully coalesced; the LAST slice
+        // to arrive at the tile's ticket counter sums all slabs in slice order (deterministic, independent of
+        // arrival order) and runs the epilogue.  Hand-off without fences (cdna_hip_programming.md G16 "R1"):
+        // write-through (sc1) slab stores, every storing wave drains vmcnt, one relaxed agent-scope ticket, sc1
+        // loads by the reducer.
+        const int tiles = (int)gridDim.x / p.splits;
+        constexpr int TILE_FLOATS = TM * TN * 4096;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            p.partial, 0, (int)((long long)p.splits * tiles * TILE_FLOATS * 4), 0x00020000);
+        const int my_off = ((split * tiles + tile_id) * TILE_FLOATS + wave * (TM * TN * 1024) + lane * 4) * 4;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    u32x4 v;
+                    v.x = __float_as_uint(acc[i][j][4 * q]);
+                    v.y = __float_as_uint(acc[i][j][4 * q + 1]);
+                    v.z = __float_as_uint(acc[i][j][4 * q + 2]);
+                    v.w = __float_as_uint(acc[i][j][4 * q + 3]);
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, my_off + (((i * TN + j) * 4 + q) * 256) * 4, 0, 16 /*sc1*/);
+                }
+        __shared__ int s_last;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            const int ticket = __hip_atomic_fetch_add(&p.tickets[tile_id], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = ticket == p.splits - 1;
+            if (s_last) __hip_atomic_store(&p.tickets[tile_id], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+        }
+        __syncthreads();
+        if (!s_last) return;
+        const int base_off = (tile_id * TILE_FLOATS + wave * (TM * TN * 1024) + lane * 4) * 4;
+        const int slice_stride = tiles * TILE_FLOATS * 4;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+                for (int sidx = 0; sidx < p.splits; ++sidx) {   // slice order: deterministic sum
+                    u32x4 t[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        t[q] = __builtin_amdgcn_raw_buffer_load_b128(
+                            rsrc, base_off + (((i * TN + j) * 4 + q) * 256) * 4 + sidx * slice_stride, 0, 16 /*sc1*/);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        acc[i][j][4 * q] += __uint_as_float(t[q].x);
+                        acc[i][j][4 * q + 1] += __uint_as_float(t[q].y);
+                        acc[i][j][4 * q + 2] += __uint_as_float(t[q].z);
+                        acc[i][j][4 * q + 3] += __uint_as_float(t[q].w);
+                    }
+                }
+            }
+    }
+
+    // ---- epilogue.  Fast path (plain NHWC store, 16-B alignable): the tile goes through LDS so every lane stores
+    // 16 contiguous bytes (a wave-instruction covers 4 full 256-B rows).  The direct form -- 16 dword stores per
+    // lane, 128-B segments -- was store-issue bound: s_memtime stamps showed 4-8k cycles per block in the epilogue,
+    // as much as 3-6 K-chunks of MFMA work.
+    const bool vec_ok = p.store_mode == ST_NHWC && p.res_scale == nullptr && (p.out_ld & 3) == 0 && (p.Cout & 3) == 0 &&
+                        (p.res == nullptr || (p.res_ld & 3) == 0);
+    if (vec_ok) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    smem[row * LDT + wn * (BN / 2) + j * 32 + (lane & 31)] = acc[i][j][r];
+                }
+        __syncthreads();
+        constexpr int TPR = BN / 4;              // threads per tile row
+        constexpr int ROWS_PER_PASS = 256 / TPR;
+        const int n4 = (tid % TPR) * 4;
+        const int n = n0 + n4;
+        if (n < p.Cout) {
+            const f32x4 bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+            for (int pass = 0; pass < BM / ROWS_PER_PASS; ++pass) {
+                const int row = pass * ROWS_PER_PASS + tid / TPR;
+                const int m = m0 + row;
+                if (m < p.M) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(&smem[row * LDT + n4]);
+                    f32x4 r4 = {0.f, 0.f, 0.f, 0.f};
+                    if (p.res) r4 = *reinterpret_cast<const f32x4*>(p.res + m * p.res_ld + n);
+                    v += bias4;
+                    if (!p.res_after_act) v += r4;
+                    v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act);
+                    v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act);
+                    if (p.res_after_act) v += r4;
+                    *reinterpret_cast<f32x4*>(p.out + m * p.out_ld + n) = v;
+                }
+            }
+        }
+    } else {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -375,67 +466,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                 for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r];
                 epilogue_tile(p, v, m0 + wm * (BM / 2) + i * 32 + 4 * (lane >> 5), n);
             }
-        return;
     }
-    // ---- split-K: every slice parks its fp32 accumulators in a slab laid out in FRAGMENT order
-    // (slice, tile, wave, quad, lane) so each lane moves 16 B per instruction, fully coalesced; the LAST slice
-    // to arrive at the tile's ticket counter sums all slabs in slice order (deterministic, independent of arrival
-    // order) and runs the epilogue.  Hand-off without fences (cdna_hip_programming.md G16 "R1"): write-through
-    // (sc1) slab stores, every storing wave drains vmcnt, one relaxed agent-scope ticket, sc1 loads by the reducer.
-    const int tiles = (int)gridDim.x / p.splits;
-    constexpr int TILE_FLOATS = TM * TN * 4096;
-    const __amdgpu_buffer_rsrc_t rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(p.partial, 0, (int)((long long)p.splits * tiles * TILE_FLOATS * 4), 0x00020000);
-    const int my_off = ((split * tiles + tile_id) * TILE_FLOATS + wave * (TM * TN * 1024) + lane * 4) * 4;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                u32x4 v;
-                v.x = __float_as_uint(acc[i][j][4 * q]);
-                v.y = __float_as_uint(acc[i][j][4 * q + 1]);
-                v.z = __float_as_uint(acc[i][j][4 * q + 2]);
-                v.w = __float_as_uint(acc[i][j][4 * q + 3]);
-                __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, my_off + (((i * TN + j) * 4 + q) * 256) * 4, 0, 16 /*sc1*/);
-            }
-    __shared__ int s_last;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        const int ticket = __hip_atomic_fetch_add(&p.tickets[tile_id], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = ticket == p.splits - 1;
-        if (s_last) __hip_atomic_store(&p.tickets[tile_id], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
-    }
-    __syncthreads();
-    if (!s_last) return;
-    const int base_off = (tile_id * TILE_FLOATS + wave * (TM * TN * 1024) + lane * 4) * 4;
-    const int slice_stride = tiles * TILE_FLOATS * 4;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
-            float v[16];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) v[e] = 0.f;
-            for (int sidx = 0; sidx < p.splits; ++sidx) {   // slice order: deterministic sum
-                u32x4 t[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    t[q] = __builtin_amdgcn_raw_buffer_load_b128(
-                        rsrc, base_off + (((i * TN + j) * 4 + q) * 256) * 4 + sidx * slice_stride, 0, 16 /*sc1*/);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    v[4 * q] += __uint_as_float(t[q].x);
-                    v[4 * q + 1] += __uint_as_float(t[q].y);
-                    v[4 * q + 2] += __uint_as_float(t[q].z);
-                    v[4 * q + 3] += __uint_as_float(t[q].w);
-                }
-            }
-            epilogue_tile(p, v, m0 + wm * (BM / 2) + i * 32 + 4 * (lane >> 5), n);
-        }
+    if (p.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); BP_STAMP(4); }
 }
 
 thread_local ConvProfHook* g_conv_prof = nullptr;

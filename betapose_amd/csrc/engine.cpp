@@ -156,6 +156,7 @@ int Net::add_conv(const std::string& name, const Tensor& in, const Tensor& out_v
     c.res_after_act = res_after_act; c.store_mode = store_mode;
     c.M = OH * OW; c.nchunks = Kpad / 32; c.splits = 1; c.chunks_per_split = c.nchunks; c.partial = nullptr;
     c.tickets = nullptr;
+    c.stamps = nullptr;
     c.CoutPad = CoutPad;
     op.flops = 2.0 * OH * OW * (double)Cout * K;
     op.bytes = 4.0 * ((double)Cout * K + (double)in.H * in.W * Cin + (double)OH * OW * Cout + (res ? (double)OH * OW * Cout : 0.0));

@@ -1,14 +1,8 @@
-run() { python bench.py --steps 400 --warmup 40 --no-cpu-baseline --no-roofline "$@" 2>&1 | grep "^{" | grep -o "\"value\": [0-9.]*\|\"ms_per_step\": [0-9.]*" | tr "\n" " "; echo " :: $QQ $@"; }
-QQ=""; run --streams 4
-QQ=""; run --streams 4 --sk-target 256
-QQ=""; run --streams 4 --sk-target 384 --sk-min 6
-QQ=""; run --streams 4 --sk-target 768
-QQ=""; run --streams 4 --sk-max 4
-QQ=""; run --streams 4 --sk-max 16
-export GPU_MAX_HW_QUEUES=8; QQ="HWQ8"
-run --streams 4
-run --streams 6
-run --streams 8
-export GPU_MAX_HW_QUEUES=16; QQ="HWQ16"
-run --streams 8
-run --streams 12
+run() { python bench.py --steps $1 --warmup 20 --no-cpu-baseline --no-roofline "${@:2}" 2>&1 | grep "^{" | grep -o "\"value\": [0-9.]*\|\"ms_per_step\": [0-9.]*" | tr "\n" " "; echo " :: ${@:2}"; }
+run 200 --batch 2 --streams 4
+run 200 --batch 2 --streams 2
+run 100 --batch 4 --streams 2
+run 100 --batch 4 --streams 3
+run 60 --batch 8 --streams 2
+run 30 --batch 28 --streams 1
+run 30 --batch 28 --streams 2
