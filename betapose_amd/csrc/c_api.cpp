@@ -331,7 +331,7 @@ int bp_conv2d(const float* d_in, int N, int H, int W, int Cin, const float* h_w,
     bp::ConvParams p = net.ops_[0].conv;
     p.N = N; p.M = N * OH * OW;
     int t = tile;
-    if (t < 0) t = ((p.M + 127) / 128) * (p.CoutPad / 64) >= 1024 ? bp::TILE_128x64 : bp::TILE_64x64;
+    if (t < 0) t = bp::TILE_64x64;
     int sp = splits;
     if (sp <= 0) {
         const int bm = bp::conv_tile_bm(t);

@@ -96,8 +96,7 @@ static void choose_launch(const Op& op, int batch, int force_tile, int sk_target
     const ConvParams& c = op.conv;
     const long long M = (long long)batch * c.OH * c.OW;
     const int nt = c.CoutPad / 64;
-    int t = TILE_64x64;
-    if (((M + 127) / 128) * nt >= 1024) t = TILE_128x64;
+    int t = TILE_64x64;   // 128x64 measured slower on every layer of both networks (tools/bench_conv.py)
     if (force_tile >= 0) t = force_tile;
     const int bm = conv_tile_bm(t);
     const long long blocks = ((M + bm - 1) / bm) * nt;

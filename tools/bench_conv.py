@@ -9,6 +9,8 @@ from betapose_amd import ops
 
 LAYERS = {
     # name: (H, W, Cin, Cout, k, stride)
+    "y3x3_3_32_416": (416, 416, 3, 32, 3, 1),
+    "k7x7_3_64_s2_320x256": (320, 256, 3, 64, 7, 2),
     "y3x3_32_64_s2_416": (416, 416, 32, 64, 3, 2),
     "y3x3_64_128_104": (104, 104, 64, 128, 3, 1),
     "y1x1_256_128_52": (52, 52, 256, 128, 1, 1),
