@@ -67,27 +67,33 @@ def refine_keypoints(vertices: np.ndarray, keep: int) -> np.ndarray:
 
 def evaluate_results(final_result: List[dict], gt_frames: Dict[int, dict], model_vertices, cam_K, diameter_mm,
                      pixel_thresh: float = 5.0):
-    """The metric loop of betapose_evaluate.py:204-266.  ``gt_frames[nr] = {'pose': 4x4, 'bbox': [x, y, w, h]}``.
+    """The metric loop of betapose_evaluate.py:204-266.  ``gt_frames[nr]`` = list of ``{'pose': 4x4, 'bbox': [x, y, w, h]}`` (one per ground-truth
+    annotation compared; a bare dict is accepted for one).
     Returns dict(mean_add, mean_2d_acc, mean_iou, n)."""
     add_errs, adds, proj, ious = [], [], [], []
     for f in final_result:
         nr = int(os.path.basename(f["imgname"])[0:-4])
-        if nr not in gt_frames or len(f["result"]) < 1:
+        if nr not in gt_frames:
             continue
-        gt = gt_frames[nr]
-        x, y, w, h = gt["bbox"]
-        gt_box = [x, y, x + w, y + h]
-        pred_box = np.asarray(f["result"][0]["bbox"]).tolist()
-        i = iou(gt_box, pred_box)
-        ious.append(i)
-        pose = np.eye(4)
-        pose[:3, :3] = f["cam_R"]
-        pose[:3, 3] = np.asarray(f["cam_t"])[:, 0]
-        if i >= 0.5:
-            a = add_err(gt["pose"], pose, model_vertices) * 1000
-            add_errs.append(a)
-            adds.append(a < diameter_mm / 10)
-            proj.append(projection_error_2d(gt["pose"], pose, model_vertices, cam_K))
+        entries = gt_frames[nr]
+        if isinstance(entries, dict):
+            entries = [entries]
+        for gt in entries:
+            if len(f["result"]) < 1 or len(f["result"][0]) < 1:
+                continue
+            x, y, w, h = gt["bbox"]
+            gt_box = [x, y, x + w, y + h]
+            pred_box = np.asarray(f["result"][0]["bbox"]).tolist()
+            i = iou(gt_box, pred_box)
+            ious.append(i)
+            pose = np.eye(4)
+            pose[:3, :3] = f["cam_R"]
+            pose[:3, 3] = np.asarray(f["cam_t"])[:, 0]
+            if i >= 0.5:
+                a = add_err(gt["pose"], pose, model_vertices) * 1000
+                add_errs.append(a)
+                adds.append(a < diameter_mm / 10)
+                proj.append(projection_error_2d(gt["pose"], pose, model_vertices, cam_K))
     return {"mean_add": float(np.mean(adds)) if adds else float("nan"),
             "mean_2d_acc": float(np.mean(np.array(proj) < pixel_thresh)) if proj else float("nan"),
             "mean_iou": float(np.mean(np.array(ious) > 0.5)) if ious else float("nan"),

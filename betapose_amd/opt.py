@@ -37,6 +37,8 @@ def build_parser() -> argparse.ArgumentParser:
                         'frame, --left_keypoints for PnP, 20 px reprojection threshold')
     p.add_argument('--fused', default=False, action='store_true', help='one hipGraph per frame instead of stage threads')
     p.add_argument('--synthetic', type=int, default=0, help='run on N seeded synthetic frames / weights')
+    p.add_argument('--synth_weights', default=False, action='store_true',
+                   help='seeded synthetic weights with real frames / ground truth (plumbing runs without checkpoints)')
     p.add_argument('--sixd_base', default='/media/data_2/SIXD/hinterstoisser')
     p.add_argument('--yolo_weights', default='')
     p.add_argument('--kpd_weights', default='')

@@ -129,3 +129,44 @@ def synth_kp3d(n: int = 50, seed: int = 7, radius: float = 0.06) -> np.ndarray:
     rng = _rng(seed)
     p = rng.uniform(-1, 1, (n, 3))
     return (p * np.array([radius, radius * 0.7, radius * 0.5])).astype(np.float64)
+
+
+def _write_ply(path: str, pts: np.ndarray) -> None:
+    with open(path, "w") as f:
+        f.write("ply\nformat ascii 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n"
+                "end_header\n" % len(pts))
+        for x, y, z in pts:
+            f.write("%.6f %.6f %.6f\n" % (x, y, z))
+
+
+def write_sixd_tree(base: str, seq: int, gt_by_frame: Dict[int, list], models_mm: Dict[int, np.ndarray],
+                    kpmodels_mm: Dict[int, np.ndarray], diameters_mm: Dict[int, float], cam_K=None) -> None:
+    """Lay out a SIXD-format ground-truth tree the harness reads (utils/sixd.py:60-111; betapose_evaluate.py:60-75):
+    ``camera.yml``, ``models/models_info.yml``, ``models/obj_XX.ply``, ``kpmodels/obj_XX.ply`` (millimetres) and
+    ``test/<seq>/{gt.yml, info.yml}``.  ``gt_by_frame[nr]`` = list of ``(obj_id, R[3,3], t_mm[3], bbox[x,y,w,h])``."""
+    import os
+    import yaml
+    K = CAM_K if cam_K is None else np.asarray(cam_K, dtype=np.float64)
+    os.makedirs(os.path.join(base, "models"), exist_ok=True)
+    os.makedirs(os.path.join(base, "kpmodels"), exist_ok=True)
+    sdir = os.path.join(base, "test", "%02d" % seq)
+    os.makedirs(os.path.join(sdir, "rgb"), exist_ok=True)
+    with open(os.path.join(base, "camera.yml"), "w") as f:
+        yaml.safe_dump({"fx": float(K[0, 0]), "fy": float(K[1, 1]), "cx": float(K[0, 2]), "cy": float(K[1, 2]),
+                        "depth_scale": 1.0, "width": 640, "height": 480}, f)
+    with open(os.path.join(base, "models", "models_info.yml"), "w") as f:
+        yaml.safe_dump({int(k): {"diameter": float(v)} for k, v in sorted(diameters_mm.items())}, f)
+    for oid, pts in models_mm.items():
+        _write_ply(os.path.join(base, "models", "obj_%02d.ply" % oid), np.asarray(pts))
+    for oid, pts in kpmodels_mm.items():
+        _write_ply(os.path.join(base, "kpmodels", "obj_%02d.ply" % oid), np.asarray(pts))
+    gt, info = {}, {}
+    for nr, objs in sorted(gt_by_frame.items()):
+        gt[int(nr)] = [{"obj_id": int(o), "cam_R_m2c": [float(v) for v in np.asarray(R).reshape(9)],
+                        "cam_t_m2c": [float(v) for v in np.asarray(t).reshape(3)],
+                        "obj_bb": [float(v) for v in bb]} for (o, R, t, bb) in objs]
+        info[int(nr)] = {"cam_K": [float(v) for v in K.reshape(9)], "depth_scale": 1.0}
+    with open(os.path.join(sdir, "gt.yml"), "w") as f:
+        yaml.safe_dump(gt, f)
+    with open(os.path.join(sdir, "info.yml"), "w") as f:
+        yaml.safe_dump(info, f)

@@ -37,16 +37,29 @@ def load_sixd_gt(base, obj_id, seq_id=None):
     info = yaml.safe_load(open(os.path.join(base, "models", "models_info.yml")))
     frames = {}
     for nr, objs in gt.items():
-        for o in objs:
+        # LineMod looks at the frame's FIRST annotation only and skips the frame when that is another object
+        # (betapose_evaluate.py:219-221); Occlusion-LineMod walks every annotation of the frame
+        # (occlusion_betapose_evaluate.py:218-220)
+        cand = objs if seq_id is not None else objs[:1]
+        ent = []
+        for o in cand:
             if o["obj_id"] == obj_id:
                 pose = np.eye(4)
                 pose[:3, :3] = np.array(o["cam_R_m2c"]).reshape(3, 3)
-                pose[:3, 3] = np.array(o["cam_t_m2c"]) / 1000.0
-                frames[int(nr)] = {"pose": pose, "bbox": list(o["obj_bb"])}
-                break
+                pose[:3, 3] = np.array(o["cam_t_m2c"]).reshape(3) / 1000.0
+                ent.append({"pose": pose, "bbox": list(o["obj_bb"])})
+        frames[int(nr)] = ent
     model = metrics.load_ply_vertices(os.path.join(base, "models", "obj_%02d.ply" % obj_id)) / 1000.0
     kp = metrics.load_ply_vertices(os.path.join(base, "kpmodels", "obj_%02d.ply" % obj_id)) / 1000.0
-    return frames, model, kp, float(info[obj_id]["diameter"])
+    # camera of the 2-D reprojection metric: camera.yml when the dataset has one, identity otherwise
+    # (utils/sixd.py:53-68 -- ``Benchmark.cam``); PnP always uses the hard-coded LineMod K (betapose_evaluate.py:59)
+    cam = np.identity(3)
+    if os.path.exists(os.path.join(base, "camera.yml")):
+        c = yaml.safe_load(open(os.path.join(base, "camera.yml")))
+        cam[0, 0], cam[0, 2], cam[1, 1], cam[1, 2] = c["fx"], c["cx"], c["fy"], c["cy"]
+    # the reference indexes a list built in models_info.yml key order (sixd.py:72-76), which equals a lookup by
+    # object id for the 1..N keys every SIXD dataset has
+    return frames, model, kp, float(info[obj_id]["diameter"]), cam
 
 
 def main():
@@ -73,7 +86,7 @@ def main():
     os.makedirs(args.outputpath, exist_ok=True)
 
     # ---- inputs
-    gt_frames, model_vertices, diameter = None, None, None
+    gt_frames, model_vertices, diameter, metric_cam = None, None, None, None
     if args.synthetic:
         from PIL import Image
         args.inputpath = tempfile.mkdtemp(prefix="bp_frames_")
@@ -92,13 +105,13 @@ def main():
         else:
             raise IOError('Error: must contain either --indir/--list')
         cam_K = synth.CAM_K
-        gt_frames, model_vertices, kp3d, diameter = load_sixd_gt(args.sixd_base, obj_id, 2 if args.occlusion else None)
+        gt_frames, model_vertices, kp3d, diameter, metric_cam = load_sixd_gt(args.sixd_base, obj_id, 2 if args.occlusion else None)
         kp3d = metrics.refine_keypoints(kp3d, 50) if len(kp3d) > 50 else kp3d
 
     # ---- weights: rank 0 reads the files, the fp32 streams are broadcast (RCCL)
     ys = ks = None
     if rank == 0:
-        if args.synthetic and not args.yolo_weights:
+        if (args.synthetic or args.synth_weights) and not args.yolo_weights:
             ys = synth.synth_yolo_stream(1)
             ks = fastpose_stream_from_state_dict(synth.synth_fastpose_state_dict(2, args.nClasses), args.nClasses)
         else:
@@ -159,7 +172,7 @@ def main():
             len(im_names), sum(len(f['result']) > 0 for f in final_result), time.time() - t0))
         write_json(final_result, args.outputpath)
         if gt_frames is not None:
-            m = metrics.evaluate_results(final_result, gt_frames, model_vertices, cam_K, diameter, pixel_thresh)
+            m = metrics.evaluate_results(final_result, gt_frames, model_vertices, metric_cam, diameter, pixel_thresh)
             print("Mean add accuracy for seq %02d is: %.3f" % (obj_id, m["mean_add"]))
             print("2d reprojection accuracy for seq %02d is: %.3f" % (obj_id, m["mean_2d_acc"]))
             print("Mean IoU for seq %02d is: %.3f" % (obj_id, m["mean_iou"]))

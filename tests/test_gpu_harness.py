@@ -40,3 +40,55 @@ def test_dynamic_write_results_convention(cuda):
     assert dets.shape == (1, 8) and dets[0, 0] == 0
     np.testing.assert_allclose(dets[0, 1:].numpy(), [8, 8, 12, 12, 0.9, 0.7, 0], rtol=1e-6)
     assert dynamic_write_results(pred, 0.95, 80) == 0
+
+
+@pytest.mark.parametrize("occlusion", [False, True])
+def test_evaluate_dataset_layout_closed_loop(tmp_path, cuda, occlusion):
+    """The non-synthetic route of the harness (--indir frames + --sixd_base ground truth, LineMod and Occlusion
+    protocol): the ground-truth tree is written from the pipeline's own poses and boxes, so the three printed
+    numbers must all be 1.000 -- this exercises frame files -> engines -> JSON -> gt.yml / models / kpmodels
+    readers -> metric loop end to end."""
+    import re
+    from PIL import Image
+    from betapose_amd import synth
+    from betapose_amd.darknet import Darknet
+    from betapose_amd.kpd import FastPoseHIP
+    from betapose_amd.pipeline import FramePipeline, finish_record
+    from betapose_amd.weights import fastpose_stream_from_state_dict
+
+    obj_id, left = 1, (10 if occlusion else 50)
+    frames = helpers.frames(3)
+    indir = tmp_path / "rgb"
+    indir.mkdir()
+    for i, fr in enumerate(frames):
+        Image.fromarray(fr[:, :, ::-1].copy()).save(indir / ("%04d.png" % i))
+    kp_mm = np.round(synth.synth_kp3d(50) * 1000.0, 6)          # what the .ply holds after the %.6f write
+    kp3d = kp_mm / 1000.0
+
+    det = Darknet("yolo/cfg/yolov3-single.cfg", reso=416).load_stream(helpers.yolo_stream()).cuda()
+    pose = FastPoseHIP.from_stream(fastpose_stream_from_state_dict(helpers.kpd_state_dict(), 50), n_classes=50).cuda()
+    pipe = FramePipeline(det, pose, 480, 640, batch=1, confidence=0.01)
+    gt = {}
+    for i, fr in enumerate(frames):
+        out = finish_record(pipe.run(fr)[0], "%04d.png" % i, kp3d, synth.CAM_K, left)
+        assert out["boxes"] is not None and len(out["result"]) == 1
+        x1, y1, x2, y2 = [float(v) for v in out["result"][0]["bbox"]]
+        mine = (obj_id, out["cam_R"], np.asarray(out["cam_t"]).reshape(3) * 1000.0, [x1, y1, x2 - x1, y2 - y1])
+        other = (7, np.eye(3), np.array([0.0, 0.0, 800.0]), [5, 5, 20, 20])
+        gt[i] = [other, mine] if occlusion else [mine]
+    del pipe, det, pose
+    rng = np.random.default_rng(0)
+    model_mm = rng.normal(size=(300, 3)) * 30.0
+    synth.write_sixd_tree(str(tmp_path / "sixd"), 2 if occlusion else obj_id, gt, {obj_id: model_mm},
+                          {obj_id: kp_mm}, {obj_id: 100.0})
+
+    script = "occlusion_evaluate.py" if occlusion else "evaluate.py"
+    out = tmp_path / "out"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, script), "--indir", str(indir), "--outdir", str(out),
+                        "--sixd_base", str(tmp_path / "sixd"), "--synth_weights", "--fused",
+                        "--obj_id", str(obj_id), "--left_keypoints", "10"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    nums = dict(re.findall(r"(Mean add accuracy|2d reprojection accuracy|Mean IoU) for seq \d+ is: ([\d.nan]+)", r.stdout))
+    assert nums == {"Mean add accuracy": "1.000", "2d reprojection accuracy": "1.000", "Mean IoU": "1.000"}, r.stdout
+    assert len(json.loads(open(out / "Betapose-results.json").read())) == 3

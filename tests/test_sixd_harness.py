@@ -1,0 +1,100 @@
+"""Ground-truth side of the harness: the SIXD tree reader, the LineMod / Occlusion-LineMod
+annotation-selection rules and the metric loop (betapose_evaluate.py:204-266, occlusion_betapose_evaluate.py:202-262,
+utils/sixd.py:60-111) on a seeded synthetic tree -- no GPU."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import evaluate  # noqa: E402
+from betapose_amd import metrics, synth  # noqa: E402
+
+
+def _rot(rng):
+    q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+    return q * np.sign(np.linalg.det(q))
+
+
+def _tree(tmp_path, seq, per_frame):
+    rng = np.random.default_rng(3)
+    model = rng.normal(size=(200, 3)) * 30.0           # mm
+    kp = synth.synth_kp3d(60) * 1000.0                 # > 50: exercises Model3D.refine
+    synth.write_sixd_tree(str(tmp_path), seq, per_frame, {1: model, 5: model * 0.5}, {1: kp, 5: kp},
+                          {1: 100.0, 2: 50.0, 5: 80.0})
+    return model / 1000.0
+
+
+def _gt(rng, n, obj_ids):
+    out = {}
+    for nr in range(n):
+        out[nr] = [(o, _rot(rng), np.array([rng.uniform(-50, 50), rng.uniform(-50, 50), rng.uniform(600, 900)]),
+                    [100 + 10 * nr + o, 120, 80, 60]) for o in obj_ids]
+    return out
+
+
+def _result_from_gt(frames, nr, which=0, dt=(0, 0, 0), shift=0.0):
+    g = frames[nr][which]
+    x, y, w, h = g["bbox"]
+    return {"imgname": "%04d.png" % nr, "result": [{"bbox": np.array([x + shift, y, x + w + shift, y + h])}],
+            "cam_R": g["pose"][:3, :3].copy(), "cam_t": (g["pose"][:3, 3] + np.array(dt)).reshape(3, 1)}
+
+
+def test_linemod_tree_and_metric_loop(tmp_path):
+    rng = np.random.default_rng(1)
+    model_m = _tree(tmp_path, 1, _gt(rng, 4, [1]))
+    frames, model, kp, diameter, cam = evaluate.load_sixd_gt(str(tmp_path), 1)
+    assert sorted(frames) == [0, 1, 2, 3] and all(len(v) == 1 for v in frames.values())
+    np.testing.assert_allclose(model, model_m, atol=1e-9)
+    assert kp.shape == (60, 3) and diameter == 100.0
+    np.testing.assert_allclose(cam, synth.CAM_K)
+    assert metrics.refine_keypoints(kp, 50).shape == (50, 3)
+    assert 0.6 <= frames[2][0]["pose"][2, 3] <= 0.9      # millimetres in gt.yml -> metres (sixd.py:64,101)
+
+    perfect = [_result_from_gt(frames, nr) for nr in range(4)]
+    m = metrics.evaluate_results(perfect, frames, model, cam, diameter, 5.0)
+    assert (m["mean_add"], m["mean_2d_acc"], m["mean_iou"], m["n"]) == (1.0, 1.0, 1.0, 4)
+
+    mixed = [_result_from_gt(frames, 0), _result_from_gt(frames, 1, dt=(0, 0, 0.02)),   # 20 mm off: ADD miss (> d/10)
+             _result_from_gt(frames, 2, dt=(0.012, 0, 0)),                                # 12 mm sideways: > 5 px
+             _result_from_gt(frames, 3, shift=70.0),                                      # box IoU < 0.5: not scored
+             {"imgname": "0009.png", "result": [], "cam_R": [], "cam_t": []}]             # no GT for the frame
+    m = metrics.evaluate_results(mixed, frames, model, cam, diameter, 5.0)
+    assert m["n"] == 4 and abs(m["mean_iou"] - 0.75) < 1e-12
+    assert abs(m["mean_add"] - 1 / 3) < 1e-12           # frames 0..2 scored; 1 and 2 miss the 10 mm ADD threshold
+    # 2-D reprojection: frame 0 exact, frame 1 moved 20 mm along the optical axis (sub-5-px), frame 2 moved 12 mm
+    # sideways at 0.6-0.9 m (> 5 px) -- checked explicitly so the expectation is not accidental
+    def err(i):
+        est = np.vstack([np.c_[mixed[i]["cam_R"], mixed[i]["cam_t"]], [0, 0, 0, 1]])
+        return metrics.projection_error_2d(frames[i][0]["pose"], est, model, cam)
+    assert err(0) < 1e-9 and err(1) < 5.0 < err(2)
+    assert abs(m["mean_2d_acc"] - 2 / 3) < 1e-12
+
+
+def test_linemod_first_annotation_rule_and_occlusion_walk(tmp_path):
+    rng = np.random.default_rng(2)
+    gt = _gt(rng, 3, [5, 1])               # every frame: object 5 first, object 1 second
+    gt[1] = gt[1][::-1]                    # frame 1: object 1 first
+    model = _tree(tmp_path, 1, gt)
+    _tree(tmp_path, 2, gt)                 # the same annotations as Occlusion sequence 02
+    lm, _, _, _, cam = evaluate.load_sixd_gt(str(tmp_path), 1)
+    assert [len(lm[i]) for i in range(3)] == [0, 1, 0]       # LineMod: only gt[0] counts (betapose_evaluate.py:219)
+    occ, _, _, d5, _ = evaluate.load_sixd_gt(str(tmp_path), 5, 2)
+    assert [len(occ[i]) for i in range(3)] == [1, 1, 1] and d5 == 80.0
+    occ1, _, _, d1, _ = evaluate.load_sixd_gt(str(tmp_path), 1, 2)
+    assert [len(occ1[i]) for i in range(3)] == [1, 1, 1] and d1 == 100.0
+    res = [_result_from_gt(occ1, nr) for nr in range(3)]
+    m = metrics.evaluate_results(res, occ1, model, cam, d1, 20.0)
+    assert (m["mean_add"], m["mean_2d_acc"], m["mean_iou"], m["n"]) == (1.0, 1.0, 1.0, 3)
+    m = metrics.evaluate_results(res, lm, model, cam, d1, 5.0)          # LineMod rule: only frame 1 is scored
+    assert m["n"] == 1
+
+
+def test_metric_camera_defaults_to_identity_without_camera_yml(tmp_path):
+    rng = np.random.default_rng(4)
+    _tree(tmp_path, 1, _gt(rng, 1, [1]))
+    os.remove(tmp_path / "camera.yml")
+    cam = evaluate.load_sixd_gt(str(tmp_path), 1)[4]
+    np.testing.assert_array_equal(cam, np.identity(3))                   # utils/sixd.py:53 Benchmark.cam
