@@ -12,8 +12,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbetapose_hip.so")
-SOURCES = ["conv_igemm.hip", "aux_kernels.hip", "engine.cpp", "host_post.cpp", "c_api.cpp"]
-HEADERS = ["bp_common.h", "engine.h", os.path.join("..", "..", "include", "betapose_hip.h")]
+SOURCES = ["conv_igemm.hip", "aux_kernels.hip", "engine.cpp", "host_post.cpp", "frame_io.cpp", "c_api.cpp"]
+HEADERS = ["bp_common.h", "engine.h", "frame_io.h", os.path.join("..", "..", "include", "betapose_hip.h")]
 ARCH = "gfx950"
 
 
@@ -54,7 +54,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out))
         if verbose and out.strip():
             print(out)
-    cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-lz", "-lpthread"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

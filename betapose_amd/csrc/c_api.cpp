@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "engine.h"
+#include "frame_io.h"
 
 namespace bp {
 int solve_pnp(const double* P, const double* U, int n, const double* K, double* R, double* t);
@@ -508,6 +509,90 @@ int bp_solve_pnp(const double* pts3d, const double* pts2d, int n, const double* 
     BP_CHECK(pts3d && pts2d && K && R && t, "null argument");
     const int rc = bp::solve_pnp(pts3d, pts2d, n, K, R, t);
     if (rc != 0) throw bp::Error("solve_pnp failed (need >= 6 non-degenerate points)");
+    return 0;
+    BP_CATCH
+}
+
+// ------------------------------------------------------------------ frame input (host)
+struct bp_loader {
+    std::unique_ptr<bp::FrameLoader> l;
+};
+
+static void* pinned_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+static void pinned_free(void* p) { (void)hipHostFree(p); }
+
+int bp_png_info(const unsigned char* data, size_t n, int* h, int* w, int* channels) {
+    BP_TRY
+    BP_CHECK(data, "null argument");
+    bp::png_info(data, n, h, w, channels);
+    return 0;
+    BP_CATCH
+}
+
+int bp_png_decode_bgr(const unsigned char* data, size_t n, unsigned char* out_bgr, size_t cap, int* h, int* w) {
+    BP_TRY
+    BP_CHECK(data && out_bgr, "null argument");
+    static thread_local std::vector<uint8_t> scratch;
+    bp::png_decode_bgr(data, n, out_bgr, cap, h, w, scratch);
+    return 0;
+    BP_CATCH
+}
+
+int bp_loader_create(const char* const* paths, int n, int H, int W, int threads, int depth, int pinned, bp_loader** out) {
+    BP_TRY
+    BP_CHECK(paths && out && n >= 0, "null argument");
+    std::vector<std::string> v;
+    for (int i = 0; i < n; ++i) {
+        BP_CHECK(paths[i], "null path");
+        v.emplace_back(paths[i]);
+    }
+    int ndev = 0;
+    const bool pin = pinned && hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0;
+    if (!pin) (void)hipGetLastError();
+    auto* L = new bp_loader;
+    try {
+        L->l.reset(new bp::FrameLoader(std::move(v), H, W, threads, depth, pin ? pinned_alloc : nullptr,
+                                       pin ? pinned_free : nullptr));
+    } catch (...) {
+        delete L;
+        throw;
+    }
+    *out = L;
+    return 0;
+    BP_CATCH
+}
+
+void bp_loader_destroy(bp_loader* l) { delete l; }
+
+int bp_loader_next(bp_loader* l, long long* index, const unsigned char** bgr) {
+    BP_TRY
+    BP_CHECK(l, "null argument");
+    std::string err;
+    const int rc = l->l->next(index, bgr, &err);
+    if (rc < 0) g_err = err;
+    return rc;
+    BP_CATCH
+}
+
+int bp_loader_release(bp_loader* l, long long index) {
+    BP_TRY
+    BP_CHECK(l, "null argument");
+    l->l->release(index);
+    return 0;
+    BP_CATCH
+}
+
+int bp_upload(void* d_dst, const void* h_src, size_t bytes, void* stream) {
+    BP_TRY
+    BP_CHECK(d_dst && h_src, "null argument");
+    BP_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
     return 0;
     BP_CATCH
 }

@@ -39,6 +39,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument('--synthetic', type=int, default=0, help='run on N seeded synthetic frames / weights')
     p.add_argument('--synth_weights', default=False, action='store_true',
                    help='seeded synthetic weights with real frames / ground truth (plumbing runs without checkpoints)')
+    p.add_argument('--streams', type=int, default=4, help='--fused: frames in flight (HIP streams / engine clones)')
+    p.add_argument('--load_threads', type=int, default=8, help='--fused: PNG decode threads')
     p.add_argument('--sixd_base', default='/media/data_2/SIXD/hinterstoisser')
     p.add_argument('--yolo_weights', default='')
     p.add_argument('--kpd_weights', default='')

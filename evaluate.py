@@ -125,15 +125,23 @@ def main():
 
     t0 = time.time()
     if args.fused:
-        from betapose_amd.img import load_frame_bgr
-        from betapose_amd.pipeline import FramePipeline, finish_record
+        from betapose_amd.frame_loader import FrameLoader
+        from betapose_amd.pipeline import StreamedRunner, finish_record
         mine = bpd.shard_indices(len(im_names), rank, world)
-        first = load_frame_bgr(os.path.join(args.inputpath, im_names[0]))
-        pipe = FramePipeline(det, pose_model, first.shape[0], first.shape[1], batch=1, confidence=args.confidence,
-                             num_classes=args.num_classes)
-        recs = np.zeros((len(mine), pipe.results.shape[1]), np.float32)
-        for j, i in enumerate(mine):
-            recs[j] = pipe.run(load_frame_bgr(os.path.join(args.inputpath, im_names[i])))[0]
+        loader = FrameLoader([os.path.join(args.inputpath, im_names[i]) for i in mine], threads=args.load_threads,
+                             depth=max(16, 2 * args.streams + args.load_threads))
+        runner = StreamedRunner(det, pose_model, loader.height, loader.width, streams=args.streams,
+                                confidence=args.confidence, num_classes=args.num_classes)
+        recs = np.zeros((len(mine), 316), np.float32)
+
+        def keep(j, rec):
+            recs[j] = rec
+        t_dev = time.time()
+        runner.run(loader, keep)
+        t_dev = time.time() - t_dev
+        loader.close()
+        print("rank %d: %d frames, files -> records %.1f frames/sec (%d frames in flight, %d decode threads)" % (
+            rank, len(mine), len(mine) / max(t_dev, 1e-9), args.streams, args.load_threads))
         allrec = bpd.gather_records(recs, mine, len(im_names))
         final_result = []
         if rank == 0:

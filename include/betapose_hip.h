@@ -144,6 +144,23 @@ int bp_pipeline_run(bp_pipeline* p, int use_graph, void* stream);
  * pts3d [n][3], pts2d [n][2], K [9] row-major; outputs R [9] row-major, t [3]. */
 int bp_solve_pnp(const double* pts3d, const double* pts2d, int n, const double* K, double* R, double* t);
 
+/* ---- frame input (host; replaces cv2.imread on ImageLoader's thread, dataloader.py:150-179) ---- */
+/* PNG -> cv2.imread(IMREAD_COLOR) convention: [h][w][3] u8 in B,G,R order; alpha dropped, grey replicated, palette
+ * expanded, 16-bit samples reduced to the high byte.  Adam7-interlaced files are rejected. */
+int bp_png_info(const unsigned char* data, size_t n, int* h, int* w, int* channels);
+int bp_png_decode_bgr(const unsigned char* data, size_t n, unsigned char* out_bgr, size_t cap, int* h, int* w);
+/* read-ahead loader: `threads` workers decode the PNG files `paths[0..n)` (each H x W) in list order into a ring of
+ * `depth` host slots (pinned with hipHostMalloc when `pinned` and a GPU is present).
+ * bp_loader_next: 0 = *bgr points at frame *index until bp_loader_release(*index); 1 = list exhausted;
+ * <0 = that frame failed (bp_last_error(); it must still be released).  One consumer thread. */
+typedef struct bp_loader bp_loader;
+int bp_loader_create(const char* const* paths, int n, int H, int W, int threads, int depth, int pinned, bp_loader** out);
+void bp_loader_destroy(bp_loader* l);
+int bp_loader_next(bp_loader* l, long long* index, const unsigned char** bgr);
+int bp_loader_release(bp_loader* l, long long index);
+/* asynchronous host -> device copy on `stream` (h_src should be a loader slot or other pinned memory) */
+int bp_upload(void* d_dst, const void* h_src, size_t bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
