@@ -164,41 +164,27 @@ def roofline(det, pose, batch):
 
 def main():
     a = parse_args()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
-    import torch.distributed as dist
-    from betapose_amd import _lib, cfg as C, synth
+    from betapose_amd import _lib, cfg as C, dist as bpd, synth
     from betapose_amd.darknet import Darknet
     from betapose_amd.kpd import FastPoseHIP
     from betapose_amd.pipeline import FramePipeline, finish_record
     from betapose_amd.weights import fastpose_stream_from_state_dict
 
     _lib.require_gpu()
-    torch.cuda.set_device(local)
+    rank, world, local = bpd.init_from_env()
     dev = torch.device("cuda", local)
-    if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     # ---- weights: rank 0 builds the two fp32 streams, everyone else receives them over RCCL
     blocks = C.parse_cfg_text(C.yolov3_single_cfg_text())
+    ys = ks = None
     if rank == 0:
-        ys = torch.from_numpy(synth.synth_yolo_stream(1, blocks)).to(dev)
-        ks = torch.from_numpy(fastpose_stream_from_state_dict(synth.synth_fastpose_state_dict(2))).to(dev)
-        sizes = torch.tensor([ys.numel(), ks.numel()], device=dev)
-    else:
-        sizes = torch.zeros(2, dtype=torch.long, device=dev)
-    if world > 1:
-        dist.broadcast(sizes, 0)
-        if rank != 0:
-            ys = torch.empty(int(sizes[0]), device=dev)
-            ks = torch.empty(int(sizes[1]), device=dev)
-        dist.broadcast(ys, 0)
-        dist.broadcast(ks, 0)
+        ys = synth.synth_yolo_stream(1, blocks)
+        ks = fastpose_stream_from_state_dict(synth.synth_fastpose_state_dict(2))
+    ys, ks = bpd.broadcast_stream(ys), bpd.broadcast_stream(ks)
     det = Darknet("yolo/cfg/yolov3-single.cfg", reso=416, max_batch=a.batch, device=local)
-    det.load_stream(ys.cpu().numpy())
-    pose = FastPoseHIP.from_stream(ks.cpu().numpy(), n_classes=50, max_batch=a.batch, device=local)
+    det.load_stream(ys)
+    pose = FastPoseHIP.from_stream(ks, n_classes=50, max_batch=a.batch, device=local)
     del ys, ks
     det.cuda()
     pose.cuda()
@@ -259,25 +245,17 @@ def main():
 
     run(max(a.warmup, 1), False)
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    bpd.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(a.steps, True)
-    gathered = None
-    if world > 1:   # xGMI gather of detections only: [steps, batch, 316] floats per rank
-        mine = torch.from_numpy(records).to(dev)
-        gathered = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(gathered, mine)
+    # xGMI gather of detections only: steps*batch records of 316 floats per rank, in global frame order on rank 0
+    flat = records.reshape(-1, records.shape[-1])
+    gathered = bpd.gather_records(flat, [rank + world * j for j in range(len(flat))], world * len(flat))
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    bpd.barrier()
     torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([el], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t[0])
+    el = bpd.max_over_ranks(time.perf_counter() - t0)
 
     out = None
     if rank == 0:
@@ -296,7 +274,9 @@ def main():
                        "hip_graph": not a.no_graph, "fixed_box": a.fixed_box, "frames_in_flight": S,
                        "graph_nodes": pipe.kernel_count()},
             "detections": stats["det"], "poses": stats["pose"],
+            "records_gathered": int((gathered[:, 0].view(np.int32) >= -1).sum()) if gathered is not None else 0,
         }
+        assert gathered.shape == (frames_total, records.shape[-1])
         t1 = time.perf_counter()
         for _ in range(200):
             finish_record(records[0, 0], "x.png", kp3d, cam_K)
@@ -313,9 +293,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(a.cpu_seconds, kp3d, cam_K)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    bpd.finalize()
 
 
 if __name__ == "__main__":

@@ -35,6 +35,55 @@ def is_dist() -> bool:
     return dist.is_available() and dist.is_initialized()
 
 
+def init_from_env():
+    """Join the job ``torch.distributed.run`` started (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*): binds this
+    process to its GPU and, for world > 1, initialises the process group -- RCCL (``nccl``) over xGMI by default;
+    ``BP_DIST_BACKEND=gloo`` routes the (tiny) collectives through the host instead, which also lets several ranks
+    share one GPU on a single-GPU box.  Returns ``(rank, world, device_index)``."""
+    import os
+    import torch
+    dist = _dist()
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("BP_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if ndev <= 0:
+        raise RuntimeError("no GPU visible to rank %d" % rank)
+    if backend == "nccl" and world > 1 and local >= ndev:
+        raise RuntimeError("LOCAL_RANK %d but only %d GPUs visible (one process per GPU)" % (local, ndev))
+    device = local % ndev
+    torch.cuda.set_device(device)
+    if world > 1 and not is_dist():
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, device
+
+
+def barrier() -> None:
+    if is_dist() and _dist().get_world_size() > 1:
+        _dist().barrier()
+
+
+def max_over_ranks(x: float) -> float:
+    """The slowest rank's value (timed regions are reported as the max over ranks)."""
+    import torch
+    dist = _dist()
+    if not is_dist() or dist.get_world_size() == 1:
+        return float(x)
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([x], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t[0])
+
+
+def finalize() -> None:
+    if is_dist():
+        _dist().barrier()
+        _dist().destroy_process_group()
+
+
 def broadcast_stream(stream: Optional[np.ndarray], src: int = 0, device=None) -> np.ndarray:
     """Broadcast a flat fp32 weight stream (rank ``src`` passes the array, others ``None``)."""
     import torch

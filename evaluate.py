@@ -64,20 +64,14 @@ def load_sixd_gt(base, obj_id, seq_id=None):
 
 def main():
     args = parse_args()
-    import torch
-    import torch.distributed as dist
-    from betapose_amd import _lib, cfg as C
+    from betapose_amd import _lib
     from betapose_amd.darknet import Darknet
     from betapose_amd.kpd import ALLPATHS, FastPoseHIP
     from betapose_amd.pPose_nms import write_json
     from betapose_amd.weights import fastpose_stream_from_state_dict, load_kpd_pkl, read_darknet_weights
 
-    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
     _lib.require_gpu()
-    torch.cuda.set_device(local)
-    if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    rank, world, local = bpd.init_from_env()
     obj_id = args.obj_id
     # key points handed to PnP: all 50 on LineMod (betapose_evaluate.py:139), the --left_keypoints best on Occlusion
     left_number = args.left_keypoints if args.occlusion else 50
@@ -184,9 +178,7 @@ def main():
             print("Mean add accuracy for seq %02d is: %.3f" % (obj_id, m["mean_add"]))
             print("2d reprojection accuracy for seq %02d is: %.3f" % (obj_id, m["mean_2d_acc"]))
             print("Mean IoU for seq %02d is: %.3f" % (obj_id, m["mean_iou"]))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    bpd.finalize()
 
 
 if __name__ == "__main__":

@@ -54,8 +54,10 @@ WORKER = textwrap.dedent('''
         print("GATHER_OK")
     else:
         assert out is None
-    dist.barrier()
-    dist.destroy_process_group()
+    assert bpd.max_over_ranks(1.5 + rank) == 1.5 + (world - 1)      # timed regions: slowest rank
+    bpd.barrier()
+    bpd.finalize()
+    assert not bpd.is_dist()
 ''')
 
 
