@@ -43,6 +43,9 @@ def parse_args():
     ap.add_argument("--fixed-box", action="store_true", help="deterministic crop box (220,140,420,340)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--partition", type=int, default=0,
+                    help="give each of the --streams frames in flight its own 1/PARTITION slice of the CUs of every "
+                         "XCD (hipExtStreamCreateWithCUMask); 0 = ordinary streams sharing the chip")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--pool", type=int, default=8, help="distinct synthetic frames per rank")
     ap.add_argument("--streams", type=int, default=4,
@@ -199,7 +202,14 @@ def main():
         p_.set_policy(a.sk_target, a.sk_min, a.sk_max, a.tile)
     pipes = [FramePipeline(dets[k], poses[k], 480, 640, batch=a.batch, confidence=0.01, num_classes=80,
                            use_graph=not a.no_graph) for k in range(S)]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+    masked = []
+    if a.partition:
+        from betapose_amd.streams import MaskedStream, partition_cus
+        slices = partition_cus(a.partition)
+        masked = [MaskedStream(*slices[k % len(slices)], device=local) for k in range(S)]
+        streams = [m.torch for m in masked]
+    else:
+        streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     pipe = pipes[0]
     if a.fixed_box:
         for p_ in pipes:
@@ -271,7 +281,7 @@ def main():
                                    "50 kp arg-max -> pPose-NMS -> PnP",
                        "batch": a.batch, "global_batch": a.batch * world, "frame": "640x480x3 u8",
                        "parallelism": "frames sharded by image, 1 process per GPU (dp%d)" % world,
-                       "hip_graph": not a.no_graph, "fixed_box": a.fixed_box, "frames_in_flight": S,
+                       "hip_graph": not a.no_graph, "fixed_box": a.fixed_box, "frames_in_flight": S, "cu_partition": a.partition,
                        "graph_nodes": pipe.kernel_count()},
             "detections": stats["det"], "poses": stats["pose"],
             "records_gathered": int((gathered[:, 0].view(np.int32) >= -1).sum()) if gathered is not None else 0,

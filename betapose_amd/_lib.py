@@ -67,6 +67,9 @@ PROTOTYPES = {
     "bp_pipeline_set_fixed_box": (C.c_int, [vp, vp]),
     "bp_pipeline_run": (C.c_int, [vp, C.c_int, vp]),
     "bp_solve_pnp": (C.c_int, [vp, vp, C.c_int, vp, vp, vp]),
+    "bp_stream_create_masked": (C.c_int, [vp, C.c_int, C.POINTER(vp)]),
+    "bp_stream_destroy": (C.c_int, [vp]),
+    "bp_probe_placement": (C.c_int, [C.c_int, vp, vp, vp]),
     "bp_png_info": (C.c_int, [vp, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "bp_png_decode_bgr": (C.c_int, [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "bp_loader_create": (C.c_int, [C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

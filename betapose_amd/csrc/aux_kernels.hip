@@ -523,4 +523,18 @@ void launch_resize_bicubic(const uint8_t* in, int batch, int H, int W, uint8_t* 
                        out_nhwc, out_u8, oh, t.vb, t.vk, t.ksize_v, swap_rb);
 }
 
+// ---- placement probe: which XCD / CU every workgroup of a grid landed on (CU-mask experiments, tests)
+__global__ void probe_placement_kernel(int* out) {
+    if (threadIdx.x == 0) {
+        const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | ((4 - 1) << 11));    // HW_REG_XCC_ID[3:0]
+        const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | ((32 - 1) << 11));     // HW_REG_HW_ID
+        out[2 * blockIdx.x] = (int)xcc;
+        out[2 * blockIdx.x + 1] = (int)hw;
+    }
+}
+
+void launch_probe_placement(int* d_out, int blocks, hipStream_t s) {
+    hipLaunchKernelGGL(probe_placement_kernel, dim3(blocks), dim3(64), 0, s, d_out);
+}
+
 }  // namespace bp

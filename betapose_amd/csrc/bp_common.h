@@ -112,6 +112,7 @@ void launch_yolo_select(const float* pred, int N, int rows, int attrs, float con
 void launch_heatmap_argmax(const float* hm, int N, int C, int H, int W, float* out, hipStream_t s);
 
 // [batch][rec_floats] rows = sel[8] | pts[8] | kp[kp_floats]
+void launch_probe_placement(int* d_out, int blocks, hipStream_t s);
 void launch_pack_records(const float* sel, const float* pts, const float* kp, float* out, int batch, int kp_floats,
                          int rec_floats, hipStream_t s);
 

@@ -94,6 +94,43 @@ int bp_device_name(int device, char* out, int cap) {
     BP_CATCH
 }
 
+// ------------------------------------------------------------------ streams bound to a CU subset
+int bp_stream_create_masked(const uint32_t* cu_mask, int words, void** out) {
+    BP_TRY
+    BP_CHECK(cu_mask && words > 0 && out, "null argument");
+    hipStream_t s = nullptr;
+    BP_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)words, cu_mask));
+    *out = (void*)s;
+    return 0;
+    BP_CATCH
+}
+
+int bp_stream_destroy(void* stream) {
+    BP_TRY
+    BP_HIP(hipStreamDestroy((hipStream_t)stream));
+    return 0;
+    BP_CATCH
+}
+
+int bp_probe_placement(int blocks, int* h_xcc, int* h_hw_id, void* stream) {
+    BP_TRY
+    BP_CHECK(blocks > 0 && h_xcc, "bad argument");
+    int* d = nullptr;
+    BP_HIP(hipMalloc(&d, (size_t)blocks * 2 * sizeof(int)));
+    bp::launch_probe_placement(d, blocks, (hipStream_t)stream);
+    std::vector<int> h((size_t)blocks * 2);
+    hipError_t e = hipMemcpyAsync(h.data(), d, h.size() * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    (void)hipFree(d);
+    BP_HIP(e);
+    for (int i = 0; i < blocks; ++i) {
+        h_xcc[i] = h[2 * i];
+        if (h_hw_id) h_hw_id[i] = h[2 * i + 1];
+    }
+    return 0;
+    BP_CATCH
+}
+
 // ------------------------------------------------------------------ detector
 int bp_yolo_create_from_memory(const char* cfg_text, const float* stream, size_t n_floats, int reso, int max_batch,
                                int device, bp_yolo** out) {

@@ -144,6 +144,15 @@ int bp_pipeline_run(bp_pipeline* p, int use_graph, void* stream);
  * pts3d [n][3], pts2d [n][2], K [9] row-major; outputs R [9] row-major, t [3]. */
 int bp_solve_pnp(const double* pts3d, const double* pts2d, int n, const double* K, double* R, double* t);
 
+/* ---- HIP streams confined to a subset of the CUs (one frame pipeline per XCD) ---- */
+/* cu_mask: `words` x 32 bits, bit i = CU i of the device in the driver's numbering (on MI355X bit i lies on XCD i % 8,
+ * checked by bp_probe_placement).  The stream is a plain hipStream_t (void*) usable with every call above. */
+int bp_stream_create_masked(const uint32_t* cu_mask, int words, void** out_stream);
+int bp_stream_destroy(void* stream);
+/* launches `blocks` workgroups on `stream` and reports where each ran: h_xcc[b] = XCD id (0..7), h_hw_id[b] = raw
+ * HW_ID register (may be NULL) */
+int bp_probe_placement(int blocks, int* h_xcc, int* h_hw_id, void* stream);
+
 /* ---- frame input (host; replaces cv2.imread on ImageLoader's thread, dataloader.py:150-179) ---- */
 /* PNG -> cv2.imread(IMREAD_COLOR) convention: [h][w][3] u8 in B,G,R order; alpha dropped, grey replicated, palette
  * expanded, 16-bit samples reduced to the high byte.  Adam7-interlaced files are rejected. */

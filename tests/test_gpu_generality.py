@@ -115,3 +115,30 @@ def test_crop_and_resize_other_frame_sizes(cuda, hw):
     out, pts = ops.crop(torch.from_numpy(frame[None]).to(cuda), boxes=box.to(cuda))
     np.testing.assert_array_equal(pts.cpu().numpy()[0, :4], np.r_[pt1.numpy()[0], pt2.numpy()[0]])
     assert float((out.cpu() - ref).abs().max()) <= 2e-6
+
+
+def test_masked_stream_confines_work_to_its_cu_slice(cuda):
+    """hipExtStreamCreateWithCUMask: mask bit i = CU i//8 of XCD i%8; a slice of k CUs per XCD gives 8k places and the
+    workgroups still go round-robin to all 8 XCDs."""
+    import torch
+    from betapose_amd.streams import MaskedStream, partition_cus, slice_mask_words
+    assert partition_cus(4) == [(0, 8), (8, 16), (16, 24), (24, 32)]
+    w = slice_mask_words(8, 16)
+    assert w.tolist() == [0, 0, 0xFFFFFFFF, 0xFFFFFFFF, 0, 0, 0, 0]
+    seen = []
+    for lo, hi in partition_cus(4):
+        st = MaskedStream(lo, hi)
+        x, hw = st.probe(4096)
+        assert sorted(set(x.tolist())) == list(range(8))
+        places = set(zip(x.tolist(), ((hw >> 13) & 7).tolist(), ((hw >> 8) & 15).tolist()))
+        assert len(places) == 64 == st.n_cus
+        seen.append(places)
+        # the stream works as a torch stream
+        with torch.cuda.stream(st.torch):
+            y = torch.arange(1000, device="cuda").float().sum()
+        st.torch.synchronize()
+        assert float(y) == 499500.0
+        st.close()
+    for i in range(4):
+        for j in range(i):
+            assert not (seen[i] & seen[j])          # slices do not overlap
