@@ -106,6 +106,28 @@ def test_yolo_batch_equals_single(yolo, cuda):
         assert int(p1[0, :, 4].argmax()) == int(pb[i, :, 4].argmax())
 
 
+def test_yolo_vs_reference_darknet_c(yolo, cuda, tmp_path):
+    """The reference's own compiled Darknet-C (oracle/_ref, built from /root/reference by oracle/Makefile) on the same
+    .weights file: same rows after re-ordering, same YOLO box index.  Darknet-C folds BN with sqrt(var)+1e-6 instead of
+    sqrt(var+1e-5) in each of the 72 BN layers, hence ~1e-4 agreement (the torch oracle shows the same distance to it,
+    tests/test_darknet_c_ref.py)."""
+    from betapose_amd import cfg as C
+    from oracle import darknet_c_ref
+    if not darknet_c_ref.available():
+        pytest.skip("oracle/_ref/libdarknet_ref.so not built")
+    wpath = tmp_path / "01.weights"
+    W.write_darknet_weights(str(wpath), helpers.yolo_stream())
+    net = darknet_c_ref.DarknetC(C.yolov3_single_cfg_text(), str(wpath), 416)
+    x = helpers.yolo_input_from_frame(helpers.frames()[1])
+    c_rows = net.predict_rows(x[0].numpy())
+    got = yolo(x.cuda()).cpu().numpy()[0]
+    assert got.shape == c_rows.shape == (10647, 6)
+    assert np.abs(got[:, :2] - c_rows[:, :2]).max() < 2e-3
+    assert bool((np.abs(got[:, 2:4] - c_rows[:, 2:4]) <= 2e-3 + 5e-4 * np.abs(c_rows[:, 2:4])).all())
+    assert np.abs(got[:, 4:] - c_rows[:, 4:]).max() < 2e-4
+    assert int(got[:, 4].argmax()) == int(c_rows[:, 4].argmax())
+
+
 def test_yolo_no_detection_returns_int0(yolo, cuda):
     x = helpers.yolo_input_from_frame(helpers.frames()[0])
     sel = yolo.forward_select(x.to(cuda), confidence=0.9999)
