@@ -101,10 +101,63 @@ def cpu_baseline(seconds: float, kp3d, cam_K):
         el = time.perf_counter() - t0
         if el >= seconds or n >= 400:
             break
+    ref = reference_darknet_c(frames, blocks, torch.get_num_threads())
     return {"value": n / el, "unit": "frames/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "reference_darknet_c": ref,
             "sample": "%d synthetic 640x480 frames through oracle/ (PIL resize, torch-CPU fp32 YOLOv3+FastPose, "
                       "getPrediction, pose_nms, scipy PnP) in %.1f s" % (n, el),
             "cpu_model": _cpu_model()}
+
+
+class _quiet_c_output:
+    """Darknet-C prints its layer table with printf/fprintf: keep stdout to the one JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush(); sys.stderr.flush()
+        self._saved = (os.dup(1), os.dup(2))
+        null = os.open(os.devnull, os.O_WRONLY)
+        os.dup2(null, 1); os.dup2(null, 2)
+        os.close(null)
+
+    def __exit__(self, *exc):
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        os.dup2(self._saved[0], 1); os.dup2(self._saved[1], 2)
+        os.close(self._saved[0]); os.close(self._saved[1])
+        return False
+
+
+def reference_darknet_c(frames, blocks, threads):
+    """The reference's OWN detector executable code (Darknet-C compiled into oracle/_ref by oracle/Makefile) timed on
+    the same host cores: YOLO forward + get_network_boxes only -- the KPD half of the reference is Python and cannot
+    travel to this box.  None when oracle/_ref was not built."""
+    import ctypes
+    import tempfile
+    from PIL import Image
+    from betapose_amd import cfg as C, synth, weights as W
+    from oracle import darknet_c_ref
+    if not darknet_c_ref.available():
+        return None
+    try:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(threads))
+    except OSError:
+        pass
+    with tempfile.TemporaryDirectory(prefix="bp_dk_") as tmp, _quiet_c_output():
+        wpath = os.path.join(tmp, "01.weights")
+        W.write_darknet_weights(wpath, synth.synth_yolo_stream(1, blocks))
+        net = darknet_c_ref.DarknetC(C.yolov3_single_cfg_text(), wpath, 416)
+        xs = [np.asarray(Image.fromarray(np.ascontiguousarray(f[:, :, ::-1])).resize((416, 416), 3),
+                         dtype=np.float32).transpose(2, 0, 1) / 255.0 for f in frames[:3]]
+        net.predict_rows(np.ascontiguousarray(xs[0]))   # warm-up
+        t0 = time.perf_counter()
+        for x in xs:
+            net.predict_rows(np.ascontiguousarray(x))
+        el = time.perf_counter() - t0
+    return {"yolo_frames_per_sec": len(xs) / el, "threads": int(threads), "kind": "reference",
+            "sample": "%d frames, network_predict_image + get_network_boxes of the reference's Darknet-C (AVX2, OpenMP)" % len(xs)}
 
 
 def _cpu_model():
