@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_F16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: BF16/F16 ~2.5 PF dense (v_mfma_f32_32x32x16_f16)
 TILE_NAMES = {0: "1, 1", 1: "2, 1"}
 
 
@@ -55,6 +56,9 @@ def parse_args():
     ap.add_argument("--sk-min", type=int, default=4)
     ap.add_argument("--sk-max", type=int, default=8)
     ap.add_argument("--tile", type=int, default=-1)
+    ap.add_argument("--precision", choices=["f32", "f16"], default="f32",
+                    help="matrix-core operand precision: f32 = fp32 MFMA (the parity configuration, default); f16 = fp16 "
+                         "MFMA operands with fp32 accumulation (BASELINE configs[2])")
     return ap.parse_args()
 
 
@@ -205,11 +209,17 @@ def roofline(det, pose, batch):
                 break
     except Exception:
         pass
+    f16 = key[1] == 2
+    peak = PEAK_F16_MFMA_TFLOPS if f16 else PEAK_FP32_MFMA_TFLOPS
+    name = ("bp::conv_igemm_f16_kernel<%s>" % TILE_NAMES.get(key[0], "?")) if f16 else \
+        "bp::conv_igemm_kernel<%s, %s>" % (TILE_NAMES.get(key[0], "?"), "true" if key[1] else "false")
+    if f16:
+        traffic, traffic_src = None, None     # the committed PMC passes are of the fp32 kernel
     return {
-        "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+        "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+        "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
         "algorithmic_bytes_per_launch": g["bytes"] / g["launches"],
-        "kernel": "bp::conv_igemm_kernel<%s, %s>" % (TILE_NAMES.get(key[0], "?"), "true" if key[1] else "false"),
+        "kernel": name,
         "launches_per_step": g["launches"], "avg_launch_us": round(g["ms"] / g["launches"] * 1e3, 2),
         "flops_per_launch": g["flops"] / g["launches"],
         "all_conv": {"achieved": round(conv_flops / (conv_ms * 1e-3) / 1e12, 2), "ms_per_step": round(conv_ms, 4),
@@ -247,6 +257,8 @@ def main():
 
     det.set_policy(a.sk_target, a.sk_min, a.sk_max, a.tile)
     pose.set_policy(a.sk_target, a.sk_min, a.sk_max, a.tile)
+    det.set_precision(a.precision)       # clones made below inherit it
+    pose.set_precision(a.precision)
     S = max(1, a.streams)
     dets = [det] + [det.clone() for _ in range(S - 1)]
     poses = [pose] + [pose.clone() for _ in range(S - 1)]
@@ -326,7 +338,8 @@ def main():
         out = {
             "metric": "frames/sec (640x480, 50-kp KPD)", "value": round(frames_total / el, 2), "unit": "frames/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(el / a.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if a.precision == "f32" else "f16 MFMA operands, f32 accumulate and activations",
             "data": "synthetic (seeded 640x480 BGR u8 frames resident in HBM; seeded random weights of the "
                     "reference architectures)",
             "config": {"workload": "BASELINE configs[1]: single-object frame, YOLOv3 416x416 (1 class) -> 1 crop "
@@ -350,7 +363,7 @@ def main():
         # sustains on the whole path, as opposed to one kernel running alone
         gf = out["roofline"]["all_conv"]["gflop_per_step"]
         agg = gf * a.steps * world / el / 1e3 / world
-        out["roofline"]["timed_region"] = {"achieved_per_gpu": round(agg, 2), "frac": round(agg / PEAK_FP32_MFMA_TFLOPS, 4),
+        out["roofline"]["timed_region"] = {"achieved_per_gpu": round(agg, 2), "frac": round(agg / out["roofline"]["peak"], 4),
                                            "unit": "TFLOP/s"}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.cpu_seconds, kp3d, cam_K)

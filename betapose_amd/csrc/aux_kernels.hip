@@ -523,6 +523,18 @@ void launch_resize_bicubic(const uint8_t* in, int batch, int H, int W, uint8_t* 
                        out_nhwc, out_u8, oh, t.vb, t.vk, t.ksize_v, swap_rb);
 }
 
+// ---- packed filters fp32 -> fp16 (RNE), once per weight store when the fp16-MFMA path is switched on
+__global__ void f32_to_f16_kernel(const float* __restrict__ in, _Float16* __restrict__ out, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (_Float16)in[i];
+}
+
+void launch_f32_to_f16(const float* in, unsigned short* out, long long n, hipStream_t s) {
+    const int threads = 256;
+    hipLaunchKernelGGL(f32_to_f16_kernel, dim3((unsigned)((n + threads - 1) / threads)), dim3(threads), 0, s, in,
+                       reinterpret_cast<_Float16*>(out), n);
+}
+
 // ---- placement probe: which XCD / CU every workgroup of a grid landed on (CU-mask experiments, tests)
 __global__ void probe_placement_kernel(int* out) {
     if (threadIdx.x == 0) {

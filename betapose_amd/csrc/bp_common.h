@@ -64,15 +64,21 @@ struct ConvParams {
     float* partial;        // [splits][tiles][BM*64] fragment-order slabs when splits > 1
     int* tickets;          // [tiles] arrival counters (zero between launches) when splits > 1
     int CoutPad;
+    const unsigned short* w16;   // fp16 copy of w (same [CoutPad][Kpad] packing) or null
+    int use_f16;           // 1: run the fp16-MFMA kernel when w16 is present and the layer is eligible
     unsigned long long* stamps;   // debug (tools/bench_conv.py --stamps): per-block s_memtime marks, null in production
 };
 
 // tile configuration ids for launch_conv
+// arithmetic of the matrix-core operands (accumulation and activations are always fp32)
+enum Precision : int { PREC_F32 = 0, PREC_F16 = 1 };
+
 enum ConvTile : int { TILE_64x64 = 0, TILE_128x64 = 1, TILE_32x64 = 2, TILE_64x32 = 3 };
 
 // when non-null, launch_conv brackets the implicit-GEMM kernel itself (not the split-K reduce) with these events
 struct ConvProfHook { hipEvent_t e0, e1; };
 extern thread_local ConvProfHook* g_conv_prof;
+bool conv_f16_eligible(const ConvParams& p);
 
 void launch_conv(const ConvParams& p, int tile, hipStream_t s);
 int conv_tiles(const ConvParams& p, int tile);   // blocks per K-slice
@@ -112,6 +118,7 @@ void launch_yolo_select(const float* pred, int N, int rows, int attrs, float con
 void launch_heatmap_argmax(const float* hm, int N, int C, int H, int W, float* out, hipStream_t s);
 
 // [batch][rec_floats] rows = sel[8] | pts[8] | kp[kp_floats]
+void launch_f32_to_f16(const float* in, unsigned short* out, long long n, hipStream_t s);
 void launch_probe_placement(int* d_out, int blocks, hipStream_t s);
 void launch_pack_records(const float* sel, const float* pts, const float* kp, float* out, int batch, int kp_floats,
                          int rec_floats, hipStream_t s);

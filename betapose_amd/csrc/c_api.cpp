@@ -60,6 +60,7 @@ struct bp_pipeline {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     hipStream_t cap_stream = nullptr;
+    unsigned ver_y = 0, ver_k = 0;   // engine plan versions the graph was captured with
     ~bp_pipeline() {
         if (exec) (void)hipGraphExecDestroy(exec);
         if (graph) (void)hipGraphDestroy(graph);
@@ -173,6 +174,7 @@ int bp_yolo_clone(const bp_yolo* y, bp_yolo** out) {
     std::unique_ptr<bp_yolo> c(new bp_yolo);
     c->device = y->device;
     c->net.reset(y->net->clone());
+    if (y->net->precision() != bp::PREC_F32) c->net->set_precision(y->net->precision());
     *out = c.release();
     return 0;
     BP_CATCH
@@ -243,6 +245,7 @@ int bp_kpd_clone(const bp_kpd* k, bp_kpd** out) {
     std::unique_ptr<bp_kpd> c(new bp_kpd);
     c->device = k->device;
     c->net.reset(k->net->clone());
+    if (k->net->precision() != bp::PREC_F32) c->net->set_precision(k->net->precision());
     *out = c.release();
     return 0;
     BP_CATCH
@@ -278,6 +281,18 @@ int bp_yolo_set_policy(bp_yolo* y, int t, int mc, int ms, int ft) {
     y->net->set_max_splits(ms);
     y->net->set_force_tile(ft);
     return 0;
+}
+int bp_yolo_set_precision(bp_yolo* y, int prec) {
+    BP_TRY
+    y->net->set_precision(prec);
+    return 0;
+    BP_CATCH
+}
+int bp_kpd_set_precision(bp_kpd* k, int prec) {
+    BP_TRY
+    k->net->set_precision(prec);
+    return 0;
+    BP_CATCH
 }
 int bp_kpd_set_policy(bp_kpd* k, int t, int mc, int ms, int ft) {
     k->net->set_splitk_policy(t, mc);
@@ -366,9 +381,14 @@ int bp_conv2d(const float* d_in, int N, int H, int W, int Cin, const float* h_w,
     bp::ConvWeights cw; cw.w = h_w; cw.bias = h_bias;
     net.add_conv("conv", in, out, cw, Cout, k, stride, pad, act, store_mode, d_res ? &res : nullptr, nullptr,
                  res_after_act, 1e-5f, OH, OW);
+    int t = tile;
+    if (t >= 16) {   // +16: fp16-MFMA operands
+        t -= 16;
+        net.set_precision(bp::PREC_F16);
+        BP_CHECK(net.ops_[0].conv.use_f16, "layer is not eligible for the fp16 path (needs Cin % 32 == 0)");
+    }
     bp::ConvParams p = net.ops_[0].conv;
     p.N = N; p.M = N * OH * OW;
-    int t = tile;
     if (t < 0) t = bp::TILE_64x64;
     int sp = splits;
     if (sp <= 0) {
@@ -521,7 +541,16 @@ int bp_pipeline_run(bp_pipeline* p, int use_graph, void* stream) {
         pipeline_enqueue(p, s);
         return 0;
     }
+    if (p->exec && (p->ver_y != p->y->net->plan_version() || p->ver_k != p->k->net->plan_version())) {
+        // launch policy / precision changed since the capture: the recorded kernels are stale
+        (void)hipGraphExecDestroy(p->exec);
+        (void)hipGraphDestroy(p->graph);
+        p->exec = nullptr;
+        p->graph = nullptr;
+    }
     if (!p->exec) {
+        p->ver_y = p->y->net->plan_version();
+        p->ver_k = p->k->net->plan_version();
         if (!p->cap_stream) BP_HIP(hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking));
         BP_HIP(hipStreamBeginCapture(p->cap_stream, hipStreamCaptureModeThreadLocal));
         try {

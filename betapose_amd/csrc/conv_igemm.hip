@@ -354,120 +354,183 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     __syncthreads();
     BP_STAMP(3);   // K loop done
 
-    // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    if (p.splits > 1) {
-        // ---- split-K: every slice parks its fp32 accumulators in a slab laid out in FRAGMENT order
-        // (slice, tile, wave, quad, lane) so each lane moves 16 B per instruction, fully coalesced; the LAST slice
-        // to arrive at the tile's ticket counter sums all slabs in slice order (deterministic, independent of
-        // arrival order) and runs the epilogue.  Hand-off without fences (cdna_hip_programming.md G16 "R1"):
-        // write-through (sc1) slab stores, every storing wave drains vmcnt, one relaxed agent-scope ticket, sc1
-        // loads by the reducer.
-        const int tiles = (int)gridDim.x / p.splits;
-        constexpr int TILE_FLOATS = TM * TN * 4096;
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            p.partial, 0, (int)((long long)p.splits * tiles * TILE_FLOATS * 4), 0x00020000);
-        const int my_off = ((split * tiles + tile_id) * TILE_FLOATS + wave * (TM * TN * 1024) + lane * 4) * 4;
+#include "conv_tail.inc"
+    if (p.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); BP_STAMP(4); }
+}
+
+// =====================================================================================================================
+// fp16-MFMA variant (BASELINE.json configs[2]: "fp16 MFMA conv path").  Same tiling, split-K hand-off and epilogue;
+// what changes is the operand precision of the matrix cores: activations stay fp32 in HBM and are rounded (RNE) to
+// fp16 when a chunk is parked in LDS, filters are pre-rounded fp16 [CoutPad][Kpad] (half the filter traffic), products
+// are accumulated in fp32 by v_mfma_f32_32x32x16_f16 (8 passes: 16x the fp32 MFMA rate), outputs are fp32.  The K loop
+// is then bound by L2->LDS staging (12 KB per 64x64x32 chunk), not by the MFMA pipe.
+// Fragment layout of the 32x32x16 form: lane l supplies row (l & 31), k = 8*(l>>5) .. 8*(l>>5)+7 (one 16-B LDS read).
+// =====================================================================================================================
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+static constexpr int LDH = 40;   // halfs per LDS row: 32 + 8 pad = 80 B, so 8 consecutive lanes' 16-B reads hit all 32 banks once
+
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvParams p) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int RA = BM / 32;          // fp32 A rows per thread (4 floats each)
+    constexpr int RBH = BN / 64;         // fp16 B rows per thread (8 halfs each)
+    constexpr int LDT = BN + 4;
+    constexpr int STAGE_HALFS = (BM + BN) * LDH;
+    constexpr int SMEM_FLOATS = (2 * STAGE_HALFS / 2 > BM * LDT) ? 2 * STAGE_HALFS / 2 : BM * LDT;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
+    _Float16* const sh = reinterpret_cast<_Float16*>(smem);
+    // stage s: A rows at sh + s*STAGE_HALFS, B rows right after the A rows
+#define BH_AS(s_) (sh + (s_) * STAGE_HALFS)
+#define BH_BS(s_) (sh + (s_) * STAGE_HALFS + BM * LDH)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n_tiles_n = p.CoutPad / BN;
+    const int split = (int)blockIdx.x % p.splits;
+    const int tile_id = (int)blockIdx.x / p.splits;
+    const int tile_n = tile_id % n_tiles_n;
+    const int tile_m = tile_id / n_tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int c_begin = split * p.chunks_per_split;
+    const int c_end = min(p.nchunks, c_begin + p.chunks_per_split);
+
+    const int lr = tid >> 3, c4 = tid & 7;       // A: row lr (+32i), floats c4*4..+3
+    const int br = tid >> 2, b8 = (tid & 3) * 8; // B: row br (+64i), halfs b8..+7
+    const int hw = p.OH * p.OW;
+
+    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.in), 0, (int)min((long long)p.N * p.H * p.W * p.in_ld * 4, (long long)OOB), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned short*>(p.w16), 0, p.CoutPad * p.Kpad * 2, 0x00020000);
+
+    unsigned a_base[RA];
+    unsigned long long a_mask[RA];
+    const float rcp_hw = 1.0f / (float)hw, rcp_ow = 1.0f / (float)p.OW;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    u32x4 v;
-                    v.x = __float_as_uint(acc[i][j][4 * q]);
-                    v.y = __float_as_uint(acc[i][j][4 * q + 1]);
-                    v.z = __float_as_uint(acc[i][j][4 * q + 2]);
-                    v.w = __float_as_uint(acc[i][j][4 * q + 3]);
-                    __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, my_off + (((i * TN + j) * 4 + q) * 256) * 4, 0, 16 /*sc1*/);
-                }
-        __shared__ int s_last;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            const int ticket = __hip_atomic_fetch_add(&p.tickets[tile_id], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_last = ticket == p.splits - 1;
-            if (s_last) __hip_atomic_store(&p.tickets[tile_id], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+    for (int i = 0; i < RA; ++i) {
+        const int m = m0 + lr + 32 * i;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int b = fast_div(mm, hw, rcp_hw);
+        const int rem = mm - b * hw;
+        const int oy = fast_div(rem, p.OW, rcp_ow);
+        const int ox = rem - oy * p.OW;
+        const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+        a_base[i] = (unsigned)((((b * p.H + iy0) * p.W + ix0) * p.in_ld + c4 * 4) * 4);
+        const int kx_lo = max(0, -ix0), kx_hi = min(p.ksize, p.W - ix0);
+        const int ky_lo = max(0, -iy0), ky_hi = min(p.ksize, p.H - iy0);
+        unsigned long long mask = 0;
+        if (ok && kx_hi > kx_lo) {
+            const unsigned long long rowbits = ((1ull << kx_hi) - 1ull) & ~((1ull << kx_lo) - 1ull);
+            for (int ky = ky_lo; ky < ky_hi; ++ky) mask |= rowbits << (ky * p.ksize);
         }
-        __syncthreads();
-        if (!s_last) return;
-        const int base_off = (tile_id * TILE_FLOATS + wave * (TM * TN * 1024) + lane * 4) * 4;
-        const int slice_stride = tiles * TILE_FLOATS * 4;
+        a_mask[i] = mask;
+    }
+    unsigned b_base[RBH];
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-                for (int sidx = 0; sidx < p.splits; ++sidx) {   // slice order: deterministic sum
-                    u32x4 t[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        t[q] = __builtin_amdgcn_raw_buffer_load_b128(
-                            rsrc, base_off + (((i * TN + j) * 4 + q) * 256) * 4 + sidx * slice_stride, 0, 16 /*sc1*/);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        acc[i][j][4 * q] += __uint_as_float(t[q].x);
-                        acc[i][j][4 * q + 1] += __uint_as_float(t[q].y);
-                        acc[i][j][4 * q + 2] += __uint_as_float(t[q].z);
-                        acc[i][j][4 * q + 3] += __uint_as_float(t[q].w);
-                    }
-                }
-            }
+    for (int i = 0; i < RBH; ++i) b_base[i] = (unsigned)(((n0 + br + 64 * i) * p.Kpad + b8) * 2);
+
+    // wave-uniform walk over K, as in the fp32 kernel
+    const int cpt = p.Cin >> 5;
+    int w_c = c_begin;
+    int w_tap = c_begin / cpt;
+    int w_ci = (c_begin - w_tap * cpt) << 5;
+    int w_ky = w_tap / p.ksize;
+    int w_kx = w_tap - w_ky * p.ksize;
+    unsigned va[RA];
+    int sb = 0;
+#define BH_ADDR()                                                                                      \
+    {                                                                                                  \
+        const unsigned delta = (unsigned)(((w_ky * p.W + w_kx) * p.in_ld + w_ci) * 4);                \
+        _Pragma("unroll") for (int i = 0; i < RA; ++i) {                                               \
+            const bool ok = (a_mask[i] >> w_tap) & 1ull;                                               \
+            va[i] = ok ? a_base[i] + delta : OOB;                                                      \
+        }                                                                                              \
+        sb = w_c * (BK * 2);                                                                           \
+        if (w_c + 1 < c_end) {                                                                         \
+            ++w_c;                                                                                     \
+            w_ci += 32;                                                                                \
+            if (w_ci == p.Cin) {                                                                       \
+                w_ci = 0;                                                                              \
+                ++w_tap;                                                                               \
+                if (++w_kx == p.ksize) { w_kx = 0; ++w_ky; }                                           \
+            }                                                                                          \
+        }                                                                                              \
+    }
+#define BH_LOAD(ra_, rb_)                                                                              \
+    {                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < RA; ++i) ra_[i] = buf_load4(rsrcA, va[i], 0);            \
+        _Pragma("unroll") for (int i = 0; i < RBH; ++i)                                                \
+            rb_[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrcB, (int)b_base[i], sb, 0);              \
+    }
+#define BH_STORE(s_, ra_, rb_)                                                                         \
+    {                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < RA; ++i)                                                 \
+            *reinterpret_cast<f16x4*>(BH_AS(s_) + (lr + 32 * i) * LDH + c4 * 4) =                      \
+                __builtin_convertvector(ra_[i], f16x4);                                                \
+        _Pragma("unroll") for (int i = 0; i < RBH; ++i)                                                \
+            *reinterpret_cast<u32x4*>(BH_BS(s_) + (br + 64 * i) * LDH + b8) = rb_[i];                  \
     }
 
-    // ---- epilogue.  Fast path (plain NHWC store, 16-B alignable): the tile goes through LDS so every lane stores
-    // 16 contiguous bytes (a wave-instruction covers 4 full 256-B rows).  The direct form -- 16 dword stores per
-    // lane, 128-B segments -- was store-issue bound: s_memtime stamps showed 4-8k cycles per block in the epilogue,
-    // as much as 3-6 K-chunks of MFMA work.
-    const bool vec_ok = p.store_mode == ST_NHWC && p.res_scale == nullptr && (p.out_ld & 3) == 0 && (p.Cout & 3) == 0 &&
-                        (p.res == nullptr || (p.res_ld & 3) == 0);
-    if (vec_ok) {
+    f32x16 acc[TM][TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    smem[row * LDT + wn * (BN / 2) + j * 32 + (lane & 31)] = acc[i][j][r];
-                }
-        __syncthreads();
-        constexpr int TPR = BN / 4;              // threads per tile row
-        constexpr int ROWS_PER_PASS = 256 / TPR;
-        const int n4 = (tid % TPR) * 4;
-        const int n = n0 + n4;
-        if (n < p.Cout) {
-            const f32x4 bias4 = *reinterpret_cast<const f32x4*>(p.bias + n);
-#pragma unroll
-            for (int pass = 0; pass < BM / ROWS_PER_PASS; ++pass) {
-                const int row = pass * ROWS_PER_PASS + tid / TPR;
-                const int m = m0 + row;
-                if (m < p.M) {
-                    f32x4 v = *reinterpret_cast<const f32x4*>(&smem[row * LDT + n4]);
-                    f32x4 r4 = {0.f, 0.f, 0.f, 0.f};
-                    if (p.res) r4 = *reinterpret_cast<const f32x4*>(p.res + m * p.res_ld + n);
-                    v += bias4;
-                    if (!p.res_after_act) v += r4;
-                    v.x = apply_act(v.x, p.act); v.y = apply_act(v.y, p.act);
-                    v.z = apply_act(v.z, p.act); v.w = apply_act(v.w, p.act);
-                    if (p.res_after_act) v += r4;
-                    *reinterpret_cast<f32x4*>(p.out + m * p.out_ld + n) = v;
-                }
-            }
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
-                float v[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r];
-                epilogue_tile(p, v, m0 + wm * (BM / 2) + i * 32 + 4 * (lane >> 5), n);
-            }
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int frag_off = (lane & 31) * LDH + (lane >> 5) * 8;
+    const int a_off = wm * (BM / 2) * LDH + frag_off;
+    const int b_off = wn * (BN / 2) * LDH + frag_off;
+
+    f32x4 ra0[RA], ra1[RA];
+    u32x4 rb0[RBH], rb1[RBH];
+    // One chunk: LDS[cur_] holds chunk c; (rna_, rnb_) hold chunk c+1 (in flight since the previous phase);
+    // (rfa_, rfb_) receive chunk c+2, whose addresses were computed in the previous phase.
+#define BH_PHASE(cur_, rna_, rnb_, rfa_, rfb_)                                                         \
+    {                                                                                                  \
+        f16x8 fa[TM][2], fb[TN][2];                                                                    \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                             \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[i][ks] =                                 \
+                *reinterpret_cast<const f16x8*>(BH_AS(cur_) + a_off + i * 32 * LDH + ks * 16);         \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[j][ks] =                                 \
+                *reinterpret_cast<const f16x8*>(BH_BS(cur_) + b_off + j * 32 * LDH + ks * 16);         \
+        }                                                                                              \
+        BH_LOAD(rfa_, rfb_);                                                                           \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                               \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][ks], fb[j][ks], acc[i][j], 0, 0, 0); \
+        BH_STORE((cur_) ^ 1, rna_, rnb_);                                                              \
+        BH_ADDR();                                                                                     \
+        __syncthreads();                                                                               \
     }
-    if (p.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); BP_STAMP(4); }
+
+    if (c_begin < c_end) {
+        BH_ADDR(); BH_LOAD(ra0, rb0);
+        BH_ADDR(); BH_LOAD(ra1, rb1);
+        BH_ADDR();
+        BH_STORE(0, ra0, rb0);
+        __syncthreads();
+        const int nch = c_end - c_begin;
+        for (int it = 0; it < (nch >> 1); ++it) {
+            BH_PHASE(0, ra1, rb1, ra0, rb0);
+            BH_PHASE(1, ra0, rb0, ra1, rb1);
+        }
+        if (nch & 1) BH_PHASE(0, ra1, rb1, ra0, rb0);
+    }
+    __syncthreads();
+
+#include "conv_tail.inc"
+#undef BH_AS
+#undef BH_BS
+#undef BH_ADDR
+#undef BH_LOAD
+#undef BH_STORE
+#undef BH_PHASE
 }
 
 thread_local ConvProfHook* g_conv_prof = nullptr;
@@ -496,6 +559,20 @@ static void launch_t(const ConvParams& p, hipStream_t s) {
     }
 }
 
+template <int TM, int TN>
+static void launch_f16_t(const ConvParams& p, hipStream_t s) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    dim3 grid(((p.M + BM - 1) / BM) * (p.CoutPad / BN) * p.splits);
+    if (g_conv_prof)
+        hipExtLaunchKernelGGL((conv_igemm_f16_kernel<TM, TN>), grid, dim3(256), 0, s, g_conv_prof->e0, g_conv_prof->e1, 0, p);
+    else
+        hipLaunchKernelGGL((conv_igemm_f16_kernel<TM, TN>), grid, dim3(256), 0, s, p);
+}
+
+bool conv_f16_eligible(const ConvParams& p) {
+    return p.w16 != nullptr && (p.Cin % 32 == 0) && (p.in_ld % 4 == 0) && p.ksize <= 8;
+}
+
 int conv_tiles(const ConvParams& p, int tile) {
     const int bm = conv_tile_bm(tile);
     return ((p.M + bm - 1) / bm) * (p.CoutPad / 64);
@@ -506,9 +583,16 @@ void launch_conv(const ConvParams& p, int tile, hipStream_t s) {
     BP_CHECK(p.Kpad % BK == 0 && p.nchunks == p.Kpad / BK, "Kpad");
     BP_CHECK(p.splits >= 1 && (p.splits == 1 || (p.partial != nullptr && p.tickets != nullptr)), "split-K workspace");
     BP_CHECK((long long)p.N * p.H * p.W * p.in_ld * 4 < (long long)OOB, "activation tensor too large for 32-bit offsets");
-    switch (tile) {
-        case TILE_128x64: launch_t<2, 1>(p, s); break;
-        default: launch_t<1, 1>(p, s); break;
+    if (p.use_f16 && conv_f16_eligible(p)) {
+        switch (tile) {
+            case TILE_128x64: launch_f16_t<2, 1>(p, s); break;
+            default: launch_f16_t<1, 1>(p, s); break;
+        }
+    } else {
+        switch (tile) {
+            case TILE_128x64: launch_t<2, 1>(p, s); break;
+            default: launch_t<1, 1>(p, s); break;
+        }
     }
     BP_HIP(hipGetLastError());
 }

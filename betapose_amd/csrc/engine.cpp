@@ -91,8 +91,52 @@ static const SplitEntry kSplitTable[] = {
     {43264, 64, 9, 1}
 };
 
+// fp16-MFMA kernel: same procedure (tools/tune_conv.py --f16, profiles/r01_splitk_tuning_f16.txt)
+static const SplitEntry kSplitTableF16[] = {
+    {    80,   512,   64,  5},
+    {    80,   512,  144,  6},
+    {    80,  2048,   16,  1},
+    {    80,  2048,   32,  3},
+    {   169,    64,   32,  4},
+    {   169,   256,   16,  1},
+    {   169,   512,   32,  3},
+    {   169,  1024,  144,  5},
+    {   320,   256,   32,  3},
+    {   320,   256,   72,  5},
+    {   320,   512,   32,  3},
+    {   320,  1024,    8,  1},
+    {   320,  1024,   16,  1},
+    {   320,  1024,  144,  5},
+    {   676,    64,   16,  1},
+    {   676,   128,    8,  1},
+    {   676,   256,   16,  1},
+    {   676,   256,   24,  1},
+    {   676,   512,   72,  5},
+    {  1280,   128,   16,  1},
+    {  1280,   128,   36,  3},
+    {  1280,   256,   16,  1},
+    {  1280,   512,    4,  1},
+    {  1280,   512,    8,  1},
+    {  1280,   512,   72,  3},
+    {  2704,    64,    8,  1},
+    {  2704,   128,    8,  1},
+    {  2704,   128,   12,  1},
+    {  2704,   256,   36,  1},
+    {  5120,    64,    2,  1},
+    {  5120,    64,    8,  1},
+    {  5120,    64,   18,  1},
+    {  5120,    64,   36,  3},
+    {  5120,   128,    8,  1},
+    {  5120,   256,    2,  1},
+    { 10816,    64,    4,  1},
+    { 10816,   128,   18,  1},
+    { 43264,    64,    2,  1},
+    { 43264,    64,    9,  1},
+};
+
 static void choose_launch(const Op& op, int batch, int force_tile, int sk_target, int sk_min_chunks, int sk_max,
                           int* tile, int* splits, int* cps) {
+    const bool f16 = op.conv.use_f16 != 0;
     const ConvParams& c = op.conv;
     const long long M = (long long)batch * c.OH * c.OW;
     const int nt = c.CoutPad / 64;
@@ -102,9 +146,17 @@ static void choose_launch(const Op& op, int batch, int force_tile, int sk_target
     const long long blocks = ((M + bm - 1) / bm) * nt;
     int s = 1;
     while (blocks * s < sk_target && c.nchunks / (s + 1) >= sk_min_chunks && s < sk_max) ++s;
-    if (t == TILE_64x64 && sk_target == 512 && sk_min_chunks == 4 && sk_max == 8)   // default policy: measured table
-        for (const SplitEntry& e : kSplitTable)
-            if (e.M == (int)M && e.CoutPad == c.CoutPad && e.nchunks == c.nchunks) { s = e.splits; break; }
+    if (t == TILE_64x64 && sk_target == 512 && sk_min_chunks == 4 && sk_max == 8) {   // default policy: measured tables
+        if (f16) {
+            s = 1;   // the fp16 K loop is ~5x shorter: unlisted shapes (other batch sizes) run unsplit unless tiny
+            while (blocks * s < 128 && c.nchunks / (s + 1) >= 8 && s < sk_max) ++s;
+            for (const SplitEntry& e : kSplitTableF16)
+                if (e.M == (int)M && e.CoutPad == c.CoutPad && e.nchunks == c.nchunks) { s = e.splits; break; }
+        } else {
+            for (const SplitEntry& e : kSplitTable)
+                if (e.M == (int)M && e.CoutPad == c.CoutPad && e.nchunks == c.nchunks) { s = e.splits; break; }
+        }
+    }
     int per = (c.nchunks + s - 1) / s;
     s = (c.nchunks + per - 1) / per;
     *tile = t; *splits = s; *cps = per;
@@ -188,6 +240,36 @@ void Net::finalize() {
     tickets_count_ = tiles;
     tickets_ = (int*)arena_.alloc_bytes(tiles * sizeof(int));
     BP_HIP(hipMemset(tickets_, 0, tiles * sizeof(int)));
+}
+
+void Net::set_precision(int prec) {
+    BP_CHECK(prec == PREC_F32 || prec == PREC_F16, "unknown precision");
+    if (prec == PREC_F16) {
+        std::lock_guard<std::mutex> lk(store_->f16_mutex);
+        bool made = false;
+        for (Op& op : ops_) {
+            if (op.type != OP_CONV) continue;
+            ConvParams& c = op.conv;
+            if (!((c.Cin % 32 == 0) && (c.in_ld % 4 == 0) && c.ksize <= 8)) continue;   // stems (Cin = 3) stay fp32
+            auto it = store_->f16.find(c.w);
+            if (it == store_->f16.end()) {
+                const size_t n = (size_t)c.CoutPad * c.Kpad;
+                unsigned short* d = (unsigned short*)store_->arena.alloc_bytes(n * sizeof(unsigned short));
+                launch_f32_to_f16(c.w, d, (long long)n, nullptr);
+                it = store_->f16.emplace(c.w, d).first;
+                made = true;
+            }
+            c.w16 = it->second;
+        }
+        if (made) {
+            BP_HIP(hipGetLastError());
+            BP_HIP(hipDeviceSynchronize());
+        }
+    }
+    for (Op& op : ops_)
+        if (op.type == OP_CONV) op.conv.use_f16 = (prec == PREC_F16 && op.conv.w16 != nullptr) ? 1 : 0;
+    precision_ = prec;
+    ++plan_version_;
 }
 
 void Net::run_op(const Op& op, int batch, hipStream_t s) {
@@ -274,6 +356,7 @@ int Net::profile(int batch, int iters, float* ms, int* info, int cap, hipStream_
             if (conv) {
                 choose_launch(ops_[i], batch, force_tile_, sk_target_, sk_min_chunks_, sk_max_splits_, &tile, &splits, &cps);
                 vec = (ops_[i].conv.Cin % 32 == 0) && (ops_[i].conv.in_ld % 4 == 0);
+                if (ops_[i].conv.use_f16 && conv_f16_eligible(ops_[i].conv)) vec = 2;   // fp16-MFMA kernel
             }
             info[4 * i] = conv; info[4 * i + 1] = tile; info[4 * i + 2] = vec; info[4 * i + 3] = splits;
         }

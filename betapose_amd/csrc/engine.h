@@ -2,6 +2,7 @@
 #pragma once
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -58,6 +59,8 @@ struct ConvWeights {   // one conv as it arrives in the stream (un-folded)
 struct WeightStore {
     Arena arena;
     std::vector<float*> ptrs;
+    std::map<const float*, unsigned short*> f16;   // fp16 copies of packed filters, made on first use
+    std::mutex f16_mutex;
 };
 
 class Net {
@@ -69,7 +72,8 @@ public:
     int max_batch() const { return max_batch_; }
     void run_ops(int batch, hipStream_t s);
     void run_op(const Op& op, int batch, hipStream_t s);
-    // eager profiling pass: mean device ms per op; info[i] = {is_conv, tile, vec, splits}
+    // eager profiling pass: mean device ms per op; info[i] = {is_conv, tile, kernel (0 scalar-gather fp32, 1 vector
+    // fp32, 2 fp16-MFMA), splits}
     int profile(int batch, int iters, float* ms, int* info, int cap, hipStream_t s);
     size_t device_bytes() const { return arena_.total_bytes(); }
     const std::vector<Op>& ops() const { return ops_; }
@@ -78,9 +82,13 @@ public:
     const char* tap_name(int i) const { return tap_names_[i].c_str(); }
     void tap_shape(int i, int* C, int* H, int* W) const { *C = taps_[i].C; *H = taps_[i].H; *W = taps_[i].W; }
     void tap_copy(int i, int batch, float* d_out_nchw, hipStream_t s) const;
-    void set_splitk_policy(int target_blocks, int min_chunks) { sk_target_ = target_blocks; sk_min_chunks_ = min_chunks; }
-    void set_max_splits(int m) { sk_max_splits_ = m; }
-    void set_force_tile(int t) { force_tile_ = t; }
+    void set_splitk_policy(int target_blocks, int min_chunks) { sk_target_ = target_blocks; sk_min_chunks_ = min_chunks; ++plan_version_; }
+    void set_max_splits(int m) { sk_max_splits_ = m; ++plan_version_; }
+    void set_force_tile(int t) { force_tile_ = t; ++plan_version_; }
+    // PREC_F16: eligible convs (Cin % 32 == 0) run on the fp16 MFMA with fp16 copies of their filters
+    void set_precision(int prec);
+    int precision() const { return precision_; }
+    unsigned plan_version() const { return plan_version_; }
 
 protected:
     // emit a fused conv; returns index into ops_
@@ -106,6 +114,8 @@ protected:
     size_t tickets_count_ = 0;
     int sk_target_ = 512, sk_min_chunks_ = 4, sk_max_splits_ = 8;
     int force_tile_ = -1;
+    int precision_ = PREC_F32;
+    unsigned plan_version_ = 0;   // bumped whenever launches would change (captured graphs must be rebuilt)
 };
 
 class YoloNet : public Net {

@@ -141,6 +141,13 @@ class FastPoseHIP:
         self._ensure()
         _lib.lib().bp_kpd_set_policy(self._h, sk_target_blocks, sk_min_chunks, sk_max_splits, force_tile)
 
+    def set_precision(self, precision: str = "f32"):
+        """'f32' (default: fp32 MFMA, the parity configuration) or 'f16' (fp16 MFMA operands, fp32 accumulate)."""
+        self._ensure()
+        _lib.check(_lib.lib().bp_kpd_set_precision(self._h, {"f32": 0, "f16": 1}[precision]))
+        self._precision = precision
+        return self
+
     def clone(self):
         """Second engine over the same device filters (own activations): one per concurrent stream."""
         import copy

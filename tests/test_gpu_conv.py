@@ -117,3 +117,37 @@ def test_conv_full_size_layer_property(cuda):
     # and a spot check of 64 outputs against the definition
     ref = F.conv2d(x1.cpu().permute(0, 3, 1, 2), w, padding=1)
     _check(y1.cpu().permute(0, 3, 1, 2)[:, ::37, ::13, ::11], ref[:, ::37, ::13, ::11])
+
+
+# ---- fp16-MFMA variant (BASELINE configs[2]): operands rounded to fp16 (RNE) on the way into LDS / at weight upload,
+# fp32 accumulation and fp32 outputs.  Against a torch conv on the SAME rounded operands only the accumulation order
+# differs, so the fp32 tolerance applies; against the unrounded fp32 conv the distance is the fp16 rounding (~1e-3).
+F16_CASES = [c for c in CASES if c[3] % 32 == 0]
+
+
+@pytest.mark.parametrize("case", F16_CASES)
+@pytest.mark.parametrize("tile", ["64x64_f16", "128x64_f16"])
+@pytest.mark.parametrize("splits", [1, 3])
+def test_conv_f16_operands(cuda, case, tile, splits):
+    N, H, W, Cin, Cout, k, st, pad, act = case
+    g = torch.Generator().manual_seed(300 + CASES.index(case))
+    x = torch.randn(N, H, W, Cin, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g)
+    res = torch.randn(N, (H + 2 * pad - k) // st + 1, (W + 2 * pad - k) // st + 1, Cout, generator=g)
+    ref16 = _ref(x.half().float(), w.half().float(), b, st, pad, act, res, False)
+    ref32 = _ref(x, w, b, st, pad, act, res, False)
+    if splits > 1 and Cin * k * k // 32 < 2 * splits:
+        pytest.skip("too few K-chunks to split")
+    out = ops.conv2d_nhwc(x.to(cuda), w, b, stride=st, pad=pad, act=act, res=res.to(cuda), tile=tile, splits=splits)
+    out = out.cpu().permute(0, 3, 1, 2)
+    _check(out, ref16)                      # same operands: accumulation order only
+    assert float((out - ref32).abs().max()) < 2e-2 and float((out - ref32).abs().max()) > 1e-6   # really fp16 operands
+
+
+def test_conv_f16_rejects_ineligible_layer(cuda):
+    from betapose_amd import _lib
+    x = torch.randn(1, 16, 16, 3)
+    w = torch.randn(8, 3, 3, 3)
+    with pytest.raises(_lib.BetaposeHipError, match="not eligible"):
+        ops.conv2d_nhwc(x.to(cuda), w, None, stride=1, pad=1, tile="64x64_f16")

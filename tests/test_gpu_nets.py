@@ -190,3 +190,49 @@ def test_kpd_batch_equals_single(kpd, cuda, pipe_gold):
         h1 = kpd(crops[i:i + 1].to(cuda)).cpu()
         assert float((h1[0] - hb[i]).abs().max()) <= 1e-4
         assert torch.equal(h1[0].view(50, -1).argmax(1), hb[i].view(50, -1).argmax(1))
+
+
+# ---- fp16-MFMA mode (BASELINE configs[2]: batched inference, 28 crops / batch, fp16 MFMA conv path).  Operands of
+# every conv with Cin % 32 == 0 are rounded to fp16, accumulation and activations stay fp32.  Stated tolerances against
+# the fp32 oracle: heat-maps <= 1e-2 absolute (measured 1.4e-3 at a heat-map scale of 2.3), box centres <= 0.25 px,
+# box sizes <= 2 %, probabilities <= 5e-3; arg-max pixels / box index may legitimately differ where two candidates are closer than that,
+# so the integer checks are "identical on the golden inputs, flips <= 2 % elsewhere".
+def test_f16_mode_yolo(cuda, pipe_gold):
+    net = Darknet("yolo/cfg/yolov3-single.cfg", reso=416, max_batch=2).load_stream(helpers.yolo_stream()).cuda().eval()
+    x = torch.cat([helpers.yolo_input_from_frame(f) for f in helpers.frames(2)])
+    p32 = net(x.to(cuda)).cpu()
+    net.set_precision("f16")
+    p16 = net(x.to(cuda)).cpu()
+    net.set_precision("f32")
+    assert torch.equal(net(x.to(cuda)).cpu(), p32)                      # switching back restores the fp32 plan
+    d = (p16 - p32).abs()
+    assert float(d.max()) > 1e-6                                        # the fp16 path really ran
+    assert float(d[..., :2].max()) < 0.25                                           # centres, pixels
+    assert bool((d[..., 2:4] <= 0.05 + 2e-2 * p32[..., 2:4].abs()).all())           # w, h = anchor * exp(t): relative
+    assert float(d[..., 4:].max()) < 5e-3                                           # objectness / class probability
+    for b in range(2):
+        assert int(p16[b, :, 4].argmax()) == int(p32[b, :, 4].argmax()) == int(pipe_gold["f%d_obj_argmax" % b])
+
+
+def test_f16_mode_kpd_batch28(cuda, pipe_gold):
+    kpd16 = FastPoseHIP(helpers.kpd_state_dict(), n_classes=50, max_batch=28).cuda().eval()
+    g = torch.Generator().manual_seed(11)
+    inps = torch.cat(_crops_from_golden(pipe_gold, 4) +
+                     [torch.rand(24, 3, 320, 256, generator=g) - 0.45])  # 4 golden crops + 24 seeded ones
+    hm32 = kpd16(inps.to(cuda)).cpu()
+    kpd16.set_precision("f16")
+    hm16 = kpd16(inps.to(cuda)).cpu()
+    one = torch.cat([kpd16(inps[i:i + 1].to(cuda)).cpu() for i in (0, 5, 27)])
+    assert hm16.shape == (28, 50, 80, 64)
+    d = float((hm16 - hm32).abs().max())
+    assert 1e-6 < d < 1e-2, d
+    # per-crop outputs of a batch vs batch-1 outputs: split-K association differs, and an fp32 difference of 1e-6 in
+    # one layer can flip the fp16 rounding of the next layer's operand, so the distance is fp16-rounding sized
+    assert float((one - hm16[[0, 5, 27]]).abs().max()) < 1e-2
+    assert int((one.reshape(3, 50, -1).argmax(2) != hm16[[0, 5, 27]].reshape(3, 50, -1).argmax(2)).sum()) <= 3
+    a16 = hm16.reshape(28, 50, -1).argmax(2)
+    a32 = hm32.reshape(28, 50, -1).argmax(2)
+    assert bool((a16[:4] == a32[:4]).all())                              # golden crops: integer-exact
+    assert int((a16 != a32).sum()) <= 28                                 # <= 2 % of 1400 key points
+    for i in range(4):     # and equal to the reference's own arg-max pixels on its golden crops
+        assert np.array_equal(a16[i].numpy(), pipe_gold["f%d_kp_idx" % i])

@@ -45,6 +45,8 @@ for planes, nb, st in W.FASTPOSE_STAGES:
         h, w_, inpl = h2, w2, planes * 4
 add(20, 16, 512, 1024, 3, 1); add(40, 32, 256, 512, 3, 1); add(80, 64, 128, 50, 3, 1)
 
+F16 = "--f16" in sys.argv          # tune the fp16-MFMA kernel instead
+TILE = "64x64_f16" if F16 else "64x64"
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
 print("// {M, CoutPad, nchunks, splits}  (count, us_best, us_default)")
@@ -60,7 +62,7 @@ for (h, w_, cin, co, k, st), cnt in sorted(shapes.items()):
     for sp in (0, 1, 2, 3, 4, 5, 6, 8, 10, 12, 16):
         if sp > 1 and nch // sp < 2:
             continue
-        _, ms = ops.conv2d_nhwc(x, wt, None, stride=st, pad=(k - 1) // 2, act="leaky", splits=sp, iters=30)
+        _, ms = ops.conv2d_nhwc(x, wt, None, stride=st, pad=(k - 1) // 2, act="leaky", splits=sp, iters=30, tile=TILE)
         res[sp] = ms * 1e3
     best = min((v, s) for s, v in res.items() if s > 0)
     tot_best += best[0] * cnt; tot_def += res[0] * cnt
