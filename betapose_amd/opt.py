@@ -39,6 +39,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument('--synthetic', type=int, default=0, help='run on N seeded synthetic frames / weights')
     p.add_argument('--synth_weights', default=False, action='store_true',
                    help='seeded synthetic weights with real frames / ground truth (plumbing runs without checkpoints)')
+    p.add_argument('--precision', choices=['f32', 'f16'], default='f32',
+                   help='matrix-core operand precision (f16: fp16 MFMA operands, fp32 accumulate; see DESIGN.md)')
     p.add_argument('--streams', type=int, default=4, help='--fused: frames in flight (HIP streams / engine clones)')
     p.add_argument('--load_threads', type=int, default=8, help='--fused: PNG decode threads')
     p.add_argument('--sixd_base', default='/media/data_2/SIXD/hinterstoisser')

@@ -116,6 +116,8 @@ def main():
     det = Darknet("yolo/cfg/yolov3-single.cfg", reso=int(args.inp_dim), max_batch=max(1, args.detbatch), device=local)
     det.load_stream(ys).cuda()
     pose_model = FastPoseHIP.from_stream(ks, n_classes=args.nClasses, max_batch=1, device=local).cuda()
+    det.set_precision(args.precision)
+    pose_model.set_precision(args.precision)
 
     t0 = time.time()
     if args.fused:

@@ -92,3 +92,28 @@ def test_evaluate_dataset_layout_closed_loop(tmp_path, cuda, occlusion):
     nums = dict(re.findall(r"(Mean add accuracy|2d reprojection accuracy|Mean IoU) for seq \d+ is: ([\d.nan]+)", r.stdout))
     assert nums == {"Mean add accuracy": "1.000", "2d reprojection accuracy": "1.000", "Mean IoU": "1.000"}, r.stdout
     assert len(json.loads(open(out / "Betapose-results.json").read())) == 3
+
+
+def test_evaluate_f16_precision_close_to_reference_json(tmp_path):
+    """--precision f16 end to end: same frames detected; fp16 operand rounding moves the box by a fraction of a pixel
+    (re-sampling the crop) and heat-map values by ~1e-3, so a key point whose two best pixels are closer than that
+    flips.  The seeded random-weight KPD produces nearly flat heat-maps (best-vs-second margins down to 3.6e-4 at a
+    scale of 2.3, tests/golden), the worst case for this: measured 20 of 200 key points move; with the crop held
+    fixed none does (tests/test_gpu_nets.py).  Stated bound here: >= 85 % of the key points within 1.5 px, scores
+    within 5e-2 for those (the sub-pixel box shift re-samples the crop, which moves heat-map values more than the
+    rounding itself)."""
+    out = tmp_path / "out"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "evaluate.py"), "--synthetic", "4", "--outdir", str(out),
+                        "--fused", "--precision", "f16"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = json.loads(open(out / "Betapose-results.json").read())
+    ref = json.loads(str(helpers.golden("pipeline.npz")["json_text"]))
+    assert [g["image_id"] for g in got] == [r_["image_id"] for r_ in ref]
+    far = total = 0
+    for g, r_ in zip(got, ref):
+        kg, kr = np.array(g["keypoints"]).reshape(50, 3), np.array(r_["keypoints"]).reshape(50, 3)
+        near = np.abs(kg[:, :2] - kr[:, :2]).max(axis=1) < 1.5
+        far += int((~near).sum())
+        total += 50
+        assert np.abs(kg[near, 2] - kr[near, 2]).max() < 5e-2
+    assert far <= total * 15 // 100, (far, total)
