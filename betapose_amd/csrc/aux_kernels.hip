@@ -181,43 +181,76 @@ void launch_avgpool(const float* in, int in_ld, float* out, int N, int HW, int C
     hipLaunchKernelGGL(avgpool_partial_kernel, dim3((C + 63) / 64, P, N), dim3(256), 0, s, in, in_ld, out, HW, C, P);
 }
 
-// one wavefront per output neuron; float4 weight stream (pure HBM-bound GEMV)
-// in_parts > 1: in is [N][in_parts][Cin] partial sums (see avgpool_partial_kernel), scaled by in_scale
+// GEMV of the SE blocks: pure HBM-bound weight stream (C = 2048: 16.8 MB per layer).  A block of 4 waves produces
+// FC_PER_BLOCK neurons: the input vector (the slice sums of avgpool_partial_kernel, reduced and scaled here) is staged
+// once in LDS, then every wave streams its rows with 16-B loads, several in flight per lane.  The per-lane summation
+// order (i = lane, lane+64, ...) and the shuffle tree are fixed, so results do not depend on the launch shape.
+// in_parts > 1: in is [N][in_parts][Cin] partial sums, scaled by in_scale
+static constexpr int FC_PER_BLOCK = 8;
 __global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                   const float* __restrict__ bias, float* __restrict__ out, int Cin,
                                                   int Cout, int act, int in_parts, float in_scale) {
+    extern __shared__ float4 xs[];   // Cin / 4 (+ 3 more copies while the slice sums are being combined)
     const int lane = threadIdx.x & 63;
-    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wave = threadIdx.x >> 6;
     const int n = blockIdx.y;
-    if (o >= Cout) return;
-    const float4* wr = reinterpret_cast<const float4*>(w + (long long)o * Cin);
+    const int c4 = Cin >> 2;
     const float4* xr = reinterpret_cast<const float4*>(in + (long long)n * in_parts * Cin);
-    float s = 0.f;
-    for (int i = lane; i < (Cin >> 2); i += 64) {
-        const float4 a = wr[i];
-        float4 b = xr[i];
-        if (in_parts > 1) {
-            for (int q = 1; q < in_parts; ++q) {
-                const float4 t = xr[(long long)q * (Cin >> 2) + i];
+    // stage the input vector.  With slice sums (in_parts > 1) and a short vector the 256 threads split the slices
+    // G ways (G = 256 / c4, at most 4), so no thread walks all of them serially; the G partial vectors are then
+    // added in a fixed order
+    const int G = (in_parts > 1 && c4 <= 128) ? (c4 <= 64 ? 4 : 2) : 1;
+    for (int i0 = 0; i0 < c4; i0 += 256 / G) {
+        const int i = i0 + (int)threadIdx.x % (256 / G), g = (int)threadIdx.x / (256 / G);
+        if (i < c4) {
+            float4 b = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+            for (int q = g; q < in_parts; q += G) {
+                const float4 t = xr[(long long)q * c4 + i];
                 b.x += t.x; b.y += t.y; b.z += t.z; b.w += t.w;
             }
-            b.x *= in_scale; b.y *= in_scale; b.z *= in_scale; b.w *= in_scale;
+            xs[g * c4 + i] = b;
         }
-        s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
     }
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-    if (lane == 0) {
-        s += bias[o];
-        if (act == 2) s = s > 0.f ? s : 0.f;
-        else if (act == 3) s = 1.f / (1.f + __expf(-s));
-        out[(long long)n * Cout + o] = s;
+    __syncthreads();
+    if (G > 1 || in_parts > 1) {
+        for (int i = threadIdx.x; i < c4; i += 256) {
+            float4 b = xs[i];
+            for (int g = 1; g < G; ++g) {
+                const float4 t = xs[g * c4 + i];
+                b.x += t.x; b.y += t.y; b.z += t.z; b.w += t.w;
+            }
+            if (in_parts > 1) { b.x *= in_scale; b.y *= in_scale; b.z *= in_scale; b.w *= in_scale; }
+            xs[i] = b;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < FC_PER_BLOCK / 4; ++r) {
+        const int o = blockIdx.x * FC_PER_BLOCK + r * 4 + wave;
+        if (o >= Cout) continue;
+        const float4* wr = reinterpret_cast<const float4*>(w + (long long)o * Cin);
+        float s = 0.f;
+#pragma unroll 8
+        for (int i = lane; i < c4; i += 64) {
+            const float4 a = wr[i];
+            const float4 b = xs[i];
+            s += a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+        }
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if (lane == 0) {
+            s += bias[o];
+            if (act == 2) s = s > 0.f ? s : 0.f;
+            else if (act == 3) s = 1.f / (1.f + __expf(-s));
+            out[(long long)n * Cout + o] = s;
+        }
     }
 }
 void launch_fc(const float* in, const float* w, const float* bias, float* out, int N, int Cin, int Cout, int act,
                int in_parts, float in_scale, hipStream_t s) {
-    BP_CHECK(Cin % 4 == 0, "fc: Cin % 4");
-    hipLaunchKernelGGL(fc_kernel, dim3((Cout + 3) / 4, N), dim3(256), 0, s, in, w, bias, out, Cin, Cout, act, in_parts,
-                       in_scale);
+    BP_CHECK(Cin % 4 == 0 && Cin * 4 <= 64 * 1024, "fc: Cin % 4, Cin <= 16384");
+    hipLaunchKernelGGL(fc_kernel, dim3((Cout + FC_PER_BLOCK - 1) / FC_PER_BLOCK, N), dim3(256), (size_t)Cin * 4 * (Cin <= 512 ? 4 : 1), s, in, w,
+                       bias, out, Cin, Cout, act, in_parts, in_scale);
 }
 
 // ---------------------------------------------------------------- YOLO head decode (yolo/darknet.py:129-169)
