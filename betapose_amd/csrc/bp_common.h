@@ -64,6 +64,7 @@ struct ConvParams {
     float* partial;        // [splits][tiles][BM*64] fragment-order slabs when splits > 1
     int* tickets;          // [tiles] arrival counters (zero between launches) when splits > 1
     int CoutPad;
+    int cin_pack;          // channels per filter tap in the packed K order (= Cin, or 4 for Cin <= 4 stems)
     const unsigned short* w16;   // fp16 copy of w (same [CoutPad][Kpad] packing) or null
     int use_f16;           // 1: run the fp16-MFMA kernel when w16 is present and the layer is eligible
     unsigned long long* stamps;   // debug (tools/bench_conv.py --stamps): per-block s_memtime marks, null in production
@@ -79,6 +80,7 @@ enum ConvTile : int { TILE_64x64 = 0, TILE_128x64 = 1, TILE_32x64 = 2, TILE_64x3
 struct ConvProfHook { hipEvent_t e0, e1; };
 extern thread_local ConvProfHook* g_conv_prof;
 bool conv_f16_eligible(const ConvParams& p);
+int conv_vec_mode(const ConvParams& p);   // 0 scalar gather, 1 Cin % 32 == 0, 2 four-channel-packed stem
 
 void launch_conv(const ConvParams& p, int tile, hipStream_t s);
 int conv_tiles(const ConvParams& p, int tile);   // blocks per K-slice

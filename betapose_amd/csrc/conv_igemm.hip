@@ -126,7 +126,13 @@ __device__ __forceinline__ int fast_div(int m, int d, float rcp) {
     return q;
 }
 
-template <int TM, int TN, bool VEC>
+// VEC: how a thread fetches its 4 consecutive K elements of an A row --
+//   0  scalar gather (any Cin): 4 address computations + 4 dword loads per element group;
+//   1  Cin % 32 == 0: a 32-wide chunk lies inside one filter tap, one 16-B load, wave-uniform K walk;
+//   2  Cin <= 4 with filters packed 4 channels per tap (the two RGB stems): one 16-B load per TAP -- the thread's
+//      group is tap chunk*8 + (tid & 7); with Cin = 3 the 4th float it reads is the neighbouring pixel's first channel
+//      (or 0 past the tensor), which meets a zero filter entry.
+template <int TM, int TN, int VEC>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int RA = BM / 32, RB = BN / 32;
@@ -176,7 +182,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         const int oy = fast_div(rem, p.OW, rcp_ow);
         const int ox = rem - oy * p.OW;
         const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
-        a_base[i] = (unsigned)((((b * p.H + iy0) * p.W + ix0) * p.in_ld + c4 * 4) * 4);
+        a_base[i] = (unsigned)((((b * p.H + iy0) * p.W + ix0) * p.in_ld + (VEC == 2 ? 0 : c4 * 4)) * 4);
         // taps inside the image: kx in [kx_lo, kx_hi), ky in [ky_lo, ky_hi)
         const int kx_lo = max(0, -ix0), kx_hi = min(p.ksize, p.W - ix0);
         const int ky_lo = max(0, -iy0), ky_hi = min(p.ksize, p.H - iy0);
@@ -195,12 +201,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     for (int i = 0; i < RB; ++i) b_base[i] = (unsigned)(((n0 + lr + 32 * i) * p.Kpad + c4 * 4) * 4);
 
     // wave-uniform walk over K: chunk -> (tap, ky, kx, ci0); one division here, increments afterwards
-    const int cpt = VEC ? (p.Cin >> 5) : 1;  // chunks per filter tap
+    const int cpt = VEC == 1 ? (p.Cin >> 5) : 1;  // chunks per filter tap
     int w_c = c_begin;                        // next chunk to load
-    int w_tap = VEC ? c_begin / cpt : 0;
-    int w_ci = VEC ? (c_begin - w_tap * cpt) << 5 : 0;
-    int w_ky = VEC ? w_tap / p.ksize : 0;
-    int w_kx = VEC ? w_tap - w_ky * p.ksize : 0;
+    int w_tap = VEC == 1 ? c_begin / cpt : 0;
+    int w_ci = VEC == 1 ? (c_begin - w_tap * cpt) << 5 : 0;
+    int w_ky = VEC == 1 ? w_tap / p.ksize : 0;
+    int w_kx = VEC == 1 ? w_tap - w_ky * p.ksize : 0;
+    const float rcp_ks = 1.0f / (float)p.ksize;
 
     f32x4 ra0[RA], rb0[RB], ra1[RA], rb1[RB];
 
@@ -211,10 +218,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     int sb = 0, ld_c = 0;
 #define BP_ADDR()                                                                                      \
     {                                                                                                  \
-        if constexpr (VEC) {                                                                           \
+        if constexpr (VEC == 1) {                                                                      \
             const unsigned delta = (unsigned)(((w_ky * p.W + w_kx) * p.in_ld + w_ci) * 4);            \
             _Pragma("unroll") for (int i = 0; i < RA; ++i) {                                           \
                 const bool ok = (a_mask[i] >> w_tap) & 1ull;                                           \
+                va[i] = ok ? a_base[i] + delta : OOB;                                                  \
+            }                                                                                          \
+        } else if constexpr (VEC == 2) {                                                               \
+            const int tap = w_c * 8 + c4;                   /* this thread's tap of the chunk */        \
+            const int ky = fast_div(tap, p.ksize, rcp_ks);                                             \
+            const int kx = tap - ky * p.ksize;                                                         \
+            const unsigned delta = (unsigned)(((ky * p.W + kx) * p.in_ld) * 4);                        \
+            _Pragma("unroll") for (int i = 0; i < RA; ++i) {                                           \
+                const bool ok = tap < 64 && ((a_mask[i] >> tap) & 1ull);                               \
                 va[i] = ok ? a_base[i] + delta : OOB;                                                  \
             }                                                                                          \
         }                                                                                              \
@@ -222,7 +238,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         sb = w_c * (BK * 4);                                                                           \
         if (w_c + 1 < c_end) {                                                                         \
             ++w_c;                                                                                     \
-            if constexpr (VEC) {                                                                       \
+            if constexpr (VEC == 1) {                                                                  \
                 w_ci += 32;                                                                            \
                 if (w_ci == p.Cin) {                                                                   \
                     w_ci = 0;                                                                          \
@@ -234,7 +250,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     }
 #define BP_LOAD_A(ra_)                                                                                 \
     {                                                                                                  \
-        if constexpr (VEC) {                                                                           \
+        if constexpr (VEC != 0) {                                                                      \
             _Pragma("unroll") for (int i = 0; i < RA; ++i) ra_[i] = buf_load4(rsrcA, va[i], 0);        \
         } else {                                                                                       \
             _Pragma("unroll") for (int i = 0; i < RA; ++i) {                                           \
@@ -243,12 +259,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                     const int k = ld_c * BK + c4 * 4 + e;                                              \
                     float x = 0.f;                                                                     \
                     if (k < p.Ktrue) {                                                                 \
-                        const int tap = k / p.Cin;                                                     \
-                        const int ci = k - tap * p.Cin;                                                \
+                        const int tap = k / p.cin_pack;                                                \
+                        const int ci = k - tap * p.cin_pack;                                           \
                         const int ky = tap / p.ksize;                                                  \
                         const int kx = tap - ky * p.ksize;                                             \
                         const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;                              \
-                        if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)              \
+                        if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && ci < p.Cin) \
                             x = p.in[((long long)(a_bh[i] + iy) * p.W + ix) * p.in_ld + ci];           \
                     }                                                                                  \
                     v_[e] = x;                                                                         \
@@ -542,20 +558,23 @@ template <int TM, int TN>
 static void launch_t(const ConvParams& p, hipStream_t s) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     dim3 grid(((p.M + BM - 1) / BM) * (p.CoutPad / BN) * p.splits);
-    // vector path: whole 32-channel chunks inside one filter tap, taps addressable by a 64-bit mask
-    const bool vec = (p.Cin % 32 == 0) && (p.in_ld % 4 == 0) && p.ksize <= 8;
+    // vector paths: whole 32-channel chunks inside one filter tap (taps addressable by a 64-bit mask), or filters
+    // packed 4 channels per tap for the RGB stems; anything else gathers scalars
+    const int vec = conv_vec_mode(p);
     if (g_conv_prof) {
         // hipExtLaunchKernelGGL stamps the events with the kernel's own begin/end (no host-side event gap)
-        if (vec)
-            hipExtLaunchKernelGGL((conv_igemm_kernel<TM, TN, true>), grid, dim3(256), 0, s, g_conv_prof->e0,
-                                  g_conv_prof->e1, 0, p);
+        if (vec == 1)
+            hipExtLaunchKernelGGL((conv_igemm_kernel<TM, TN, 1>), grid, dim3(256), 0, s, g_conv_prof->e0, g_conv_prof->e1, 0, p);
+        else if (vec == 2)
+            hipExtLaunchKernelGGL((conv_igemm_kernel<TM, TN, 2>), grid, dim3(256), 0, s, g_conv_prof->e0, g_conv_prof->e1, 0, p);
         else
-            hipExtLaunchKernelGGL((conv_igemm_kernel<TM, TN, false>), grid, dim3(256), 0, s, g_conv_prof->e0,
-                                  g_conv_prof->e1, 0, p);
-    } else if (vec) {
-        hipLaunchKernelGGL((conv_igemm_kernel<TM, TN, true>), grid, dim3(256), 0, s, p);
+            hipExtLaunchKernelGGL((conv_igemm_kernel<TM, TN, 0>), grid, dim3(256), 0, s, g_conv_prof->e0, g_conv_prof->e1, 0, p);
+    } else if (vec == 1) {
+        hipLaunchKernelGGL((conv_igemm_kernel<TM, TN, 1>), grid, dim3(256), 0, s, p);
+    } else if (vec == 2) {
+        hipLaunchKernelGGL((conv_igemm_kernel<TM, TN, 2>), grid, dim3(256), 0, s, p);
     } else {
-        hipLaunchKernelGGL((conv_igemm_kernel<TM, TN, false>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((conv_igemm_kernel<TM, TN, 0>), grid, dim3(256), 0, s, p);
     }
 }
 
@@ -567,6 +586,12 @@ static void launch_f16_t(const ConvParams& p, hipStream_t s) {
         hipExtLaunchKernelGGL((conv_igemm_f16_kernel<TM, TN>), grid, dim3(256), 0, s, g_conv_prof->e0, g_conv_prof->e1, 0, p);
     else
         hipLaunchKernelGGL((conv_igemm_f16_kernel<TM, TN>), grid, dim3(256), 0, s, p);
+}
+
+int conv_vec_mode(const ConvParams& p) {
+    if ((p.Cin % 32 == 0) && (p.in_ld % 4 == 0) && p.ksize <= 8) return 1;
+    if (p.cin_pack == 4 && p.Cin <= 4 && p.ksize <= 8) return 2;
+    return 0;
 }
 
 bool conv_f16_eligible(const ConvParams& p) {

@@ -166,7 +166,10 @@ int Net::add_conv(const std::string& name, const Tensor& in, const Tensor& out_v
                   int k, int stride, int pad, int act, int store_mode, const Tensor* res, const float* res_scale,
                   int res_after_act, float bn_eps, int OH, int OW) {
     const int Cin = in.C;
-    const int K = k * k * Cin;
+    // K order: (ky, kx, ci) with `cpk` channels per tap -- Cin, or 4 for the RGB stems (Cin <= 4): a tap is then one
+    // 16-B load (conv_igemm.hip, VEC mode 2) and the padded channel meets zero filter entries
+    const int cpk = Cin <= 4 ? 4 : Cin;
+    const int K = k * k * cpk;
     const int Kpad = round_up(K, 32);
     const int CoutPad = round_up(Cout, 64);
     float *dW, *dB;
@@ -189,7 +192,7 @@ int Net::add_conv(const std::string& name, const Tensor& in, const Tensor& out_v
             float* dst = W.data() + (size_t)n * Kpad;
             const float* src = cw.w + (size_t)co * Cin * k * k;
             for (int ci = 0; ci < Cin; ++ci)
-                for (int t = 0; t < k * k; ++t) dst[(size_t)t * Cin + ci] = (float)((double)src[(size_t)ci * k * k + t] * s);
+                for (int t = 0; t < k * k; ++t) dst[(size_t)t * cpk + ci] = (float)((double)src[(size_t)ci * k * k + t] * s);
         }
         dW = upload_weights(W.data(), W.size());
         dB = upload_weights(B.data(), B.size());
@@ -200,7 +203,7 @@ int Net::add_conv(const std::string& name, const Tensor& in, const Tensor& out_v
     op.name = name;
     ConvParams& c = op.conv;
     c.in = in.p; c.in_ld = in.ld; c.N = 1; c.H = in.H; c.W = in.W; c.Cin = Cin;
-    c.w = dW; c.Kpad = Kpad; c.Ktrue = K; c.bias = dB;
+    c.w = dW; c.Kpad = Kpad; c.Ktrue = K; c.bias = dB; c.cin_pack = cpk;
     c.out = out_view.p; c.out_ld = out_view.ld; c.OH = OH; c.OW = OW; c.Cout = Cout;
     c.ksize = k; c.stride = stride; c.pad = pad; c.act = act;
     c.res = res ? res->p : nullptr; c.res_ld = res ? res->ld : 0; c.res_scale = res_scale;
@@ -209,8 +212,9 @@ int Net::add_conv(const std::string& name, const Tensor& in, const Tensor& out_v
     c.tickets = nullptr;
     c.stamps = nullptr;
     c.CoutPad = CoutPad;
-    op.flops = 2.0 * OH * OW * (double)Cout * K;
-    op.bytes = 4.0 * ((double)Cout * K + (double)in.H * in.W * Cin + (double)OH * OW * Cout + (res ? (double)OH * OW * Cout : 0.0));
+    const double Kalg = (double)k * k * Cin;   // algorithmic K (the packing pad is not work)
+    op.flops = 2.0 * OH * OW * (double)Cout * Kalg;
+    op.bytes = 4.0 * ((double)Cout * Kalg + (double)in.H * in.W * Cin + (double)OH * OW * Cout + (res ? (double)OH * OW * Cout : 0.0));
     ops_.push_back(op);
     return (int)ops_.size() - 1;
 }
@@ -355,7 +359,7 @@ int Net::profile(int batch, int iters, float* ms, int* info, int cap, hipStream_
             int tile = 0, splits = 1, cps = 0, vec = 0, conv = ops_[i].type == OP_CONV;
             if (conv) {
                 choose_launch(ops_[i], batch, force_tile_, sk_target_, sk_min_chunks_, sk_max_splits_, &tile, &splits, &cps);
-                vec = (ops_[i].conv.Cin % 32 == 0) && (ops_[i].conv.in_ld % 4 == 0);
+                vec = conv_vec_mode(ops_[i].conv) ? 1 : 0;
                 if (ops_[i].conv.use_f16 && conv_f16_eligible(ops_[i].conv)) vec = 2;   // fp16-MFMA kernel
             }
             info[4 * i] = conv; info[4 * i + 1] = tile; info[4 * i + 2] = vec; info[4 * i + 3] = splits;

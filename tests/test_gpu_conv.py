@@ -35,8 +35,11 @@ def _check(out, ref, tol=2e-5):
 
 CASES = [
     # N, H, W, Cin, Cout, k, stride, pad, act
-    (1, 32, 32, 3, 32, 3, 1, 1, "leaky"),      # YOLO layer 0 class (scalar gather path)
+    (1, 32, 32, 3, 32, 3, 1, 1, "leaky"),      # YOLO layer 0 class (4-channel-packed stem path)
     (1, 40, 32, 3, 64, 7, 2, 3, "relu"),       # KPD stem class
+    (2, 11, 9, 1, 20, 5, 1, 2, "linear"),      # stem path with Cin = 1, batch 2
+    (1, 12, 10, 20, 40, 3, 1, 1, "leaky"),     # Cin neither <= 4 nor % 32: scalar gather path
+    (1, 16, 16, 3, 8, 9, 1, 4, "linear"),      # 9x9 kernel: too many taps for the mask -> scalar gather, packed K
     (1, 26, 26, 32, 64, 3, 2, 1, "leaky"),     # 3x3/s2
     (1, 13, 13, 64, 32, 1, 1, 0, "leaky"),     # 1x1
     (2, 13, 13, 128, 256, 3, 1, 1, "leaky"),   # 3x3/s1, batch 2, M tail
