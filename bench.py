@@ -56,7 +56,7 @@ def parse_args():
     ap.add_argument("--sk-min", type=int, default=4)
     ap.add_argument("--sk-max", type=int, default=8)
     ap.add_argument("--tile", type=int, default=-1)
-    ap.add_argument("--precision", choices=["f32", "f16"], default="f32",
+    ap.add_argument("--precision", choices=["f32", "f16", "bf16x3"], default="f32",
                     help="matrix-core operand precision: f32 = fp32 MFMA (the parity configuration, default); f16 = fp16 "
                          "MFMA operands with fp32 accumulation (BASELINE configs[2])")
     return ap.parse_args()
@@ -209,12 +209,17 @@ def roofline(det, pose, batch):
                 break
     except Exception:
         pass
-    f16 = key[1] == 2
-    peak = PEAK_F16_MFMA_TFLOPS if f16 else PEAK_FP32_MFMA_TFLOPS
-    name = ("bp::conv_igemm_f16_kernel<%s>" % TILE_NAMES.get(key[0], "?")) if f16 else \
-        "bp::conv_igemm_kernel<%s, %s>" % (TILE_NAMES.get(key[0], "?"), "true" if key[1] else "false")
-    if f16:
+    mode = {2: "f16", 3: "bf16x3"}.get(key[1], "f32")
+    peak = PEAK_FP32_MFMA_TFLOPS if mode == "f32" else PEAK_F16_MFMA_TFLOPS
+    if mode == "f32":
+        name = "bp::conv_igemm_kernel<%s, %d>" % (TILE_NAMES.get(key[0], "?"), key[1])
+    else:
+        name = "bp::conv_igemm_h_kernel<%s, %d>" % (TILE_NAMES.get(key[0], "?"), 1 if mode == "f16" else 3)
         traffic, traffic_src = None, None     # the committed PMC passes are of the fp32 kernel
+    extra = {}
+    if mode == "bf16x3":
+        # six bf16 partial products per algorithmic multiply: the matrix cores execute 6x the algorithmic FLOPs
+        extra = {"mfma_flops_per_algorithmic_flop": 6, "frac_of_executed_mfma_flops": round(6 * achieved / peak, 4)}
     return {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
         "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
@@ -224,7 +229,7 @@ def roofline(det, pose, batch):
         "flops_per_launch": g["flops"] / g["launches"],
         "all_conv": {"achieved": round(conv_flops / (conv_ms * 1e-3) / 1e12, 2), "ms_per_step": round(conv_ms, 4),
                      "gflop_per_step": round(conv_flops / 1e9, 2)},
-        "device_ms_per_step_eager_sum": round(total_ms, 4),
+        "device_ms_per_step_eager_sum": round(total_ms, 4), **extra,
     }
 
 
@@ -339,7 +344,9 @@ def main():
             "metric": "frames/sec (640x480, 50-kp KPD)", "value": round(frames_total / el, 2), "unit": "frames/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(el / a.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if a.precision == "f32" else "f16 MFMA operands, f32 accumulate and activations",
+            "dtype": {"f32": "f32", "f16": "f16 MFMA operands, f32 accumulate and activations",
+                      "bf16x3": "f32 as an exact 3-way bf16 operand split (6 bf16 MFMA products), f32 accumulate and "
+                                "activations"}[a.precision],
             "data": "synthetic (seeded 640x480 BGR u8 frames resident in HBM; seeded random weights of the "
                     "reference architectures)",
             "config": {"workload": "BASELINE configs[1]: single-object frame, YOLOv3 416x416 (1 class) -> 1 crop "

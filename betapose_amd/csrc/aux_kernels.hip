@@ -568,6 +568,26 @@ void launch_f32_to_f16(const float* in, unsigned short* out, long long n, hipStr
                        reinterpret_cast<_Float16*>(out), n);
 }
 
+// ---- packed filters fp32 -> three bf16 planes with x == p0 + p1 + p2 exactly (PREC_BF16X3)
+__global__ void f32_to_bf16x3_kernel(const float* __restrict__ in, __bf16* __restrict__ out, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float x = in[i];
+    const __bf16 h1 = (__bf16)x;
+    const float r1 = x - (float)h1;
+    const __bf16 h2 = (__bf16)r1;
+    const float r2 = r1 - (float)h2;
+    out[i] = h1;
+    out[n + i] = h2;
+    out[2 * n + i] = (__bf16)r2;
+}
+
+void launch_f32_to_bf16x3(const float* in, unsigned short* out, long long n, hipStream_t s) {
+    const int threads = 256;
+    hipLaunchKernelGGL(f32_to_bf16x3_kernel, dim3((unsigned)((n + threads - 1) / threads)), dim3(threads), 0, s, in,
+                       reinterpret_cast<__bf16*>(out), n);
+}
+
 // ---- placement probe: which XCD / CU every workgroup of a grid landed on (CU-mask experiments, tests)
 __global__ void probe_placement_kernel(int* out) {
     if (threadIdx.x == 0) {

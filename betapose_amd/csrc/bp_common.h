@@ -65,14 +65,14 @@ struct ConvParams {
     int* tickets;          // [tiles] arrival counters (zero between launches) when splits > 1
     int CoutPad;
     int cin_pack;          // channels per filter tap in the packed K order (= Cin, or 4 for Cin <= 4 stems)
-    const unsigned short* w16;   // fp16 copy of w (same [CoutPad][Kpad] packing) or null
-    int use_f16;           // 1: run the fp16-MFMA kernel when w16 is present and the layer is eligible
+    const unsigned short* w16;   // 16-bit copy of w for mfma_mode: fp16 [CoutPad][Kpad], or three bf16 planes [3][CoutPad][Kpad]
+    int mfma_mode;         // Precision the launch uses (PREC_F16 / PREC_BF16X3 need w16 and an eligible layer)
     unsigned long long* stamps;   // debug (tools/bench_conv.py --stamps): per-block s_memtime marks, null in production
 };
 
 // tile configuration ids for launch_conv
 // arithmetic of the matrix-core operands (accumulation and activations are always fp32)
-enum Precision : int { PREC_F32 = 0, PREC_F16 = 1 };
+enum Precision : int { PREC_F32 = 0, PREC_F16 = 1, PREC_BF16X3 = 2 };
 
 enum ConvTile : int { TILE_64x64 = 0, TILE_128x64 = 1, TILE_32x64 = 2, TILE_64x32 = 3 };
 
@@ -121,6 +121,7 @@ void launch_heatmap_argmax(const float* hm, int N, int C, int H, int W, float* o
 
 // [batch][rec_floats] rows = sel[8] | pts[8] | kp[kp_floats]
 void launch_f32_to_f16(const float* in, unsigned short* out, long long n, hipStream_t s);
+void launch_f32_to_bf16x3(const float* in, unsigned short* out_planes, long long n, hipStream_t s);
 void launch_probe_placement(int* d_out, int blocks, hipStream_t s);
 void launch_pack_records(const float* sel, const float* pts, const float* kp, float* out, int batch, int kp_floats,
                          int rec_floats, hipStream_t s);

@@ -76,6 +76,17 @@ static std::string read_text(const char* path) {
     return ss.str();
 }
 
+// BP_PRECISION=f32|bf16x3|f16 overrides the built-in default of newly created engines (bp_*_set_precision still wins)
+static int default_precision() {
+    const char* e = std::getenv("BP_PRECISION");
+    if (!e || !*e) return bp::PREC_F32;
+    const std::string v(e);
+    if (v == "f32") return bp::PREC_F32;
+    if (v == "f16") return bp::PREC_F16;
+    if (v == "bf16x3") return bp::PREC_BF16X3;
+    throw bp::Error("BP_PRECISION must be f32, bf16x3 or f16, not '" + v + "'");
+}
+
 extern "C" {
 
 const char* bp_last_error(void) { return g_err.c_str(); }
@@ -141,6 +152,7 @@ int bp_yolo_create_from_memory(const char* cfg_text, const float* stream, size_t
     std::unique_ptr<bp_yolo> y(new bp_yolo);
     y->device = device;
     y->net.reset(new bp::YoloNet(cfg_text, stream, n_floats, reso, max_batch));
+    if (default_precision() != bp::PREC_F32) y->net->set_precision(default_precision());
     *out = y.release();
     return 0;
     BP_CATCH
@@ -234,6 +246,7 @@ int bp_kpd_create(const float* stream, size_t n_floats, int n_classes, int max_b
     std::unique_ptr<bp_kpd> k(new bp_kpd);
     k->device = device;
     k->net.reset(new bp::KpdNet(stream, n_floats, n_classes, max_batch));
+    if (default_precision() != bp::PREC_F32) k->net->set_precision(default_precision());
     *out = k.release();
     return 0;
     BP_CATCH
@@ -382,10 +395,11 @@ int bp_conv2d(const float* d_in, int N, int H, int W, int Cin, const float* h_w,
     net.add_conv("conv", in, out, cw, Cout, k, stride, pad, act, store_mode, d_res ? &res : nullptr, nullptr,
                  res_after_act, 1e-5f, OH, OW);
     int t = tile;
-    if (t >= 16) {   // +16: fp16-MFMA operands
-        t -= 16;
-        net.set_precision(bp::PREC_F16);
-        BP_CHECK(net.ops_[0].conv.use_f16, "layer is not eligible for the fp16 path (needs Cin % 32 == 0)");
+    if (t >= 16) {   // +16: fp16-MFMA operands, +32: bf16x3 split operands
+        const int prec = t >= 32 ? bp::PREC_BF16X3 : bp::PREC_F16;
+        t -= t >= 32 ? 32 : 16;
+        net.set_precision(prec);
+        BP_CHECK(net.ops_[0].conv.mfma_mode == prec, "layer is not eligible for the 16-bit MFMA paths (needs Cin % 32 == 0)");
     }
     bp::ConvParams p = net.ops_[0].conv;
     p.N = N; p.M = N * OH * OW;

@@ -375,30 +375,57 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 }
 
 // =====================================================================================================================
-// fp16-MFMA variant (BASELINE.json configs[2]: "fp16 MFMA conv path").  Same tiling, split-K hand-off and epilogue;
-// what changes is the operand precision of the matrix cores: activations stay fp32 in HBM and are rounded (RNE) to
-// fp16 when a chunk is parked in LDS, filters are pre-rounded fp16 [CoutPad][Kpad] (half the filter traffic), products
-// are accumulated in fp32 by v_mfma_f32_32x32x16_f16 (8 passes: 16x the fp32 MFMA rate), outputs are fp32.  The K loop
-// is then bound by L2->LDS staging (12 KB per 64x64x32 chunk), not by the MFMA pipe.
-// Fragment layout of the 32x32x16 form: lane l supplies row (l & 31), k = 8*(l>>5) .. 8*(l>>5)+7 (one 16-B LDS read).
+// 16-bit-operand MFMA variants.  Same tiling, K walk, split-K hand-off and epilogue (conv_tail.inc) as the fp32 kernel;
+// what changes is what the matrix cores multiply.  Activations stay fp32 in HBM and are converted when a chunk is
+// parked in LDS; filters are converted once on the device from the packed fp32 ones; accumulation and outputs are fp32.
+//   NP = 1  fp16 operands (BASELINE.json configs[2], "fp16 MFMA conv path"): round-to-nearest fp16 of both operands,
+//           one v_mfma_f32_32x32x16_f16 per 16 k (16x the fp32 MFMA rate).  Results carry fp16 rounding (~1e-3).
+//   NP = 3  fp32-accurate on the bf16 pipe: every fp32 operand x is split EXACTLY into three bf16 terms
+//           x = x1 + x2 + x3 (8 + 8 + 8 significand bits; bf16 has fp32's exponent range, so no overflow/underflow
+//           cases), and a*b is formed from the six partial products whose weight is >= 2^-16 of the leading one:
+//           a1b1 + a1b2 + a2b1 + a1b3 + a2b2 + a3b1 (each exact in the fp32 accumulator path).  The three dropped terms
+//           are <= 2^-23 relative -- below the rounding of the fp32 accumulation itself (measured: 3e-8 vs 3e-6
+//           relative to an fp64 conv) -- at 6/16 of the fp32-MFMA cycles.  LDS carries three planes per operand.
+// Fragment layout of the 32x32x16 forms: lane l supplies row (l & 31), k = 8*(l>>5) .. 8*(l>>5)+7 (one 16-B LDS read).
 // =====================================================================================================================
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-static constexpr int LDH = 40;   // halfs per LDS row: 32 + 8 pad = 80 B, so 8 consecutive lanes' 16-B reads hit all 32 banks once
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+// LDS rows of the 16-bit kernels are 32 elements = 64 B, unpadded; the four 16-B granules of row r are stored at
+// granule index g ^ ((r >> 1) & 3), so the 16-B fragment reads of 8 consecutive lanes (8 rows, same logical granule)
+// hit all 32 banks once
+static constexpr int LDH = 32;
 
-template <int TM, int TN>
-__global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvParams p) {
+template <int NP> struct HalfOps;
+template <> struct HalfOps<1> {
+    typedef f16x8 frag;
+    static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct HalfOps<3> {
+    typedef bf16x8 frag;
+    static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+
+template <int TM, int TN, int NP>
+__global__ __launch_bounds__(256) void conv_igemm_h_kernel(const ConvParams p) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int RA = BM / 32;          // fp32 A rows per thread (4 floats each)
-    constexpr int RBH = BN / 64;         // fp16 B rows per thread (8 halfs each)
+    constexpr int RBH = BN / 64;         // 16-bit B rows per thread and plane (8 elements each)
     constexpr int LDT = BN + 4;
-    constexpr int STAGE_HALFS = (BM + BN) * LDH;
+    constexpr int STAGE_HALFS = NP * (BM + BN) * LDH;
     constexpr int SMEM_FLOATS = (2 * STAGE_HALFS / 2 > BM * LDT) ? 2 * STAGE_HALFS / 2 : BM * LDT;
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
-    _Float16* const sh = reinterpret_cast<_Float16*>(smem);
-    // stage s: A rows at sh + s*STAGE_HALFS, B rows right after the A rows
-#define BH_AS(s_) (sh + (s_) * STAGE_HALFS)
-#define BH_BS(s_) (sh + (s_) * STAGE_HALFS + BM * LDH)
+    unsigned short* const sh = reinterpret_cast<unsigned short*>(smem);
+    typedef typename HalfOps<NP>::frag frag_t;
+    // stage s: NP planes of A rows, then NP planes of B rows
+#define BH_AS(s_, pl_) (sh + (s_) * STAGE_HALFS + (pl_) * (BM * LDH))
+#define BH_BS(s_, pl_) (sh + (s_) * STAGE_HALFS + NP * (BM * LDH) + (pl_) * (BN * LDH))
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -414,13 +441,14 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvParams p)
     const int c_end = min(p.nchunks, c_begin + p.chunks_per_split);
 
     const int lr = tid >> 3, c4 = tid & 7;       // A: row lr (+32i), floats c4*4..+3
-    const int br = tid >> 2, b8 = (tid & 3) * 8; // B: row br (+64i), halfs b8..+7
+    const int br = tid >> 2, b8 = (tid & 3) * 8; // B: row br (+64i), elements b8..+7
     const int hw = p.OH * p.OW;
+    const int plane_bytes = p.CoutPad * p.Kpad * 2;
 
     const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.in), 0, (int)min((long long)p.N * p.H * p.W * p.in_ld * 4, (long long)OOB), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<unsigned short*>(p.w16), 0, p.CoutPad * p.Kpad * 2, 0x00020000);
+        const_cast<unsigned short*>(p.w16), 0, NP * plane_bytes, 0x00020000);
 
     unsigned a_base[RA];
     unsigned long long a_mask[RA];
@@ -479,16 +507,30 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvParams p)
 #define BH_LOAD(ra_, rb_)                                                                              \
     {                                                                                                  \
         _Pragma("unroll") for (int i = 0; i < RA; ++i) ra_[i] = buf_load4(rsrcA, va[i], 0);            \
-        _Pragma("unroll") for (int i = 0; i < RBH; ++i)                                                \
-            rb_[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrcB, (int)b_base[i], sb, 0);              \
+        _Pragma("unroll") for (int pl = 0; pl < NP; ++pl)                                              \
+            _Pragma("unroll") for (int i = 0; i < RBH; ++i)                                            \
+                rb_[pl][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrcB, (int)b_base[i] + pl * plane_bytes, sb, 0); \
     }
 #define BH_STORE(s_, ra_, rb_)                                                                         \
     {                                                                                                  \
-        _Pragma("unroll") for (int i = 0; i < RA; ++i)                                                 \
-            *reinterpret_cast<f16x4*>(BH_AS(s_) + (lr + 32 * i) * LDH + c4 * 4) =                      \
-                __builtin_convertvector(ra_[i], f16x4);                                                \
-        _Pragma("unroll") for (int i = 0; i < RBH; ++i)                                                \
-            *reinterpret_cast<u32x4*>(BH_BS(s_) + (br + 64 * i) * LDH + b8) = rb_[i];                  \
+        _Pragma("unroll") for (int i = 0; i < RA; ++i) {                                               \
+            unsigned short* dst = BH_AS(s_, 0) + (lr + 32 * i) * LDH + a_st_off;                       \
+            if constexpr (NP == 1) {                                                                   \
+                *reinterpret_cast<f16x4*>(dst) = __builtin_convertvector(ra_[i], f16x4);               \
+            } else {                                                                                   \
+                const bf16x4 h1 = __builtin_convertvector(ra_[i], bf16x4);                             \
+                const f32x4 r1 = ra_[i] - __builtin_convertvector(h1, f32x4);                          \
+                const bf16x4 h2 = __builtin_convertvector(r1, bf16x4);                                 \
+                const f32x4 r2 = r1 - __builtin_convertvector(h2, f32x4);                              \
+                const bf16x4 h3 = __builtin_convertvector(r2, bf16x4);                                 \
+                *reinterpret_cast<bf16x4*>(dst) = h1;                                                  \
+                *reinterpret_cast<bf16x4*>(dst + BM * LDH) = h2;                                       \
+                *reinterpret_cast<bf16x4*>(dst + 2 * BM * LDH) = h3;                                   \
+            }                                                                                          \
+        }                                                                                              \
+        _Pragma("unroll") for (int pl = 0; pl < NP; ++pl)                                              \
+            _Pragma("unroll") for (int i = 0; i < RBH; ++i)                                            \
+                *reinterpret_cast<u32x4*>(BH_BS(s_, pl) + (br + 64 * i) * LDH + b_st_off) = rb_[pl][i]; \
     }
 
     f32x16 acc[TM][TN];
@@ -499,27 +541,39 @@ __global__ __launch_bounds__(256) void conv_igemm_f16_kernel(const ConvParams p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int frag_off = (lane & 31) * LDH + (lane >> 5) * 8;
-    const int a_off = wm * (BM / 2) * LDH + frag_off;
-    const int b_off = wn * (BN / 2) * LDH + frag_off;
+    // swizzled element offsets inside a row (all row bases used below are multiples of 32 rows, so (row >> 1) & 3
+    // depends on the thread's own row index only)
+    const int a_st_off = (((c4 >> 1) ^ ((lr >> 1) & 3)) << 3) + ((c4 & 1) << 2);
+    const int b_st_off = ((tid & 3) ^ ((br >> 1) & 3)) << 3;
+    const int frow = lane & 31, fsw = (frow >> 1) & 3;
+    const int frag_ks0 = frow * LDH + (((lane >> 5)) ^ fsw) * 8;          // logical granule (lane>>5)     (k-step 0)
+    const int frag_ks1 = frow * LDH + ((2 + (lane >> 5)) ^ fsw) * 8;      // logical granule 2 + (lane>>5) (k-step 1)
+    const int a_row0 = wm * (BM / 2) * LDH;
+    const int b_row0 = wn * (BN / 2) * LDH;
 
     f32x4 ra0[RA], ra1[RA];
-    u32x4 rb0[RBH], rb1[RBH];
+    u32x4 rb0[NP][RBH], rb1[NP][RBH];
+    // partial products (A plane, B plane), smallest first
+    constexpr int NPROD = NP == 1 ? 1 : 6;
+    constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
+    constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
     // One chunk: LDS[cur_] holds chunk c; (rna_, rnb_) hold chunk c+1 (in flight since the previous phase);
     // (rfa_, rfb_) receive chunk c+2, whose addresses were computed in the previous phase.
 #define BH_PHASE(cur_, rna_, rnb_, rfa_, rfb_)                                                         \
     {                                                                                                  \
-        f16x8 fa[TM][2], fb[TN][2];                                                                    \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                             \
-            _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[i][ks] =                                 \
-                *reinterpret_cast<const f16x8*>(BH_AS(cur_) + a_off + i * 32 * LDH + ks * 16);         \
-            _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[j][ks] =                                 \
-                *reinterpret_cast<const f16x8*>(BH_BS(cur_) + b_off + j * 32 * LDH + ks * 16);         \
-        }                                                                                              \
         BH_LOAD(rfa_, rfb_);                                                                           \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                               \
-            _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[i][ks], fb[j][ks], acc[i][j], 0, 0, 0); \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                             \
+            frag_t fa[NP][TM], fb[NP][TN];                                                             \
+            _Pragma("unroll") for (int pl = 0; pl < NP; ++pl) {                                        \
+                _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[pl][i] =                             \
+                    *reinterpret_cast<const frag_t*>(BH_AS(cur_, pl) + a_row0 + i * 32 * LDH + (ks ? frag_ks1 : frag_ks0)); \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[pl][j] =                             \
+                    *reinterpret_cast<const frag_t*>(BH_BS(cur_, pl) + b_row0 + j * 32 * LDH + (ks ? frag_ks1 : frag_ks0)); \
+            }                                                                                          \
+            _Pragma("unroll") for (int q = 0; q < NPROD; ++q)                                          \
+                _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) \
+                    acc[i][j] = HalfOps<NP>::mfma(fa[NP == 1 ? 0 : PA[q]][i], fb[NP == 1 ? 0 : PB[q]][j], acc[i][j]); \
+        }                                                                                              \
         BH_STORE((cur_) ^ 1, rna_, rnb_);                                                              \
         BH_ADDR();                                                                                     \
         __syncthreads();                                                                               \
@@ -578,14 +632,14 @@ static void launch_t(const ConvParams& p, hipStream_t s) {
     }
 }
 
-template <int TM, int TN>
-static void launch_f16_t(const ConvParams& p, hipStream_t s) {
+template <int TM, int TN, int NP>
+static void launch_h_t(const ConvParams& p, hipStream_t s) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     dim3 grid(((p.M + BM - 1) / BM) * (p.CoutPad / BN) * p.splits);
     if (g_conv_prof)
-        hipExtLaunchKernelGGL((conv_igemm_f16_kernel<TM, TN>), grid, dim3(256), 0, s, g_conv_prof->e0, g_conv_prof->e1, 0, p);
+        hipExtLaunchKernelGGL((conv_igemm_h_kernel<TM, TN, NP>), grid, dim3(256), 0, s, g_conv_prof->e0, g_conv_prof->e1, 0, p);
     else
-        hipLaunchKernelGGL((conv_igemm_f16_kernel<TM, TN>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((conv_igemm_h_kernel<TM, TN, NP>), grid, dim3(256), 0, s, p);
 }
 
 int conv_vec_mode(const ConvParams& p) {
@@ -608,11 +662,14 @@ void launch_conv(const ConvParams& p, int tile, hipStream_t s) {
     BP_CHECK(p.Kpad % BK == 0 && p.nchunks == p.Kpad / BK, "Kpad");
     BP_CHECK(p.splits >= 1 && (p.splits == 1 || (p.partial != nullptr && p.tickets != nullptr)), "split-K workspace");
     BP_CHECK((long long)p.N * p.H * p.W * p.in_ld * 4 < (long long)OOB, "activation tensor too large for 32-bit offsets");
-    if (p.use_f16 && conv_f16_eligible(p)) {
+    if (p.mfma_mode == PREC_F16 && conv_f16_eligible(p)) {
         switch (tile) {
-            case TILE_128x64: launch_f16_t<2, 1>(p, s); break;
-            default: launch_f16_t<1, 1>(p, s); break;
+            case TILE_128x64: launch_h_t<2, 1, 1>(p, s); break;
+            default: launch_h_t<1, 1, 1>(p, s); break;
         }
+    } else if (p.mfma_mode == PREC_BF16X3 && conv_f16_eligible(p)) {
+        BP_CHECK(tile == TILE_64x64, "the bf16x3 kernel is built for the 64x64 tile");
+        launch_h_t<1, 1, 3>(p, s);
     } else {
         switch (tile) {
             case TILE_128x64: launch_t<2, 1>(p, s); break;

@@ -134,9 +134,52 @@ static const SplitEntry kSplitTableF16[] = {
     { 43264,    64,    9,  1},
 };
 
+// bf16x3 kernel: same procedure (tools/tune_conv.py --b3, profiles/r01_splitk_tuning_bf16x3.txt)
+static const SplitEntry kSplitTableB3[] = {
+    {    80,   512,   64,  6},
+    {    80,   512,  144, 10},
+    {    80,  2048,   16,  3},
+    {    80,  2048,   32,  3},
+    {   169,    64,   32, 10},
+    {   169,   256,   16,  5},
+    {   169,   512,   32,  5},
+    {   169,  1024,  144,  5},
+    {   320,   256,   32,  5},
+    {   320,   256,   72,  6},
+    {   320,   512,   32,  5},
+    {   320,  1024,    8,  1},
+    {   320,  1024,   16,  3},
+    {   320,  1024,  144,  6},
+    {   676,    64,   16,  5},
+    {   676,   128,    8,  1},
+    {   676,   256,   16,  3},
+    {   676,   256,   24,  5},
+    {   676,   512,   72,  5},
+    {  1280,   128,   16,  3},
+    {  1280,   128,   36,  5},
+    {  1280,   256,   16,  3},
+    {  1280,   512,    4,  1},
+    {  1280,   512,    8,  1},
+    {  1280,   512,   72,  3},
+    {  2704,    64,    8,  1},
+    {  2704,   128,    8,  1},
+    {  2704,   128,   12,  1},
+    {  2704,   256,   36,  2},
+    {  5120,    64,    2,  1},
+    {  5120,    64,    8,  1},
+    {  5120,    64,   18,  3},
+    {  5120,    64,   36,  3},
+    {  5120,   128,    8,  1},
+    {  5120,   256,    2,  1},
+    { 10816,    64,    4,  1},
+    { 10816,   128,   18,  1},
+    { 43264,    64,    2,  1},
+    { 43264,    64,    9,  1},
+};
+
 static void choose_launch(const Op& op, int batch, int force_tile, int sk_target, int sk_min_chunks, int sk_max,
                           int* tile, int* splits, int* cps) {
-    const bool f16 = op.conv.use_f16 != 0;
+    const int mode = op.conv.mfma_mode;
     const ConvParams& c = op.conv;
     const long long M = (long long)batch * c.OH * c.OW;
     const int nt = c.CoutPad / 64;
@@ -147,10 +190,13 @@ static void choose_launch(const Op& op, int batch, int force_tile, int sk_target
     int s = 1;
     while (blocks * s < sk_target && c.nchunks / (s + 1) >= sk_min_chunks && s < sk_max) ++s;
     if (t == TILE_64x64 && sk_target == 512 && sk_min_chunks == 4 && sk_max == 8) {   // default policy: measured tables
-        if (f16) {
+        if (mode == PREC_F16) {
             s = 1;   // the fp16 K loop is ~5x shorter: unlisted shapes (other batch sizes) run unsplit unless tiny
             while (blocks * s < 128 && c.nchunks / (s + 1) >= 8 && s < sk_max) ++s;
             for (const SplitEntry& e : kSplitTableF16)
+                if (e.M == (int)M && e.CoutPad == c.CoutPad && e.nchunks == c.nchunks) { s = e.splits; break; }
+        } else if (mode == PREC_BF16X3) {
+            for (const SplitEntry& e : kSplitTableB3)
                 if (e.M == (int)M && e.CoutPad == c.CoutPad && e.nchunks == c.nchunks) { s = e.splits; break; }
         } else {
             for (const SplitEntry& e : kSplitTable)
@@ -247,20 +293,24 @@ void Net::finalize() {
 }
 
 void Net::set_precision(int prec) {
-    BP_CHECK(prec == PREC_F32 || prec == PREC_F16, "unknown precision");
-    if (prec == PREC_F16) {
+    BP_CHECK(prec == PREC_F32 || prec == PREC_F16 || prec == PREC_BF16X3, "unknown precision");
+    if (prec != PREC_F32) {
         std::lock_guard<std::mutex> lk(store_->f16_mutex);
+        auto& copies = prec == PREC_F16 ? store_->f16 : store_->bf16x3;
         bool made = false;
         for (Op& op : ops_) {
             if (op.type != OP_CONV) continue;
             ConvParams& c = op.conv;
-            if (!((c.Cin % 32 == 0) && (c.in_ld % 4 == 0) && c.ksize <= 8)) continue;   // stems (Cin = 3) stay fp32
-            auto it = store_->f16.find(c.w);
-            if (it == store_->f16.end()) {
+            c.w16 = nullptr;
+            if (!((c.Cin % 32 == 0) && (c.in_ld % 4 == 0) && c.ksize <= 8)) continue;   // the RGB stems stay on the fp32 kernel
+            auto it = copies.find(c.w);
+            if (it == copies.end()) {
                 const size_t n = (size_t)c.CoutPad * c.Kpad;
-                unsigned short* d = (unsigned short*)store_->arena.alloc_bytes(n * sizeof(unsigned short));
-                launch_f32_to_f16(c.w, d, (long long)n, nullptr);
-                it = store_->f16.emplace(c.w, d).first;
+                const size_t planes = prec == PREC_F16 ? 1 : 3;
+                unsigned short* d = (unsigned short*)store_->arena.alloc_bytes(planes * n * sizeof(unsigned short));
+                if (prec == PREC_F16) launch_f32_to_f16(c.w, d, (long long)n, nullptr);
+                else launch_f32_to_bf16x3(c.w, d, (long long)n, nullptr);
+                it = copies.emplace(c.w, d).first;
                 made = true;
             }
             c.w16 = it->second;
@@ -271,7 +321,7 @@ void Net::set_precision(int prec) {
         }
     }
     for (Op& op : ops_)
-        if (op.type == OP_CONV) op.conv.use_f16 = (prec == PREC_F16 && op.conv.w16 != nullptr) ? 1 : 0;
+        if (op.type == OP_CONV) op.conv.mfma_mode = (prec != PREC_F32 && op.conv.w16 != nullptr) ? prec : PREC_F32;
     precision_ = prec;
     ++plan_version_;
 }
@@ -360,7 +410,8 @@ int Net::profile(int batch, int iters, float* ms, int* info, int cap, hipStream_
             if (conv) {
                 choose_launch(ops_[i], batch, force_tile_, sk_target_, sk_min_chunks_, sk_max_splits_, &tile, &splits, &cps);
                 vec = conv_vec_mode(ops_[i].conv) ? 1 : 0;
-                if (ops_[i].conv.use_f16 && conv_f16_eligible(ops_[i].conv)) vec = 2;   // fp16-MFMA kernel
+                if (ops_[i].conv.mfma_mode != PREC_F32 && conv_f16_eligible(ops_[i].conv))
+                    vec = 1 + ops_[i].conv.mfma_mode;   // 2 fp16-MFMA kernel, 3 bf16x3 kernel
             }
             info[4 * i] = conv; info[4 * i + 1] = tile; info[4 * i + 2] = vec; info[4 * i + 3] = splits;
         }

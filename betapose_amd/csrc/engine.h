@@ -59,7 +59,8 @@ struct ConvWeights {   // one conv as it arrives in the stream (un-folded)
 struct WeightStore {
     Arena arena;
     std::vector<float*> ptrs;
-    std::map<const float*, unsigned short*> f16;   // fp16 copies of packed filters, made on first use
+    std::map<const float*, unsigned short*> f16;      // fp16 copies of packed filters, made on first use
+    std::map<const float*, unsigned short*> bf16x3;   // three bf16 planes per filter (PREC_BF16X3)
     std::mutex f16_mutex;
 };
 
@@ -73,7 +74,7 @@ public:
     void run_ops(int batch, hipStream_t s);
     void run_op(const Op& op, int batch, hipStream_t s);
     // eager profiling pass: mean device ms per op; info[i] = {is_conv, tile, kernel (0 scalar-gather fp32, 1 vector
-    // fp32, 2 fp16-MFMA), splits}
+    // fp32, 2 fp16-MFMA, 3 bf16x3), splits}
     int profile(int batch, int iters, float* ms, int* info, int cap, hipStream_t s);
     size_t device_bytes() const { return arena_.total_bytes(); }
     const std::vector<Op>& ops() const { return ops_; }
@@ -85,7 +86,7 @@ public:
     void set_splitk_policy(int target_blocks, int min_chunks) { sk_target_ = target_blocks; sk_min_chunks_ = min_chunks; ++plan_version_; }
     void set_max_splits(int m) { sk_max_splits_ = m; ++plan_version_; }
     void set_force_tile(int t) { force_tile_ = t; ++plan_version_; }
-    // PREC_F16: eligible convs (Cin % 32 == 0) run on the fp16 MFMA with fp16 copies of their filters
+    // PREC_F16 / PREC_BF16X3: eligible convs (Cin % 32 == 0) run on the 16-bit MFMA kernels with converted filter copies
     void set_precision(int prec);
     int precision() const { return precision_; }
     unsigned plan_version() const { return plan_version_; }

@@ -142,9 +142,10 @@ class FastPoseHIP:
         _lib.lib().bp_kpd_set_policy(self._h, sk_target_blocks, sk_min_chunks, sk_max_splits, force_tile)
 
     def set_precision(self, precision: str = "f32"):
-        """'f32' (default: fp32 MFMA, the parity configuration) or 'f16' (fp16 MFMA operands, fp32 accumulate)."""
+        """'f32' (fp32 MFMA), 'bf16x3' (fp32-accurate: exact 3-way bf16 operand split on the bf16 MFMA) or 'f16'
+        (fp16 operands, fp32 accumulate: carries fp16 rounding)."""
         self._ensure()
-        _lib.check(_lib.lib().bp_kpd_set_precision(self._h, {"f32": 0, "f16": 1}[precision]))
+        _lib.check(_lib.lib().bp_kpd_set_precision(self._h, {"f32": 0, "f16": 1, "bf16x3": 2}[precision]))
         self._precision = precision
         return self
 

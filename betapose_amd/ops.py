@@ -12,7 +12,7 @@ from . import _lib
 
 ACT = {"linear": 0, "leaky": 1, "relu": 2}
 STORE = {"nhwc": 0, "up2": 1, "pixshuf": 2, "nchw": 3}
-TILE = {"auto": -1, "64x64": 0, "128x64": 1, "64x64_f16": 16, "128x64_f16": 17}
+TILE = {"auto": -1, "64x64": 0, "128x64": 1, "64x64_f16": 16, "128x64_f16": 17, "64x64_b3": 32}
 
 
 def conv2d_nhwc(x, weight, bias=None, stride: int = 1, pad: int = 0, act: str = "linear", store: str = "nhwc",

@@ -98,9 +98,12 @@ int bp_kpd_tap_copy(bp_kpd* k, int i, int batch, float* d_out_nchw, void* stream
  * slices, forced tile (-1 auto) */
 int bp_yolo_set_policy(bp_yolo* y, int sk_target_blocks, int sk_min_chunks, int sk_max_splits, int force_tile);
 int bp_kpd_set_policy(bp_kpd* k, int sk_target_blocks, int sk_min_chunks, int sk_max_splits, int force_tile);
-/* operand precision of the matrix cores: 0 = fp32 MFMA (default; the parity configuration), 1 = fp16 MFMA for every
- * conv with Cin % 32 == 0 (fp16 copies of the filters are made on first use and shared by clones; activations and
- * accumulation stay fp32).  A pipeline re-captures its graph on the next run. */
+/* what the matrix cores multiply, for every conv with Cin % 32 == 0 (activations, accumulation and outputs are fp32 in
+ * all modes; converted filter copies are made on first use and shared by clones; a pipeline re-captures its graph):
+ *   0  fp32 MFMA (v_mfma_f32_32x32x2_f32);
+ *   1  fp16 operands, one fp16 MFMA per product (BASELINE configs[2]; results carry fp16 rounding, ~1e-3);
+ *   2  fp32-accurate on the bf16 pipe: operands split exactly into three bf16 terms, six partial products
+ *      (dropped terms <= 2^-23 relative, below the fp32 accumulation rounding). */
 int bp_yolo_set_precision(bp_yolo* y, int precision);
 int bp_kpd_set_precision(bp_kpd* k, int precision);
 /* per-op static description: returns number of ops; fills up to cap entries of (flops, bytes) per image */
@@ -127,7 +130,7 @@ int bp_resize_bicubic(const uint8_t* d_in, int batch, int H, int W, int oh, int 
 /* one fused convolution on device tensors (unit tests / kernel benchmarks).  h_w: host OIHW filter, h_bias host or NULL.
  * d_in NHWC [N,H,W,Cin]; d_out per store_mode (0 NHWC, 1 nearest-x2 NHWC, 2 PixelShuffle(2) NHWC, 3 NCHW);
  * act 0 linear / 1 leaky(0.1) / 2 relu; d_res NHWC residual or NULL; tile -1 auto, 0 = 64x64, 1 = 128x64, +16 = the
- * fp16-MFMA kernel on that tile; splits 0 auto. */
+ * fp16-MFMA kernel on that tile, 32 = the bf16x3 kernel (64x64); splits 0 auto. */
 int bp_conv2d(const float* d_in, int N, int H, int W, int Cin, const float* h_w, const float* h_bias, int Cout, int k,
               int stride, int pad, int act, int store_mode, const float* d_res, int res_after_act, int tile, int splits,
               float* d_out, int iters, float* ms_per_iter, void* stream);

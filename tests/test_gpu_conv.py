@@ -154,3 +154,28 @@ def test_conv_f16_rejects_ineligible_layer(cuda):
     w = torch.randn(8, 3, 3, 3)
     with pytest.raises(_lib.BetaposeHipError, match="not eligible"):
         ops.conv2d_nhwc(x.to(cuda), w, None, stride=1, pad=1, tile="64x64_f16")
+
+
+# ---- bf16x3 variant: fp32 operands split exactly into three bf16 terms, six partial products on the bf16 MFMA.
+# It must be AS ACCURATE AS the fp32-MFMA kernel: same tolerance against the fp32 conv, and its distance to an fp64
+# conv must not exceed the fp32 kernel's.
+@pytest.mark.parametrize("case", F16_CASES)
+@pytest.mark.parametrize("splits", [1, 3])
+def test_conv_bf16x3_is_fp32_accurate(cuda, case, splits):
+    N, H, W, Cin, Cout, k, st, pad, act = case
+    g = torch.Generator().manual_seed(500 + CASES.index(case))
+    x = torch.randn(N, H, W, Cin, generator=g) * torch.exp(2 * torch.randn(N, H, W, 1, generator=g))   # wide dynamic range
+    w = torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g)
+    if splits > 1 and Cin * k * k // 32 < 2 * splits:
+        pytest.skip("too few K-chunks to split")
+    ref64 = _ref(x.double(), w.double(), b.double(), st, pad, act, None, False)
+    ref32 = ref64.float()
+    out3 = ops.conv2d_nhwc(x.to(cuda), w, b, stride=st, pad=pad, act=act, tile="64x64_b3", splits=splits)
+    out32 = ops.conv2d_nhwc(x.to(cuda), w, b, stride=st, pad=pad, act=act, tile="64x64", splits=splits)
+    out3, out32 = out3.cpu().permute(0, 3, 1, 2), out32.cpu().permute(0, 3, 1, 2)
+    scale = float(ref64.abs().mean())
+    e3 = float((out3.double() - ref64).abs().max()) / scale
+    e32 = float((out32.double() - ref64).abs().max()) / scale
+    assert e3 <= max(1.5 * e32, 2e-6), (e3, e32)           # no less accurate than the fp32-MFMA kernel
+    _check(out3, ref32, tol=2e-5 * max(1.0, scale))

@@ -200,6 +200,7 @@ def test_kpd_batch_equals_single(kpd, cuda, pipe_gold):
 def test_f16_mode_yolo(cuda, pipe_gold):
     net = Darknet("yolo/cfg/yolov3-single.cfg", reso=416, max_batch=2).load_stream(helpers.yolo_stream()).cuda().eval()
     x = torch.cat([helpers.yolo_input_from_frame(f) for f in helpers.frames(2)])
+    net.set_precision("f32")
     p32 = net(x.to(cuda)).cpu()
     net.set_precision("f16")
     p16 = net(x.to(cuda)).cpu()
@@ -219,6 +220,7 @@ def test_f16_mode_kpd_batch28(cuda, pipe_gold):
     g = torch.Generator().manual_seed(11)
     inps = torch.cat(_crops_from_golden(pipe_gold, 4) +
                      [torch.rand(24, 3, 320, 256, generator=g) - 0.45])  # 4 golden crops + 24 seeded ones
+    kpd16.set_precision("f32")
     hm32 = kpd16(inps.to(cuda)).cpu()
     kpd16.set_precision("f16")
     hm16 = kpd16(inps.to(cuda)).cpu()
@@ -238,3 +240,27 @@ def test_f16_mode_kpd_batch28(cuda, pipe_gold):
     gold = np.stack([pipe_gold["f%d_kp_idx" % i] for i in range(4)])
     assert np.array_equal(a32[:4].numpy(), gold)
     assert int((a16[:4].numpy() != gold).sum()) <= 4                     # <= 2 % of the 200 golden key points
+
+
+# ---- bf16x3 mode: fp32 operands split exactly into three bf16 terms, six partial products on the bf16 MFMA, fp32
+# accumulation.  It is an fp32-accurate mode, so it is held to the SAME tolerances and integer-exactness as the fp32-MFMA
+# path against the oracle and the reference's golden vectors.
+def test_bf16x3_mode_meets_the_fp32_parity_bar(cuda, pipe_gold):
+    net = Darknet("yolo/cfg/yolov3-single.cfg", reso=416, max_batch=1).load_stream(helpers.yolo_stream()).cuda().eval()
+    net.set_precision("bf16x3")
+    blocks = helpers.yolo_blocks()
+    convs = W.split_darknet_stream(blocks, helpers.yolo_stream())
+    kpd3 = FastPoseHIP(helpers.kpd_state_dict(), n_classes=50, max_batch=1).cuda().eval()
+    kpd3.set_precision("bf16x3")
+    sd = helpers.kpd_state_dict()
+    crops = _crops_from_golden(pipe_gold, 4)
+    for i in range(4):
+        x = helpers.yolo_input_from_frame(helpers.frames()[i])
+        got = net(x.to(cuda)).cpu()
+        ref = yolo_ref.darknet_forward(blocks, convs, x)
+        assert _box_ok(got[0, :, :4].numpy(), ref[0, :, :4].numpy())
+        assert float((got[0, :, 4:] - ref[0, :, 4:]).abs().max()) <= PROB_TOL
+        assert int(got[0, :, 4].argmax()) == int(pipe_gold["f%d_obj_argmax" % i])
+        hm = kpd3(crops[i].to(cuda)).cpu()
+        assert float((hm - kpd_ref.fastpose_forward(sd, crops[i])).abs().max()) <= HM_TOL
+        assert np.array_equal(hm.view(50, -1).argmax(1).numpy(), pipe_gold["f%d_kp_idx" % i])

@@ -46,7 +46,8 @@ for planes, nb, st in W.FASTPOSE_STAGES:
 add(20, 16, 512, 1024, 3, 1); add(40, 32, 256, 512, 3, 1); add(80, 64, 128, 50, 3, 1)
 
 F16 = "--f16" in sys.argv          # tune the fp16-MFMA kernel instead
-TILE = "64x64_f16" if F16 else "64x64"
+B3 = "--b3" in sys.argv            # ... or the bf16x3 kernel
+TILE = "64x64_f16" if F16 else ("64x64_b3" if B3 else "64x64")
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
 print("// {M, CoutPad, nchunks, splits}  (count, us_best, us_default)")
