@@ -200,22 +200,23 @@ def roofline(det, pose, batch):
     # HBM traffic per launch of that kernel: not measurable from inside the process -- taken from the committed
     # rocprofv3 PMC passes (profiles/*_pmc_traffic.json, collected with tools/pmc_traffic.sh, corrections inside)
     traffic, traffic_src = None, None
+    mode = {2: "f16", 3: "bf16x3"}.get(key[1], "f32")
+    want = "bp::conv_igemm_kernel<%s" % TILE_NAMES.get(key[0], "?") if mode == "f32" else \
+        "bp::conv_igemm_h_kernel<%s, %d>" % (TILE_NAMES.get(key[0], "?"), 1 if mode == "f16" else 3)
     try:
         import glob
-        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[::-1]:
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic*.json")))[::-1]:
             t = json.load(open(f))
-            if t.get("kernel", "").startswith("bp::conv_igemm_kernel<%s" % TILE_NAMES.get(key[0], "?")):
+            if t.get("kernel", "").startswith(want):
                 traffic, traffic_src = t["traffic_bytes_per_launch"], os.path.relpath(f, ROOT)
                 break
     except Exception:
         pass
-    mode = {2: "f16", 3: "bf16x3"}.get(key[1], "f32")
     peak = PEAK_FP32_MFMA_TFLOPS if mode == "f32" else PEAK_F16_MFMA_TFLOPS
     if mode == "f32":
         name = "bp::conv_igemm_kernel<%s, %d>" % (TILE_NAMES.get(key[0], "?"), key[1])
     else:
         name = "bp::conv_igemm_h_kernel<%s, %d>" % (TILE_NAMES.get(key[0], "?"), 1 if mode == "f16" else 3)
-        traffic, traffic_src = None, None     # the committed PMC passes are of the fp32 kernel
     extra = {}
     if mode == "bf16x3":
         # six bf16 partial products per algorithmic multiply: the matrix cores execute 6x the algorithmic FLOPs

@@ -1,5 +1,10 @@
+#!/bin/bash
+# HBM-side traffic of the conv kernels: two separate rocprofv3 PMC passes (kernel-trace only), then the summary JSON.
+#   tools/pmc_traffic.sh [extra bench.py args, e.g. --precision f16] ; output: gpurun_out/pmc_traffic.json
+EXTRA="$*"
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-rocprofv3 --pmc $C --kernel-trace --output-format csv -d /root/repo/gpurun_out/pmc_$C -o p -- python /root/repo/bench.py --steps 20 --warmup 2 --no-roofline --no-cpu-baseline --streams 1 > /dev/null 2>&1
+  rm -rf /root/repo/gpurun_out/pmc_$C
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d /root/repo/gpurun_out/pmc_$C -o p -- python /root/repo/bench.py --steps 20 --warmup 2 --no-roofline --no-cpu-baseline --streams 1 $EXTRA > /dev/null 2>&1
 done
-ls /root/repo/gpurun_out/pmc_FETCH_SIZE /root/repo/gpurun_out/pmc_WRITE_SIZE
+cd /root/repo && BP_BENCH_EXTRA="$EXTRA" python tools/pmc_traffic_summarize.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/pmc_traffic.json
