@@ -69,6 +69,16 @@ PROTOTYPES = {
     "bp_pipeline_set_fixed_box": (C.c_int, [vp, vp]),
     "bp_pipeline_run": (C.c_int, [vp, C.c_int, vp]),
     "bp_solve_pnp": (C.c_int, [vp, vp, C.c_int, vp, vp, vp]),
+    "bp_darknet_last_error": (C.c_char_p, []),
+    "bp_darknet_create": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(vp)]),
+    "bp_darknet_destroy": (None, [vp]),
+    "bp_darknet_width": (C.c_int, [vp]),
+    "bp_darknet_height": (C.c_int, [vp]),
+    "bp_darknet_classes": (C.c_int, [vp]),
+    "bp_darknet_detect_rgb": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, C.c_float, vp, C.c_int]),
+    "bp_darknet_detect_png": (C.c_int, [vp, vp, C.c_size_t, C.c_float, C.c_float, vp, C.c_int]),
+    "bp_darknet_detect_file": (C.c_int, [vp, C.c_char_p, C.c_float, C.c_float, vp, C.c_int]),
+    "bp_yolo_create_darknet": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
     "bp_stream_create_masked": (C.c_int, [vp, C.c_int, C.POINTER(vp)]),
     "bp_stream_destroy": (C.c_int, [vp]),
     "bp_probe_placement": (C.c_int, [C.c_int, vp, vp, vp]),

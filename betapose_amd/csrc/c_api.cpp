@@ -158,9 +158,7 @@ int bp_yolo_create_from_memory(const char* cfg_text, const float* stream, size_t
     BP_CATCH
 }
 
-int bp_yolo_create(const char* cfg_path, const char* weights_path, int reso, int max_batch, int device, bp_yolo** out) {
-    BP_TRY
-    const std::string cfg = read_text(cfg_path);
+static std::vector<float> read_weights_file(const char* weights_path) {
     std::ifstream f(weights_path, std::ios::binary);
     if (!f) throw bp::Error(std::string("cannot open ") + weights_path);
     f.seekg(0, std::ios::end);
@@ -175,7 +173,31 @@ int bp_yolo_create(const char* cfg_path, const char* weights_path, int reso, int
     std::vector<float> stream((bytes - off) / 4);
     f.seekg(off);
     f.read(reinterpret_cast<char*>(stream.data()), bytes - off);
+    return stream;
+}
+
+int bp_yolo_create(const char* cfg_path, const char* weights_path, int reso, int max_batch, int device, bp_yolo** out) {
+    BP_TRY
+    BP_CHECK(cfg_path && weights_path && out, "null argument");
+    const std::string cfg = read_text(cfg_path);
+    const std::vector<float> stream = read_weights_file(weights_path);
     return bp_yolo_create_from_memory(cfg.c_str(), stream.data(), stream.size(), reso, max_batch, device, out);
+    BP_CATCH
+}
+
+int bp_yolo_create_darknet(const char* cfg_path, const char* weights_path, int reso, int max_batch, int device,
+                           bp_yolo** out) {
+    BP_TRY
+    BP_CHECK(cfg_path && weights_path && out, "null argument");
+    const std::string cfg = read_text(cfg_path);
+    const std::vector<float> stream = read_weights_file(weights_path);
+    BP_HIP(hipSetDevice(device));
+    std::unique_ptr<bp_yolo> y(new bp_yolo);
+    y->device = device;
+    y->net.reset(new bp::YoloNet(cfg, stream.data(), stream.size(), reso, max_batch, nullptr, /*darknet_bn=*/true));
+    if (default_precision() != bp::PREC_F32) y->net->set_precision(default_precision());
+    *out = y.release();
+    return 0;
     BP_CATCH
 }
 

@@ -227,7 +227,8 @@ int Net::add_conv(const std::string& name, const Tensor& in, const Tensor& out_v
         for (int co = 0; co < Cout; ++co) {
             double s = 1.0, b = 0.0;
             if (cw.bn_scale) {
-                s = (double)cw.bn_scale[co] / std::sqrt((double)cw.bn_var[co] + (double)bn_eps);
+                s = darknet_bn_ ? (double)cw.bn_scale[co] / (std::sqrt((double)cw.bn_var[co]) + 1e-6)
+                                : (double)cw.bn_scale[co] / std::sqrt((double)cw.bn_var[co] + (double)bn_eps);
                 b = (double)cw.bn_bias[co] - (double)cw.bn_mean[co] * s;
             } else if (cw.bias) {
                 b = cw.bias[co];
@@ -478,8 +479,9 @@ static std::vector<int> parse_ints(const std::string& s) {
 
 // ------------------------------------------------------------------ YoloNet
 YoloNet::YoloNet(const std::string& cfg_text, const float* stream, size_t n_floats, int reso, int max_batch,
-                 std::shared_ptr<WeightStore> store)
+                 std::shared_ptr<WeightStore> store, bool darknet_bn)
     : Net(max_batch, store), cfg_text_(cfg_text), n_floats_(n_floats), reso_(reso) {
+    darknet_bn_ = darknet_bn;
     BP_CHECK(reso % 32 == 0 && reso > 32, "reso must be a multiple of 32 and > 32 (dataloader.py:298-299)");
     const std::vector<CfgBlock> L = parse_cfg(cfg_text);
     const int n = (int)L.size();

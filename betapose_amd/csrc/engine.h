@@ -115,15 +115,18 @@ protected:
     size_t tickets_count_ = 0;
     int sk_target_ = 512, sk_min_chunks_ = 4, sk_max_splits_ = 8;
     int force_tile_ = -1;
+    bool darknet_bn_ = false;
     int precision_ = PREC_F32;
     unsigned plan_version_ = 0;   // bumped whenever launches would change (captured graphs must be rebuilt)
 };
 
 class YoloNet : public Net {
 public:
+    // darknet_bn: fold BatchNorm the Darknet-C way, scale / (sqrt(var) + 1e-6) (blas.c:136, network.c:827-834), instead
+    // of PyTorch's scale / sqrt(var + 1e-5) (yolo/darknet.py:256) -- for the Darknet-API-compatible detector
     YoloNet(const std::string& cfg_text, const float* stream, size_t n_floats, int reso, int max_batch,
-            std::shared_ptr<WeightStore> store = nullptr);
-    YoloNet* clone() const { return new YoloNet(cfg_text_, nullptr, n_floats_, reso_, max_batch_, store_); }
+            std::shared_ptr<WeightStore> store = nullptr, bool darknet_bn = false);
+    YoloNet* clone() const { return new YoloNet(cfg_text_, nullptr, n_floats_, reso_, max_batch_, store_, darknet_bn_); }
     int rows() const { return rows_; }
     int attrs() const { return attrs_; }
     int reso() const { return reso_; }

@@ -153,6 +153,33 @@ int bp_pipeline_run(bp_pipeline* p, int use_graph, void* stream);
  * pts3d [n][3], pts2d [n][2], K [9] row-major; outputs R [9] row-major, t [3]. */
 int bp_solve_pnp(const double* pts3d, const double* pts2d, int n, const double* K, double* R, double* t);
 
+/* ---- Darknet-API-compatible detector (replaces the reference's CPU/CUDA Detector, train_YOLO/src/yolo_v2_class.cpp) ----
+ * cfg WITH a [net] block (width == height); BatchNorm folded the Darknet-C way; detections as Detector::detect makes
+ * them: candidates with objectness > thresh, prob = objectness * class probability, per-class NMS, boxes in image
+ * pixels.  The six yolo_v2_class symbols themselves are declared in include/yolo_v2_class_compat.h. */
+typedef struct bp_darknet bp_darknet;
+typedef struct bp_bbox {
+    unsigned int x, y, w, h;
+    float prob;
+    unsigned int obj_id, track_id, frames_counter;
+} bp_bbox;
+const char* bp_darknet_last_error(void);
+int bp_darknet_create(const char* cfg_path, const char* weights_path, int device, bp_darknet** out);
+void bp_darknet_destroy(bp_darknet* d);
+int bp_darknet_width(const bp_darknet* d);
+int bp_darknet_height(const bp_darknet* d);
+int bp_darknet_classes(const bp_darknet* d);
+/* planar_rgb: host [3][h][w] floats 0..1 (Darknet's `image`).  Returns the number of detections (the first `cap` are
+ * written to out), < 0 on error. */
+int bp_darknet_detect_rgb(bp_darknet* d, const float* planar_rgb, int w, int h, float thresh, float nms, bp_bbox* out,
+                          int cap);
+int bp_darknet_detect_png(bp_darknet* d, const unsigned char* png, size_t n, float thresh, float nms, bp_bbox* out,
+                          int cap);
+int bp_darknet_detect_file(bp_darknet* d, const char* png_path, float thresh, float nms, bp_bbox* out, int cap);
+/* detector engine from a Darknet cfg/.weights pair with Darknet-C BatchNorm folding (used by bp_darknet_create) */
+int bp_yolo_create_darknet(const char* cfg_path, const char* weights_path, int reso, int max_batch, int device,
+                           bp_yolo** out);
+
 /* ---- HIP streams confined to a subset of the CUs (one frame pipeline per XCD) ---- */
 /* cu_mask: `words` x 32 bits, bit i = CU i of the device in the driver's numbering (on MI355X bit i lies on XCD i % 8,
  * checked by bp_probe_placement).  The stream is a plain hipStream_t (void*) usable with every call above. */

@@ -87,3 +87,46 @@ class DarknetC:
             off += g * g * n_anchor
         assert off == n
         return np.concatenate(rows)
+
+    def detect(self, img_chw: np.ndarray, thresh: float = 0.2, nms: float = 0.4):
+        """The reference's ``Detector::detect`` chain (yolo_v2_class.cpp:239-317) through its own C functions:
+        ``network_predict_image`` (resize_image + network_predict, network.c:652-660) -> ``get_network_boxes`` with
+        relative boxes -> ``do_nms_sort`` (box.c:331) -> bbox conversion restated from yolo_v2_class.cpp:293-311.
+        ``img_chw``: f32 [3,h,w] RGB 0..1 at the IMAGE's size.  Returns [(x, y, w, h, prob, obj_id)]."""
+        img = np.ascontiguousarray(img_chw, dtype=np.float32)
+        _, h, w = img.shape
+        L = self.lib
+        L.do_nms_sort.argtypes = [C.POINTER(_Detection), C.c_int, C.c_int, C.c_float]
+        L.do_nms_sort.restype = None
+        im = _Image(w, h, 3, img.ctypes.data_as(C.POINTER(C.c_float)))
+        L.network_predict_image(self.net, im)
+        num = C.c_int(0)
+        dets = L.get_network_boxes(self.net, w, h, float(thresh), 0.5, None, 1, C.byref(num), 0)
+        n = num.value
+        out = []
+        if n:
+            classes = dets[0].classes
+            if nms:
+                L.do_nms_sort(dets, n, classes, float(nms))
+            for i in range(n):
+                d = dets[i]
+                probs = [d.prob[c] for c in range(classes)]
+                obj_id = int(np.argmax(probs))
+                prob = probs[obj_id]
+                if prob > thresh:
+                    b = d.bbox
+                    out.append((int(max(0.0, (b.x - b.w / 2.) * w)), int(max(0.0, (b.y - b.h / 2.) * h)),
+                                int(np.float32(b.w) * np.float32(w)), int(np.float32(b.h) * np.float32(h)), float(prob), obj_id))
+        L.free_detections(dets, n)
+        return out
+
+    def load_image(self, path: str) -> np.ndarray:
+        """``load_image_color`` (image.c: stb decode -> planar RGB float / 255)."""
+        L = self.lib
+        L.load_image_color.restype = _Image
+        L.load_image_color.argtypes = [C.c_char_p, C.c_int, C.c_int]
+        L.free_image.argtypes = [_Image]
+        im = L.load_image_color(path.encode(), 0, 0)
+        arr = np.ctypeslib.as_array(im.data, shape=(im.c, im.h, im.w)).copy()
+        L.free_image(im)
+        return arr

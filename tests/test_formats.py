@@ -124,6 +124,13 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
     assert lib.bp_version() >= 100
     assert isinstance(lib.bp_last_error(), bytes)
+    # include/yolo_v2_class_compat.h: the reference's six Darknet-library entry points (yolo_v2_class.hpp:49-54)
+    compat = open(os.path.join(ROOT, "include", "yolo_v2_class_compat.h")).read()
+    compat = re.sub(r"/\*.*?\*/", "", compat, flags=re.S)
+    names = set(re.findall(r'extern "C" int (\w+)\(', compat))
+    assert names == {"init", "detect_image", "detect_mat", "dispose", "get_device_count", "get_device_name"}
+    for name in names:
+        assert hasattr(lib, name), "libbetapose_hip.so does not export %s" % name
 
 
 def test_product_path_fails_loudly_without_gpu():
