@@ -43,6 +43,9 @@ def parse_args():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--fixed-box", action="store_true", help="deterministic crop box (220,140,420,340)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--other-modes", default="bf16x3,f16",
+                    help="N=1 only: after the timed region, also time a short run of these matrix-core operand modes on "
+                         "the same workload and report them under \"other_precisions\" (never as \"value\"); '' = skip")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--partition", type=int, default=0,
                     help="give each of the --streams frames in flight its own 1/PARTITION slice of the CUs of every "
@@ -373,6 +376,28 @@ def main():
         agg = gf * a.steps * world / el / 1e3 / world
         out["roofline"]["timed_region"] = {"achieved_per_gpu": round(agg, 2), "frac": round(agg / out["roofline"]["peak"], 4),
                                            "unit": "TFLOP/s"}
+    if rank == 0 and world == 1 and a.other_modes:
+        # the opt-in precisions on the same workload, for the record: 4 frames in flight, same
+        # graph pipeline (re-captured on the precision change), a short timed run each
+        other = {}
+        for mode in [m for m in a.other_modes.split(",") if m and m != a.precision]:
+            for d, p_ in zip(dets, poses):
+                d.set_precision(mode)
+                p_.set_precision(mode)
+            n_alt = min(a.steps, 120)
+            run(max(2 * S, 8), False)
+            torch.cuda.synchronize()
+            t_alt = time.perf_counter()
+            run(n_alt, False)
+            torch.cuda.synchronize()
+            other[mode] = {"value": round(n_alt * a.batch / (time.perf_counter() - t_alt), 2), "unit": "frames/sec",
+                           "steps": n_alt}
+        for d, p_ in zip(dets, poses):
+            d.set_precision(a.precision)
+            p_.set_precision(a.precision)
+        other["note"] = ("bf16x3 = fp32-accurate (exact 3-way bf16 operand split, passes the whole parity suite); "
+                         "f16 = fp16 operands (stated-tolerance mode, BASELINE configs[2])")
+        out["other_precisions"] = other
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.cpu_seconds, kp3d, cam_K)
     if rank == 0:
