@@ -249,12 +249,14 @@ static int tap_info(const bp::Net& n, int i, char* name, int cap, int* C, int* H
     n.tap_shape(i, C, H, W);
     return 0;
 }
-int bp_yolo_tap_count(const bp_yolo* y) { return y->net->tap_count(); }
+int bp_yolo_tap_count(const bp_yolo* y) { return y ? y->net->tap_count() : -1; }
 int bp_yolo_tap_info(const bp_yolo* y, int i, char* name, int cap, int* C, int* H, int* W) {
+    if (!y || !C || !H || !W) { g_err = "null argument"; return -1; }
     return tap_info(*y->net, i, name, cap, C, H, W);
 }
 int bp_yolo_tap_copy(bp_yolo* y, int i, int batch, float* d_out, void* stream) {
     BP_TRY
+    BP_CHECK(y && d_out, "null argument");
     y->net->tap_copy(i, batch, d_out, (hipStream_t)stream);
     return 0;
     BP_CATCH
@@ -300,40 +302,54 @@ int bp_kpd_forward_argmax(bp_kpd* k, const float* d_inps, int batch, float* d_hm
     return 0;
     BP_CATCH
 }
-int bp_kpd_tap_count(const bp_kpd* k) { return k->net->tap_count(); }
+int bp_kpd_tap_count(const bp_kpd* k) { return k ? k->net->tap_count() : -1; }
 int bp_kpd_tap_info(const bp_kpd* k, int i, char* name, int cap, int* C, int* H, int* W) {
+    if (!k || !C || !H || !W) { g_err = "null argument"; return -1; }
     return tap_info(*k->net, i, name, cap, C, H, W);
 }
 int bp_kpd_tap_copy(bp_kpd* k, int i, int batch, float* d_out, void* stream) {
     BP_TRY
+    BP_CHECK(k && d_out, "null argument");
     k->net->tap_copy(i, batch, d_out, (hipStream_t)stream);
     return 0;
     BP_CATCH
 }
 
 int bp_yolo_set_policy(bp_yolo* y, int t, int mc, int ms, int ft) {
+    BP_TRY
+    BP_CHECK(y, "null argument");
+    BP_CHECK(t >= 1 && mc >= 1 && ms >= 1 && ft >= -1 && ft <= bp::TILE_128x64, "policy values out of range");
     y->net->set_splitk_policy(t, mc);
     y->net->set_max_splits(ms);
     y->net->set_force_tile(ft);
     return 0;
+    BP_CATCH
 }
 int bp_yolo_set_precision(bp_yolo* y, int prec) {
     BP_TRY
+    BP_CHECK(y, "null argument");
+    BP_HIP(hipSetDevice(y->device));
     y->net->set_precision(prec);
     return 0;
     BP_CATCH
 }
 int bp_kpd_set_precision(bp_kpd* k, int prec) {
     BP_TRY
+    BP_CHECK(k, "null argument");
+    BP_HIP(hipSetDevice(k->device));
     k->net->set_precision(prec);
     return 0;
     BP_CATCH
 }
 int bp_kpd_set_policy(bp_kpd* k, int t, int mc, int ms, int ft) {
+    BP_TRY
+    BP_CHECK(k, "null argument");
+    BP_CHECK(t >= 1 && mc >= 1 && ms >= 1 && ft >= -1 && ft <= bp::TILE_128x64, "policy values out of range");
     k->net->set_splitk_policy(t, mc);
     k->net->set_max_splits(ms);
     k->net->set_force_tile(ft);
     return 0;
+    BP_CATCH
 }
 static int op_stats(const bp::Net& n, double* flops, double* bytes, int cap) {
     const auto& ops = n.ops();
@@ -542,11 +558,11 @@ int bp_pipeline_create(bp_yolo* y, bp_kpd* k, int frame_h, int frame_w, int batc
     BP_CATCH
 }
 void bp_pipeline_destroy(bp_pipeline* p) { delete p; }
-uint8_t* bp_pipeline_frames(bp_pipeline* p) { return p->frames; }
-float* bp_pipeline_results(bp_pipeline* p) { return p->results; }
-float* bp_pipeline_heatmaps(bp_pipeline* p) { return p->hm; }
+uint8_t* bp_pipeline_frames(bp_pipeline* p) { return p ? p->frames : nullptr; }
+float* bp_pipeline_results(bp_pipeline* p) { return p ? p->results : nullptr; }
+float* bp_pipeline_heatmaps(bp_pipeline* p) { return p ? p->hm : nullptr; }
 int bp_pipeline_kernel_count(bp_pipeline* p) {
-    if (!p->graph) return -1;
+    if (!p || !p->graph) return -1;
     size_t n = 0;
     if (hipGraphGetNodes(p->graph, nullptr, &n) != hipSuccess) return -1;
     return (int)n;

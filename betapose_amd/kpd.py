@@ -139,7 +139,7 @@ class FastPoseHIP:
     def set_policy(self, sk_target_blocks: int = 512, sk_min_chunks: int = 4, sk_max_splits: int = 8,
                    force_tile: int = -1):
         self._ensure()
-        _lib.lib().bp_kpd_set_policy(self._h, sk_target_blocks, sk_min_chunks, sk_max_splits, force_tile)
+        _lib.check(_lib.lib().bp_kpd_set_policy(self._h, sk_target_blocks, sk_min_chunks, sk_max_splits, force_tile))
 
     def set_precision(self, precision: str = "f32"):
         """'f32' (fp32 MFMA), 'bf16x3' (fp32-accurate: exact 3-way bf16 operand split on the bf16 MFMA) or 'f16'
