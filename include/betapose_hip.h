@@ -23,6 +23,12 @@
  *   bp_pipeline_*          DetectionLoader.update -> DetectionProcessor.update -> main loop
  *                          (dataloader.py:330-401,438-457; betapose_evaluate.py:145-176) fused on device
  *   bp_solve_pnp           pnp (cv2.solvePnP + cv2.Rodrigues)                 utils/utils.py:17-41
+ *   bp_png_*, bp_loader_*  cv2.imread on ImageLoader's thread (PNG frames)   dataloader.py:150-179
+ *   bp_upload              the H2D of a frame (img.cuda())                    dataloader.py:339
+ *   bp_darknet_*           Detector(cfg, weights, gpu) / Detector::detect    train_YOLO/src/yolo_v2_class.cpp:95-317
+ *                          (+ init/detect_image/detect_mat/dispose: include/yolo_v2_class_compat.h)
+ *   bp_*_set_precision, bp_*_set_policy, bp_stream_create_masked, bp_probe_placement, bp_conv2d, bp_*_tap_*,
+ *   bp_*_profile, bp_*_op_stats: no reference counterpart (tuning, measurement and test hooks)
  *
  * Weight streams.  "YOLO stream" = payload of a Darknet .weights file after its
  * header (train_YOLO/src/parser.c:1148-1174): per [convolutional] block in cfg order
