@@ -64,6 +64,34 @@ def test_crop_edge_boxes_vs_oracle(cuda, box):
     assert float((got.cpu() - ref).abs().max()) <= 2e-6
 
 
+def test_crop_random_box_sweep_vs_oracle(cuda):
+    """240 seeded boxes of every flavour -- tiny, huge, partly or wholly outside the frame, fractional corners, the
+    w == 100 px pad-rule boundary -- in one batched launch against the oracle's per-box crop_from_dets."""
+    rng = np.random.default_rng(42)
+    fr = helpers.frames()[2]
+    boxes = []
+    for _ in range(200):
+        cx, cy = rng.uniform(-50, 690), rng.uniform(-50, 530)
+        w, h = np.exp(rng.uniform(np.log(2), np.log(700))), np.exp(rng.uniform(np.log(2), np.log(500)))
+        boxes.append([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2])
+    for w in (99.0, 99.999, 100.0, 100.001, 101.0):                    # scaleRate switches at width 100 (dataloader.py:811)
+        for x0 in (0.0, 33.3, 539.5, 560.0):
+            boxes.append([x0, 120.25, x0 + w, 300.5])
+    for _ in range(20):                                                 # integer-cornered boxes
+        x0, y0 = rng.integers(0, 600), rng.integers(0, 440)
+        boxes.append([float(x0), float(y0), float(x0 + rng.integers(1, 200)), float(y0 + rng.integers(1, 200))])
+    b = torch.tensor(boxes, dtype=torch.float32)
+    n = len(boxes)
+    got, pts = ops.crop(torch.from_numpy(np.repeat(fr[None], n, 0)).to(cuda), boxes=b.to(cuda))
+    got, pts = got.cpu(), pts.cpu().numpy()
+    worst = 0.0
+    for i in range(n):
+        ref, pt1, pt2 = post_ref.crop_from_dets_frame(fr, b[i:i + 1])
+        np.testing.assert_array_equal(pts[i, :4], np.r_[pt1.numpy()[0], pt2.numpy()[0]], err_msg=str(boxes[i]))
+        worst = max(worst, float((got[i] - ref[0]).abs().max()))
+    assert worst <= 2e-6, worst
+
+
 @pytest.fixture(scope="module")
 def engines(cuda):
     det = Darknet("yolo/cfg/yolov3-single.cfg", reso=416, max_batch=4).load_stream(helpers.yolo_stream()).cuda()
