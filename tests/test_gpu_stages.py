@@ -155,3 +155,54 @@ def test_pipeline_fixed_box(engines, cuda):
     fp.set_fixed_box(None)
     rec2 = fp.run(helpers.frames()[0])[0]
     assert not np.allclose(rec2[12:16], [220, 140, 420, 340])
+
+
+def test_select_random_predictions_vs_oracle(cuda):
+    """dynamic_write_results on 60 seeded prediction tensors against the oracle's write_results: multi-class rows whose
+    arg-max class is not 0 (dropped by the reference), ties on objectness (first index wins), images without any row
+    above the threshold, batches mixing all of these."""
+    from betapose_amd.yolo_util import dynamic_write_results
+    from oracle import yolo_ref
+    rng = np.random.default_rng(7)
+    for trial in range(60):
+        B = int(rng.integers(1, 5))
+        rows = int(rng.choice([17, 507, 2535]))
+        ncls = int(rng.choice([1, 3]))
+        pred = np.zeros((B, rows, 5 + ncls), np.float32)
+        pred[..., 0:2] = rng.uniform(0, 416, (B, rows, 2))
+        pred[..., 2:4] = rng.uniform(2, 300, (B, rows, 2))
+        pred[..., 4] = rng.uniform(0, 1, (B, rows)) ** 3
+        pred[..., 5:] = rng.uniform(0, 1, (B, rows, ncls))
+        conf = float(rng.choice([0.01, 0.5, 0.9]))
+        if trial % 4 == 0:                                    # an image with nothing above the threshold
+            pred[0, :, 4] *= conf * 0.5
+        tied = trial % 5 == 0
+        if tied:                                              # exact ties on the best objectness
+            b = int(rng.integers(0, B))
+            top = pred[b, :, 4].max()
+            for j in rng.choice(rows, 3, replace=False):
+                pred[b, j, 4] = top
+        t = torch.from_numpy(pred)
+        want = yolo_ref.write_results(t.clone(), conf, 80)
+        got = dynamic_write_results(t.to(cuda), conf, 80)
+        if isinstance(want, int):
+            assert isinstance(got, int) and got == 0, (trial, got)
+            continue
+        assert not isinstance(got, int), trial
+        assert got.shape == want.shape, (trial, got.shape, want.shape)
+        g, w_ = got.cpu().numpy(), want.numpy()
+        if not tied:
+            np.testing.assert_allclose(g, w_, rtol=1e-6, atol=1e-5, err_msg="trial %d" % trial)
+            continue
+        # exact ties: the reference ranks with an unstable torch.sort (util.py:175-181), so WHICH of the tied rows it
+        # returns is unspecified; here the first one in row order wins.  Both must return a tied row of class 0.
+        np.testing.assert_allclose(g[:, [0, 5]], w_[:, [0, 5]], rtol=1e-6, err_msg="trial %d" % trial)
+        for r in g:
+            img = pred[int(r[0])]
+            ok = (img[:, 4] == r[5]) & (img[:, 5:].argmax(1) == 0)
+            cand = img[ok]
+            corners = np.stack([cand[:, 0] - cand[:, 2] / 2, cand[:, 1] - cand[:, 3] / 2, cand[:, 0] + cand[:, 2] / 2,
+                                cand[:, 1] + cand[:, 3] / 2], 1)
+            d = np.abs(corners - r[1:5]).max(1)
+            assert d.min() < 1e-3, trial
+            assert d.argmin() == 0, "first tied row in row order must win (trial %d)" % trial
