@@ -375,6 +375,7 @@ __global__ __launch_bounds__(256) void heatmap_argmax_kernel(const float* __rest
     if (threadIdx.x == 0) {
         for (int k = 1; k < 4; ++k)
             if (sv[k] > best || (sv[k] == best && si[k] < bi)) { best = sv[k]; bi = si[k]; }
+        if (bi < 0 || bi >= HW) { bi = 0; best = P[0]; }   // no element compared greater (all -inf / NaN): stay in bounds
         float* o = out + (long long)blockIdx.x * 6;
         const int x = bi % W, y = bi / W;
         o[0] = __int_as_float(bi);

@@ -409,6 +409,15 @@ int bp_resize_bicubic(const uint8_t* d_in, int batch, int H, int W, int oh, int 
     BP_CATCH
 }
 
+int bp_heatmap_argmax(const float* d_hm, int batch, int C, int H, int W, float* d_kp, void* stream) {
+    BP_TRY
+    BP_CHECK(d_hm && d_kp && batch > 0 && C > 0 && H > 0 && W > 0, "bad argument");
+    bp::launch_heatmap_argmax(d_hm, batch, C, H, W, d_kp, (hipStream_t)stream);
+    BP_HIP(hipGetLastError());
+    return 0;
+    BP_CATCH
+}
+
 int bp_conv2d(const float* d_in, int N, int H, int W, int Cin, const float* h_w, const float* h_bias, int Cout, int k,
               int stride, int pad, int act, int store_mode, const float* d_res, int res_after_act, int tile, int splits,
               float* d_out, int iters, float* ms_per_iter, void* stream) {

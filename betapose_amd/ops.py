@@ -93,3 +93,14 @@ def solve_pnp(points_3d, points_2d, K):
     _lib.check(_lib.lib().bp_solve_pnp(p3.ctypes.data, p2.ctypes.data, p3.shape[0], Kc.ctypes.data, R.ctypes.data,
                                        t.ctypes.data))
     return R, t.reshape(3, 1)
+
+
+def heatmap_argmax(hm):
+    """Device arg-max records of a heat-map tensor: cuda f32 [B,K,H,W] -> [B,K,6] (idx as int bits, max, l, r, u, d)."""
+    import torch
+    _lib.require_gpu()
+    hm = hm.contiguous().float()
+    B, K, H, W = hm.shape
+    kp = torch.empty((B, K, 6), device=hm.device, dtype=torch.float32)
+    _lib.check(_lib.lib().bp_heatmap_argmax(hm.data_ptr(), B, K, H, W, kp.data_ptr(), _lib.current_stream()))
+    return kp

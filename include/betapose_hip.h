@@ -133,6 +133,10 @@ int bp_crop(const uint8_t* d_frames, int batch, int H, int W, const float* d_sel
  * d_out_nhwc f32 /255 (nullable).  swap_rb: read BGR, write RGB. */
 int bp_resize_bicubic(const uint8_t* d_in, int batch, int H, int W, int oh, int ow, int swap_rb, uint8_t* d_out_u8,
                       float* d_out_nhwc, void* stream);
+/* the arg-max half of getPrediction on an existing heat-map tensor (KPD/src/utils/eval.py:113-131): d_hm [batch][C][H][W]
+ * -> d_kp [batch][C][6] = (flat arg-max index as int bits -- first maximum wins --, max, left, right, up, down; the four
+ * neighbours are 0 when the maximum lies on the border) */
+int bp_heatmap_argmax(const float* d_hm, int batch, int C, int H, int W, float* d_kp, void* stream);
 /* one fused convolution on device tensors (unit tests / kernel benchmarks).  h_w: host OIHW filter, h_bias host or NULL.
  * d_in NHWC [N,H,W,Cin]; d_out per store_mode (0 NHWC, 1 nearest-x2 NHWC, 2 PixelShuffle(2) NHWC, 3 NCHW);
  * act 0 linear / 1 leaky(0.1) / 2 relu; d_res NHWC residual or NULL; tile -1 auto, 0 = 64x64, 1 = 128x64, +16 = the

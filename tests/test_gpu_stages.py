@@ -206,3 +206,42 @@ def test_select_random_predictions_vs_oracle(cuda):
             d = np.abs(corners - r[1:5]).max(1)
             assert d.min() < 1e-3, trial
             assert d.argmin() == 0, "first tied row in row order must win (trial %d)" % trial
+
+
+def test_heatmap_argmax_random_maps_vs_oracle(cuda):
+    """The arg-max half of getPrediction on seeded heat-maps with the awkward cases planted: maxima on every border and
+    corner (no quarter-pixel shift there), exact ties (first pixel wins, as torch.max on CPU), maps that are <= 0
+    everywhere (key point zeroed), flat neighbourhoods (sign(0) = 0).  Compared through the whole decode against the
+    oracle's get_prediction."""
+    from betapose_amd.eval import decode_keypoints
+    rng = np.random.default_rng(11)
+    n, K, H, W = 6, 50, 80, 64
+    hm = rng.normal(0, 0.3, (n, K, H, W)).astype(np.float32)
+    for k, (y, x) in enumerate([(0, 0), (0, 63), (79, 0), (79, 63), (0, 30), (79, 31), (40, 0), (41, 63)]):
+        hm[0, k, y, x] = 5.0                                   # border / corner maxima
+    for k in range(8, 16):                                     # exact ties: two equal maxima, the earlier pixel wins
+        a, b = sorted(rng.choice(H * W, 2, replace=False))
+        hm[0, k].reshape(-1)[[a, b]] = 4.0
+    hm[1, :10] = -np.abs(hm[1, :10]) - 0.01                    # all negative
+    hm[1, 10:12] = 0.0                                         # all zero: maxval == 0 -> zeroed too
+    for k in range(12, 20):                                    # interior maximum with equal left/right or up/down
+        y, x = int(rng.integers(1, H - 1)), int(rng.integers(1, W - 1))
+        hm[1, k, y, x] = 6.0
+        hm[1, k, y, x - 1] = hm[1, k, y, x + 1] = 1.5
+        hm[1, k, y - 1, x], hm[1, k, y + 1, x] = 0.5, 2.5
+    pt1 = rng.uniform(0, 200, (n, 2)).astype(np.float32)
+    pt2 = pt1 + rng.uniform(20, 300, (n, 2)).astype(np.float32)
+    t = torch.from_numpy(hm)
+    kp = ops.heatmap_argmax(t.to(cuda)).cpu().numpy()
+    idx = kp[..., 0].copy().view(np.int32)
+    assert np.array_equal(idx, hm.reshape(n, K, -1).argmax(2))
+    got_hm, got_img, got_max = decode_keypoints(kp, pt1, pt2)
+    ref_hm, ref_img, ref_max = post_ref.get_prediction(t, torch.from_numpy(pt1), torch.from_numpy(pt2))
+    np.testing.assert_array_equal(got_hm, ref_hm.numpy())
+    np.testing.assert_allclose(got_img, ref_img.numpy(), rtol=0, atol=2e-4)
+    np.testing.assert_array_equal(got_max, ref_max.numpy())
+    assert np.all(got_hm[1, :12] == np.float32(0.2))           # zeroed key points (then the +0.2 of eval.py:131)
+    # degenerate input must stay in bounds
+    bad = torch.full((1, 2, H, W), float("-inf"))
+    out = ops.heatmap_argmax(bad.to(cuda)).cpu().numpy()
+    assert np.all(out[..., 0].copy().view(np.int32) == 0)
