@@ -118,22 +118,36 @@ class StreamedRunner:
             on_record(idx, rec)
 
         j = 0
-        for idx, frame, addr in source:
-            if frame.shape != (self.H, self.W, 3):
-                raise ValueError("frame %d is %s, pipeline was built for %s" % (idx, frame.shape, (self.H, self.W, 3)))
-            k = j % S
-            st = self.streams[k]
-            with torch.cuda.stream(st):
-                _lib.check(L.bp_upload(self.pipes[k].frames.data_ptr(), addr, nbytes, st.cuda_stream))
-                self.pipes[k].enqueue(st.cuda_stream)
-                self._pinned[j % NS].copy_(self.pipes[k].results, non_blocking=True)
-                self._events[j % NS].record(st)
-            inflight.append((j, idx))
-            j += 1
-            if len(inflight) > S:
+        try:
+            for idx, frame, addr in source:
+                if frame.shape != (self.H, self.W, 3):
+                    source.release(idx)
+                    raise ValueError("frame %d is %s, pipeline was built for %s" % (idx, frame.shape, (self.H, self.W, 3)))
+                k = j % S
+                st = self.streams[k]
+                with torch.cuda.stream(st):
+                    _lib.check(L.bp_upload(self.pipes[k].frames.data_ptr(), addr, nbytes, st.cuda_stream))
+                    self.pipes[k].enqueue(st.cuda_stream)
+                    self._pinned[j % NS].copy_(self.pipes[k].results, non_blocking=True)
+                    self._events[j % NS].record(st)
+                inflight.append((j, idx))
+                j += 1
+                if len(inflight) > S:
+                    finish()
+            while inflight:
                 finish()
-        while inflight:
-            finish()
+        finally:
+            # an error mid-stream (a broken frame, a failed launch): let the device drain, then hand the loader its
+            # slots back so it can be closed or iterated further
+            if inflight:
+                for st in self.streams:
+                    st.synchronize()
+                for _, idx in inflight:
+                    try:
+                        source.release(idx)
+                    except Exception:
+                        pass
+                inflight.clear()
         return j
 
 

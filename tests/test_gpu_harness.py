@@ -117,3 +117,41 @@ def test_evaluate_f16_precision_close_to_reference_json(tmp_path):
         total += 50
         assert np.abs(kg[near, 2] - kr[near, 2]).max() < 5e-2
     assert far <= total * 15 // 100, (far, total)
+
+
+def test_streamed_runner_order_and_failure_cleanup(tmp_path, cuda):
+    """Frames-in-flight driver over the native loader: records come back in list order and equal the one-at-a-time
+    pipeline's; a broken frame in the middle surfaces as an exception after the frames in flight have drained, and the
+    loader can still be closed (no slot left checked out)."""
+    from PIL import Image
+    from betapose_amd import _lib, synth
+    from betapose_amd.darknet import Darknet
+    from betapose_amd.frame_loader import FrameLoader
+    from betapose_amd.kpd import FastPoseHIP
+    from betapose_amd.pipeline import FramePipeline, StreamedRunner
+    from betapose_amd.weights import fastpose_stream_from_state_dict
+    frames = synth.synth_frames(7, 321)
+    paths = []
+    for i, fr in enumerate(frames):
+        p = tmp_path / ("%04d.png" % i)
+        Image.fromarray(fr[:, :, ::-1].copy()).save(p, compress_level=1)
+        paths.append(str(p))
+    det = Darknet("yolo/cfg/yolov3-single.cfg", reso=416).load_stream(helpers.yolo_stream()).cuda()
+    pose = FastPoseHIP.from_stream(fastpose_stream_from_state_dict(helpers.kpd_state_dict(), 50), n_classes=50).cuda()
+    runner = StreamedRunner(det, pose, 480, 640, streams=3)
+    got = {}
+    ld = FrameLoader(paths, threads=2, depth=8)
+    assert runner.run(ld, lambda i, rec: got.__setitem__(i, rec)) == 7
+    ld.close()
+    assert list(got) == list(range(7))
+    single = FramePipeline(det.clone(), pose.clone(), 480, 640)
+    for i in (0, 3, 6):
+        np.testing.assert_array_equal(single.run(frames[i])[0], got[i])      # same kernels, same plan: bit-identical
+    # broken frame in the middle
+    open(tmp_path / "bad.png", "wb").write(open(paths[2], "rb").read()[:4000])
+    ld = FrameLoader(paths[:3] + [str(tmp_path / "bad.png")] + paths[3:], threads=2, depth=8)
+    seen = []
+    with pytest.raises(_lib.BetaposeHipError, match="bad.png"):
+        runner.run(ld, lambda i, rec: seen.append(i))
+    assert seen == sorted(seen) and set(seen) <= {0, 1, 2}
+    ld.close()                                                                 # must not hang
