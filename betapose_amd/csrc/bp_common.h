@@ -74,7 +74,7 @@ struct ConvParams {
 // arithmetic of the matrix-core operands (accumulation and activations are always fp32)
 enum Precision : int { PREC_F32 = 0, PREC_F16 = 1, PREC_BF16X3 = 2 };
 
-enum ConvTile : int { TILE_64x64 = 0, TILE_128x64 = 1, TILE_32x64 = 2, TILE_64x32 = 3 };
+enum ConvTile : int { TILE_64x64 = 0, TILE_128x64 = 1 };
 
 // when non-null, launch_conv brackets the implicit-GEMM kernel itself (not the split-K reduce) with these events
 struct ConvProfHook { hipEvent_t e0, e1; };

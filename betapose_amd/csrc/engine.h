@@ -28,8 +28,7 @@ private:
 };
 
 enum OpType : int {
-    OP_CONV, OP_NCHW2NHWC, OP_MAXPOOL, OP_ADD, OP_UPSAMPLE, OP_COPYCH, OP_PIXSHUF, OP_AVGPOOL, OP_FC,
-    OP_NHWC2NCHW
+    OP_CONV, OP_MAXPOOL, OP_ADD, OP_UPSAMPLE, OP_COPYCH, OP_PIXSHUF, OP_AVGPOOL, OP_FC
 };
 
 struct Op {
