@@ -142,3 +142,31 @@ def test_masked_stream_confines_work_to_its_cu_slice(cuda):
     for i in range(4):
         for j in range(i):
             assert not (seen[i] & seen[j])          # slices do not overlap
+
+
+def test_engines_of_several_objects_coexist(cuda):
+    """BASELINE configs[2] serves all LineMod objects: one detector + key-point engine per object, each with its own
+    filters, side by side in one process (no hidden globals).  Three differently seeded KPD engines at batch 28 in the
+    fp16 mode, called interleaved on two streams, must each return what they return when run alone."""
+    import torch
+    from betapose_amd import synth
+    from betapose_amd.kpd import FastPoseHIP
+    g = torch.Generator().manual_seed(3)
+    x = (torch.rand(28, 3, 320, 256, generator=g) - 0.45).to(cuda)
+    engines, alone = [], []
+    for obj, seed in enumerate((2, 12, 22)):
+        e = FastPoseHIP(synth.synth_fastpose_state_dict(seed), n_classes=50, max_batch=28).cuda()
+        e.set_precision("f16")
+        engines.append(e)
+        alone.append(e(x).clone())
+    torch.cuda.synchronize()
+    assert float((alone[0] - alone[1]).abs().max()) > 1e-2          # different objects really differ
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = [None] * 3
+    for rep in range(2):
+        for i, e in enumerate(engines):
+            with torch.cuda.stream(s1 if (i + rep) % 2 else s2):
+                outs[i] = e(x).clone()
+    torch.cuda.synchronize()
+    for i in range(3):
+        assert torch.equal(outs[i], alone[i]), "object %d" % i
