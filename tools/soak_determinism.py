@@ -14,11 +14,14 @@ from betapose_amd.pipeline import FramePipeline
 ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=3000)
 ap.add_argument("--streams", type=int, default=4)
+ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "f16"])
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 blocks = C.parse_cfg_text(C.yolov3_single_cfg_text())
 det = Darknet("yolov3-single.cfg").load_stream(synth.synth_yolo_stream(1, blocks)).cuda()
 pose = FastPoseHIP(synth.synth_fastpose_state_dict(2)).cuda()
+det.set_precision(a.precision)
+pose.set_precision(a.precision)
 S = a.streams
 dets = [det] + [det.clone() for _ in range(S - 1)]
 poses = [pose] + [pose.clone() for _ in range(S - 1)]
@@ -42,5 +45,5 @@ for it in range(a.iters):
                 bad += 1
                 d = (pipes[k].heatmaps - ref_hm[k]).abs().max().item()
                 print("MISMATCH iter", it, "stream", k, "max |d hm|", d, flush=True)
-print("soak: %d iterations x %d streams, mismatching checks: %d" % (a.iters, S, bad))
+print("soak[%s]: %d iterations x %d streams, mismatching checks: %d" % (a.precision, a.iters, S, bad))
 sys.exit(1 if bad else 0)
