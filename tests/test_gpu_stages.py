@@ -245,3 +245,19 @@ def test_heatmap_argmax_random_maps_vs_oracle(cuda):
     bad = torch.full((1, 2, H, W), float("-inf"))
     out = ops.heatmap_argmax(bad.to(cuda)).cpu().numpy()
     assert np.all(out[..., 0].copy().view(np.int32) == 0)
+
+
+def test_pipeline_frame_without_detection(engines, cuda):
+    """No candidate above the confidence: the record carries index -1, the host tail forwards the frame with
+    boxes=None exactly as the reference does (dataloader.py:344-349), and the next frame is unaffected."""
+    from betapose_amd.pipeline import finish_record
+    det, pose = engines
+    fr = helpers.frames()[0]
+    strict = FramePipeline(det, pose, 480, 640, batch=1, confidence=0.9999)
+    rec = strict.run(fr)[0]
+    assert int(rec[:1].view(np.int32)[0]) == -1
+    out = finish_record(rec, "0000.png", synth.synth_kp3d(50), synth.CAM_K)
+    assert out["boxes"] is None and out["result"] == [] and out["cam_R"] == []
+    normal = FramePipeline(det, pose, 480, 640, batch=1, confidence=0.01)
+    rec2 = normal.run(fr)[0]
+    assert int(rec2[:1].view(np.int32)[0]) == int(helpers.golden("pipeline.npz")["f0_obj_argmax"])
