@@ -415,7 +415,7 @@ template <> struct HalfOps<3> {
 template <int TM, int TN, int NP>
 __global__ __launch_bounds__(256) void conv_igemm_h_kernel(const ConvParams p) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
-    constexpr int RA = BM / 32;          // fp32 A rows per thread (4 floats each)
+    constexpr int RA = BM / 64;          // fp32 A rows per thread (8 consecutive floats each: two 16-B loads, one 16-B LDS store per plane)
     constexpr int RBH = BN / 64;         // 16-bit B rows per thread and plane (8 elements each)
     constexpr int LDT = BN + 4;
     constexpr int STAGE_HALFS = NP * (BM + BN) * LDH;
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(256) void conv_igemm_h_kernel(const ConvParams p) {
     const int c_begin = split * p.chunks_per_split;
     const int c_end = min(p.nchunks, c_begin + p.chunks_per_split);
 
-    const int lr = tid >> 3, c4 = tid & 7;       // A: row lr (+32i), floats c4*4..+3
+    const int lr = tid >> 2, a8 = (tid & 3) * 8; // A: row lr (+64i), floats a8..a8+7
     const int br = tid >> 2, b8 = (tid & 3) * 8; // B: row br (+64i), elements b8..+7
     const int hw = p.OH * p.OW;
     const int plane_bytes = p.CoutPad * p.Kpad * 2;
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(256) void conv_igemm_h_kernel(const ConvParams p) {
     const float rcp_hw = 1.0f / (float)hw, rcp_ow = 1.0f / (float)p.OW;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-        const int m = m0 + lr + 32 * i;
+        const int m = m0 + lr + 64 * i;
         const bool ok = m < p.M;
         const int mm = ok ? m : 0;
         const int b = fast_div(mm, hw, rcp_hw);
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256) void conv_igemm_h_kernel(const ConvParams p) {
         const int oy = fast_div(rem, p.OW, rcp_ow);
         const int ox = rem - oy * p.OW;
         const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
-        a_base[i] = (unsigned)((((b * p.H + iy0) * p.W + ix0) * p.in_ld + c4 * 4) * 4);
+        a_base[i] = (unsigned)((((b * p.H + iy0) * p.W + ix0) * p.in_ld + a8) * 4);
         const int kx_lo = max(0, -ix0), kx_hi = min(p.ksize, p.W - ix0);
         const int ky_lo = max(0, -iy0), ky_hi = min(p.ksize, p.H - iy0);
         unsigned long long mask = 0;
@@ -506,7 +506,10 @@ __global__ __launch_bounds__(256) void conv_igemm_h_kernel(const ConvParams p) {
     }
 #define BH_LOAD(ra_, rb_)                                                                              \
     {                                                                                                  \
-        _Pragma("unroll") for (int i = 0; i < RA; ++i) ra_[i] = buf_load4(rsrcA, va[i], 0);            \
+        _Pragma("unroll") for (int i = 0; i < RA; ++i) {                                               \
+            ra_[2 * i] = buf_load4(rsrcA, va[i], 0);                                                   \
+            ra_[2 * i + 1] = buf_load4(rsrcA, va[i], 16);                                              \
+        }                                                                                              \
         _Pragma("unroll") for (int pl = 0; pl < NP; ++pl)                                              \
             _Pragma("unroll") for (int i = 0; i < RBH; ++i)                                            \
                 rb_[pl][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrcB, (int)b_base[i] + pl * plane_bytes, sb, 0); \
@@ -514,18 +517,20 @@ __global__ __launch_bounds__(256) void conv_igemm_h_kernel(const ConvParams p) {
 #define BH_STORE(s_, ra_, rb_)                                                                         \
     {                                                                                                  \
         _Pragma("unroll") for (int i = 0; i < RA; ++i) {                                               \
-            unsigned short* dst = BH_AS(s_, 0) + (lr + 32 * i) * LDH + a_st_off;                       \
+            unsigned short* dst = BH_AS(s_, 0) + (lr + 64 * i) * LDH + a_st_off;                       \
+            const f32x4 lo = ra_[2 * i], hi = ra_[2 * i + 1];                                          \
             if constexpr (NP == 1) {                                                                   \
-                *reinterpret_cast<f16x4*>(dst) = __builtin_convertvector(ra_[i], f16x4);               \
+                const f16x4 l = __builtin_convertvector(lo, f16x4), h = __builtin_convertvector(hi, f16x4); \
+                *reinterpret_cast<f16x8*>(dst) = __builtin_shufflevector(l, h, 0, 1, 2, 3, 4, 5, 6, 7); \
             } else {                                                                                   \
-                const bf16x4 h1 = __builtin_convertvector(ra_[i], bf16x4);                             \
-                const f32x4 r1 = ra_[i] - __builtin_convertvector(h1, f32x4);                          \
-                const bf16x4 h2 = __builtin_convertvector(r1, bf16x4);                                 \
-                const f32x4 r2 = r1 - __builtin_convertvector(h2, f32x4);                              \
-                const bf16x4 h3 = __builtin_convertvector(r2, bf16x4);                                 \
-                *reinterpret_cast<bf16x4*>(dst) = h1;                                                  \
-                *reinterpret_cast<bf16x4*>(dst + BM * LDH) = h2;                                       \
-                *reinterpret_cast<bf16x4*>(dst + 2 * BM * LDH) = h3;                                   \
+                const bf16x4 l1 = __builtin_convertvector(lo, bf16x4), h1 = __builtin_convertvector(hi, bf16x4); \
+                const f32x4 rl1 = lo - __builtin_convertvector(l1, f32x4), rh1 = hi - __builtin_convertvector(h1, f32x4); \
+                const bf16x4 l2 = __builtin_convertvector(rl1, bf16x4), h2 = __builtin_convertvector(rh1, bf16x4); \
+                const f32x4 rl2 = rl1 - __builtin_convertvector(l2, f32x4), rh2 = rh1 - __builtin_convertvector(h2, f32x4); \
+                const bf16x4 l3 = __builtin_convertvector(rl2, bf16x4), h3 = __builtin_convertvector(rh2, bf16x4); \
+                *reinterpret_cast<bf16x8*>(dst) = __builtin_shufflevector(l1, h1, 0, 1, 2, 3, 4, 5, 6, 7); \
+                *reinterpret_cast<bf16x8*>(dst + BM * LDH) = __builtin_shufflevector(l2, h2, 0, 1, 2, 3, 4, 5, 6, 7); \
+                *reinterpret_cast<bf16x8*>(dst + 2 * BM * LDH) = __builtin_shufflevector(l3, h3, 0, 1, 2, 3, 4, 5, 6, 7); \
             }                                                                                          \
         }                                                                                              \
         _Pragma("unroll") for (int pl = 0; pl < NP; ++pl)                                              \
@@ -543,7 +548,7 @@ __global__ __launch_bounds__(256) void conv_igemm_h_kernel(const ConvParams p) {
 
     // swizzled element offsets inside a row (all row bases used below are multiples of 32 rows, so (row >> 1) & 3
     // depends on the thread's own row index only)
-    const int a_st_off = (((c4 >> 1) ^ ((lr >> 1) & 3)) << 3) + ((c4 & 1) << 2);
+    const int a_st_off = ((tid & 3) ^ ((lr >> 1) & 3)) << 3;
     const int b_st_off = ((tid & 3) ^ ((br >> 1) & 3)) << 3;
     const int frow = lane & 31, fsw = (frow >> 1) & 3;
     const int frag_ks0 = frow * LDH + (((lane >> 5)) ^ fsw) * 8;          // logical granule (lane>>5)     (k-step 0)
@@ -551,7 +556,7 @@ __global__ __launch_bounds__(256) void conv_igemm_h_kernel(const ConvParams p) {
     const int a_row0 = wm * (BM / 2) * LDH;
     const int b_row0 = wn * (BN / 2) * LDH;
 
-    f32x4 ra0[RA], ra1[RA];
+    f32x4 ra0[2 * RA], ra1[2 * RA];
     u32x4 rb0[NP][RBH], rb1[NP][RBH];
     // partial products (A plane, B plane), smallest first
     constexpr int NPROD = NP == 1 ? 1 : 6;

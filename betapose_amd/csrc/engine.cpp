@@ -145,12 +145,12 @@ static const SplitEntry kSplitTableB3[] = {
     {   169,   512,   32,  5},
     {   169,  1024,  144,  5},
     {   320,   256,   32,  5},
-    {   320,   256,   72,  6},
+    {   320,   256,   72,  5},
     {   320,   512,   32,  5},
     {   320,  1024,    8,  1},
     {   320,  1024,   16,  3},
     {   320,  1024,  144,  6},
-    {   676,    64,   16,  5},
+    {   676,    64,   16,  4},
     {   676,   128,    8,  1},
     {   676,   256,   16,  3},
     {   676,   256,   24,  5},
@@ -164,7 +164,7 @@ static const SplitEntry kSplitTableB3[] = {
     {  2704,    64,    8,  1},
     {  2704,   128,    8,  1},
     {  2704,   128,   12,  1},
-    {  2704,   256,   36,  2},
+    {  2704,   256,   36,  4},
     {  5120,    64,    2,  1},
     {  5120,    64,    8,  1},
     {  5120,    64,   18,  3},
@@ -172,7 +172,7 @@ static const SplitEntry kSplitTableB3[] = {
     {  5120,   128,    8,  1},
     {  5120,   256,    2,  1},
     { 10816,    64,    4,  1},
-    { 10816,   128,   18,  1},
+    { 10816,   128,   18,  2},
     { 43264,    64,    2,  1},
     { 43264,    64,    9,  1},
 };
