@@ -54,14 +54,19 @@ def load_ply_vertices(path: str) -> np.ndarray:
 
 
 def refine_keypoints(vertices: np.ndarray, keep: int) -> np.ndarray:
-    """``Model3D.refine`` (utils/model.py:29-46): repeatedly delete one point of the globally closest pair
-    until ``keep`` points are left."""
+    """``Model3D.refine`` (utils/model.py:29-46): ``len - keep`` times, delete the first point (in row-major pair
+    order) of the closest pair.  Two quirks of the reference are kept: the running minimum of a round starts at the
+    hard-wired 100.0, and the index to delete is carried over from the previous round (initially 0) -- so when every
+    pair is at least 100 apart (millimetre-scale, spread-out points) the previous round's index is deleted again."""
     v = np.array(vertices, dtype=np.float64)
-    while len(v) > keep:
-        d = np.linalg.norm(v[:, None, :] - v[None, :, :], axis=2)
+    min_index = 0
+    for _ in range(max(0, len(v) - keep)):
+        diff = v[:, None, :] - v[None, :, :]
+        d = np.sqrt(np.sum(np.square(diff), axis=2))
         d[np.diag_indices(len(v))] = np.inf
-        i, _ = np.unravel_index(np.argmin(d), d.shape)
-        v = np.delete(v, i, axis=0)
+        if d.min() < 100.0:
+            min_index = int(np.unravel_index(np.argmin(d), d.shape)[0])
+        v = np.delete(v, min_index, axis=0)
     return v
 
 

@@ -98,3 +98,14 @@ def test_metric_camera_defaults_to_identity_without_camera_yml(tmp_path):
     os.remove(tmp_path / "camera.yml")
     cam = evaluate.load_sixd_gt(str(tmp_path), 1)[4]
     np.testing.assert_array_equal(cam, np.identity(3))                   # utils/sixd.py:53 Benchmark.cam
+
+
+def test_refine_matches_reference_model3d():
+    """``Model3D.refine`` golden vectors made by the reference's own class (tools/make_golden_refine.py): generic point
+    sets, a coarse grid with exactly tied distances, and a millimetre-scale set where every pair is farther apart than
+    the reference's hard-wired 100.0 start value (it then deletes the index carried over from the round before)."""
+    from helpers import golden
+    g = golden("refine.npz")
+    for k in "abcd":
+        got = metrics.refine_keypoints(g[k + "_in"], int(g[k + "_keep"]))
+        np.testing.assert_array_equal(got, g[k + "_out"], err_msg="case " + k)
