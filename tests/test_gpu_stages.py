@@ -261,3 +261,26 @@ def test_pipeline_frame_without_detection(engines, cuda):
     normal = FramePipeline(det, pose, 480, 640, batch=1, confidence=0.01)
     rec2 = normal.run(fr)[0]
     assert int(rec2[:1].view(np.int32)[0]) == int(helpers.golden("pipeline.npz")["f0_obj_argmax"])
+
+
+def test_crop_and_select_match_reference_edge_goldens(cuda):
+    """The HIP crop and select kernels directly against the REFERENCE's outputs on the edge-case fixtures
+    (tests/golden/edges.npz, tools/make_golden_edges.py)."""
+    from betapose_amd.yolo_util import dynamic_write_results
+    e = helpers.golden("edges.npz")
+    fr = synth.synth_frame(int(e["crop_frame_seed"]))
+    boxes = torch.from_numpy(e["crop_boxes"])
+    n = len(boxes)
+    got, pts = ops.crop(torch.from_numpy(np.repeat(fr[None], n, 0)).to(cuda), boxes=boxes.to(cuda))
+    got, pts = got.cpu().reshape(n, -1), pts.cpu().numpy()
+    np.testing.assert_array_equal(pts[:, 0:2], e["crop_pt1"])
+    np.testing.assert_array_equal(pts[:, 2:4], e["crop_pt2"])
+    assert np.abs(got.numpy()[:, e["crop_samp_idx"]] - e["crop_samples"]).max() <= 2e-6
+    assert np.abs(got.double().sum(1).numpy() - e["crop_sum"]).max() < 0.05
+    for t in range(int(e["sel_n"])):
+        want = e["sel%d_out" % t]
+        res = dynamic_write_results(torch.from_numpy(e["sel%d_pred" % t]).to(cuda), float(e["sel%d_conf" % t]), 80)
+        if len(want) == 0:
+            assert isinstance(res, int) and res == 0, t
+        else:
+            np.testing.assert_allclose(res.cpu().numpy(), want, rtol=1e-6, atol=1e-5, err_msg="case %d" % t)

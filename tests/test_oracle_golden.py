@@ -92,3 +92,41 @@ def test_oracle_metrics_match_reference(post):
     assert abs(post_ref.projection_error_2d(post["m_gt"], post["m_est"], post["m_model"], CAM_K) - float(post["m_proj"])) < 1e-9
     assert abs(post_ref.iou([10, 10, 110, 210], [30, 40, 100, 260]) - float(post["m_iou"][0])) < 1e-12
     assert post_ref.iou([10, 10, 50, 50], [60, 60, 80, 80]) == float(post["m_iou"][1]) == 0.0
+
+
+@pytest.fixture(scope="module")
+def edges():
+    return helpers.golden("edges.npz")
+
+
+def test_oracle_crop_edge_boxes_match_reference(edges):
+    """64 boxes through the reference's own crop_from_dets / cropBox (tools/make_golden_edges.py): tiny, huge, crossing
+    the border, fractional corners, both sides of the width-100 pad-rule switch."""
+    from betapose_amd import synth
+    fr = synth.synth_frame(int(edges["crop_frame_seed"]))
+    assert bool(edges["crop_ok"].all())                      # the reference handled every one of them
+    for i, b in enumerate(edges["crop_boxes"]):
+        inps, pt1, pt2 = post_ref.crop_from_dets_frame(fr, torch.from_numpy(b[None]))
+        np.testing.assert_array_equal(pt1.numpy()[0], edges["crop_pt1"][i], err_msg=str(b))
+        np.testing.assert_array_equal(pt2.numpy()[0], edges["crop_pt2"][i], err_msg=str(b))
+        flat = inps[0].reshape(-1)
+        assert np.abs(flat.numpy()[edges["crop_samp_idx"]] - edges["crop_samples"][i]).max() <= 1e-6, b
+        assert abs(float(flat.double().sum()) - float(edges["crop_sum"][i])) < 0.02
+        assert abs(float(flat.double().abs().sum()) - float(edges["crop_abs_sum"][i])) < 0.02
+
+
+def test_oracle_select_matches_reference(edges):
+    """48 prediction tensors through the reference's dynamic_write_results: multi-class rows, images / whole batches
+    without a candidate (int 0)."""
+    n_empty = 0
+    for t in range(int(edges["sel_n"])):
+        pred = torch.from_numpy(edges["sel%d_pred" % t])
+        want = edges["sel%d_out" % t]
+        got = yolo_ref.write_results(pred.clone(), float(edges["sel%d_conf" % t]), 80)
+        if len(want) == 0:
+            assert isinstance(got, int) and got == 0
+            n_empty += 1
+        else:
+            assert got.shape == want.shape
+            np.testing.assert_allclose(got.numpy(), want, rtol=1e-6, atol=1e-5, err_msg="case %d" % t)
+    assert 3 <= n_empty <= 20

@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""Edge-case golden vectors from the REFERENCE's own functions (build container only; shims as tools/make_golden.py):
+
+  * ``crop_from_dets`` / ``cropBox`` (dataloader.py:794-835, KPD/src/utils/img.py:242-262) on 64 seeded boxes of every
+    flavour -- tiny, huge, touching or crossing the frame border, fractional corners, both sides of the width-100
+    pad-rule switch.  Stored per box: pt1, pt2, crop sum / abs-sum and 96 sampled crop values.  Boxes the reference
+    itself cannot process (it prints and leaves the slot empty, :825-831, or raises) are recorded as such.
+  * ``dynamic_write_results`` (yolo/util.py:104-223) on 48 seeded prediction tensors: single / multi class, images
+    without a candidate above the threshold, several images per batch.  (No exact objectness ties: the reference ranks
+    with an unstable sort, so its pick among ties is unspecified.)
+
+Writes tests/golden/edges.npz."""
+import os, sys
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import ref_shims  # noqa: E402
+
+ref_shims.install()
+import torch  # noqa: E402
+
+os.chdir(ref_shims.REF)
+sys.path.insert(0, ref_shims.REF)
+sys.argv = [sys.argv[0]]
+from opt import opt  # noqa: E402
+import dataloader as ref_dl  # noqa: E402
+from yolo.util import dynamic_write_results  # noqa: E402
+from KPD.src.utils.img import im_to_torch  # noqa: E402
+from betapose_amd import synth  # noqa: E402
+
+out = {}
+g = np.random.Generator(np.random.PCG64(77))
+
+# ---------------------------------------------------------------- crop
+frame = synth.synth_frame(4321)                       # BGR u8 480x640
+boxes = []
+for _ in range(40):
+    cx, cy = g.uniform(-30, 670), g.uniform(-30, 510)
+    w, h = np.exp(g.uniform(np.log(3), np.log(650))), np.exp(g.uniform(np.log(3), np.log(470)))
+    boxes.append([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2])
+for w in (99.0, 100.0, 100.5, 101.0):
+    for x0 in (0.0, 33.3, 539.5):
+        boxes.append([x0, 120.25, x0 + w, 300.5])
+for _ in range(12):
+    x0, y0 = int(g.integers(0, 600)), int(g.integers(0, 440))
+    boxes.append([float(x0), float(y0), float(x0 + g.integers(1, 200)), float(y0 + g.integers(1, 200))])
+boxes = np.array(boxes, np.float32)
+samp = g.choice(3 * 320 * 256, 96, replace=False)
+ok, pt1s, pt2s, sums, asums, samples = [], [], [], [], [], []
+for b in boxes:
+    img = im_to_torch(np.ascontiguousarray(frame[:, :, ::-1]))          # RGB float CHW /255, as dataloader.py:452
+    inps = torch.full((1, 3, opt.inputResH, opt.inputResW), float("nan"))
+    pt1, pt2 = torch.zeros(1, 2), torch.zeros(1, 2)
+    try:
+        ref_dl.crop_from_dets(img, torch.from_numpy(b[None]), inps, pt1, pt2)
+        good = bool(torch.isfinite(inps).all())
+    except Exception as e:                                              # noqa: BLE001
+        good = False
+    ok.append(good)
+    pt1s.append(pt1[0].numpy().copy()); pt2s.append(pt2[0].numpy().copy())
+    flat = inps[0].reshape(-1).double()
+    sums.append(float(flat.sum()) if good else 0.0)
+    asums.append(float(flat.abs().sum()) if good else 0.0)
+    samples.append(inps[0].reshape(-1)[samp].numpy().copy() if good else np.zeros(96, np.float32))
+out["crop_frame_seed"] = np.array(4321)
+out["crop_boxes"], out["crop_ok"] = boxes, np.array(ok)
+out["crop_pt1"], out["crop_pt2"] = np.array(pt1s), np.array(pt2s)
+out["crop_sum"], out["crop_abs_sum"] = np.array(sums), np.array(asums)
+out["crop_samp_idx"], out["crop_samples"] = samp, np.array(samples)
+print("crop: %d boxes, reference handled %d" % (len(boxes), int(np.sum(ok))))
+
+# ---------------------------------------------------------------- select
+n_cases = 48
+out["sel_n"] = np.array(n_cases)
+kept = 0
+for t in range(n_cases):
+    B = int(g.integers(1, 4))
+    rows = 60
+    ncls = int(g.choice([1, 3]))
+    pred = np.zeros((B, rows, 5 + ncls), np.float32)
+    pred[..., 0:2] = g.uniform(0, 416, (B, rows, 2))
+    pred[..., 2:4] = g.uniform(2, 300, (B, rows, 2))
+    pred[..., 4] = g.uniform(0, 1, (B, rows)) ** 3
+    pred[..., 5:] = g.uniform(0, 1, (B, rows, ncls))
+    conf = float(g.choice([0.01, 0.5, 0.9]))
+    if t % 4 == 0:
+        pred[0, :, 4] *= conf * 0.5
+    if t % 7 == 0:
+        pred[:, :, 4] *= conf * 0.5                       # nothing anywhere -> int 0
+    res = dynamic_write_results(torch.from_numpy(pred.copy()), conf, 80, nms=True, nms_conf=0.6)
+    out["sel%d_pred" % t] = pred
+    out["sel%d_conf" % t] = np.array(conf)
+    if isinstance(res, int):
+        out["sel%d_out" % t] = np.zeros((0, 8), np.float32)
+    else:
+        out["sel%d_out" % t] = res.numpy().astype(np.float32)
+        kept += 1
+print("select: %d cases, %d with detections" % (n_cases, kept))
+np.savez_compressed(os.path.join(ROOT, "tests", "golden", "edges.npz"), **out)
+print(os.path.getsize(os.path.join(ROOT, "tests", "golden", "edges.npz")), "bytes")
