@@ -284,3 +284,11 @@ def test_crop_and_select_match_reference_edge_goldens(cuda):
             assert isinstance(res, int) and res == 0, t
         else:
             np.testing.assert_allclose(res.cpu().numpy(), want, rtol=1e-6, atol=1e-5, err_msg="case %d" % t)
+    # arg-max kernel + host decode against the reference's getPrediction on the planted heat-maps
+    from betapose_amd.eval import decode_keypoints
+    hm = torch.from_numpy(e["gpe_hms"].astype(np.float32))
+    kp = ops.heatmap_argmax(hm.to(cuda)).cpu().numpy()
+    a, b, c = decode_keypoints(kp, e["gpe_pt1"], e["gpe_pt2"])
+    np.testing.assert_array_equal(a, e["gpe_preds_hm"])
+    np.testing.assert_allclose(b, e["gpe_preds_img"], rtol=0, atol=1e-4)
+    np.testing.assert_array_equal(c, e["gpe_maxval"])

@@ -130,3 +130,20 @@ def test_oracle_select_matches_reference(edges):
             assert got.shape == want.shape
             np.testing.assert_allclose(got.numpy(), want, rtol=1e-6, atol=1e-5, err_msg="case %d" % t)
     assert 3 <= n_empty <= 20
+
+
+def test_get_prediction_planted_cases_match_reference(edges):
+    """Heat-maps with maxima on corners / borders, two equal maxima, all-negative and all-zero maps, equal neighbours:
+    the reference's getPrediction output (tools/make_golden_edges.py) against the oracle AND the product's host decode
+    of arg-max records (betapose_amd.eval), all exact."""
+    from betapose_amd.eval import decode_keypoints, kp_records_from_heatmaps
+    hm = edges["gpe_hms"].astype(np.float32)
+    a, b, c = post_ref.get_prediction(torch.from_numpy(hm), torch.from_numpy(edges["gpe_pt1"]),
+                                      torch.from_numpy(edges["gpe_pt2"]))
+    np.testing.assert_array_equal(a.numpy(), edges["gpe_preds_hm"])
+    np.testing.assert_allclose(b.numpy(), edges["gpe_preds_img"], rtol=0, atol=1e-4)
+    np.testing.assert_array_equal(c.numpy(), edges["gpe_maxval"])
+    a2, b2, c2 = decode_keypoints(kp_records_from_heatmaps(hm), edges["gpe_pt1"], edges["gpe_pt2"])
+    np.testing.assert_array_equal(a2, edges["gpe_preds_hm"])
+    np.testing.assert_allclose(b2, edges["gpe_preds_img"], rtol=0, atol=1e-4)
+    np.testing.assert_array_equal(c2, edges["gpe_maxval"])

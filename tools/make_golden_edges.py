@@ -98,5 +98,28 @@ for t in range(n_cases):
         out["sel%d_out" % t] = res.numpy().astype(np.float32)
         kept += 1
 print("select: %d cases, %d with detections" % (n_cases, kept))
+# ---------------------------------------------------------------- getPrediction on planted heat-maps
+from KPD.src.utils.eval import getPrediction  # noqa: E402
+n, K, H, Wd = 2, 50, 80, 64
+hm = g.normal(0, 0.3, (n, K, H, Wd)).astype(np.float32)
+for k, (y, x) in enumerate([(0, 0), (0, 63), (79, 0), (79, 63), (0, 30), (79, 31), (40, 0), (41, 63)]):
+    hm[0, k, y, x] = 5.0                                   # maxima on corners / borders: no quarter-pixel shift
+for k in range(8, 16):                                     # two equal maxima
+    a, b = sorted(g.choice(H * Wd, 2, replace=False))
+    hm[0, k].reshape(-1)[[a, b]] = 4.0
+hm[1, :10] = -np.abs(hm[1, :10]) - 0.01                    # all negative -> zeroed key point
+hm[1, 10:12] = 0.0                                         # all zero
+for k in range(12, 20):                                    # equal left/right neighbours: sign(0) = 0
+    y, x = int(g.integers(1, H - 1)), int(g.integers(1, Wd - 1))
+    hm[1, k, y, x] = 6.0
+    hm[1, k, y, x - 1] = hm[1, k, y, x + 1] = 1.5
+    hm[1, k, y - 1, x], hm[1, k, y + 1, x] = 0.5, 2.5
+hm = hm.astype(np.float16).astype(np.float32)              # stored as fp16: those values ARE the input
+pt1 = g.uniform(0, 200, (n, 2)).astype(np.float32)
+pt2 = pt1 + g.uniform(20, 300, (n, 2)).astype(np.float32)
+a_, b_, c_ = getPrediction(torch.from_numpy(hm), torch.from_numpy(pt1), torch.from_numpy(pt2), 320, 256, 80, 64)
+out["gpe_hms"], out["gpe_pt1"], out["gpe_pt2"] = hm.astype(np.float16), pt1, pt2
+out["gpe_preds_hm"], out["gpe_preds_img"], out["gpe_maxval"] = a_.numpy(), b_.numpy(), c_.numpy()
+print("getPrediction planted:", a_.shape)
 np.savez_compressed(os.path.join(ROOT, "tests", "golden", "edges.npz"), **out)
 print(os.path.getsize(os.path.join(ROOT, "tests", "golden", "edges.npz")), "bytes")
