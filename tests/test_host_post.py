@@ -77,3 +77,30 @@ def test_write_json_matches_reference(tmp_path):
         np.testing.assert_allclose(g["cam_t"], r["cam_t"])
         np.testing.assert_allclose(g["keypoints"], r["keypoints"], rtol=1e-6, atol=2e-5)
         assert abs(g["score"] - r["score"]) < 1e-5
+
+
+def test_pose_nms_seeded_candidate_sets_match_reference():
+    """24 candidate sets (1-6 poses: near-duplicates, loosely similar, shifted, unrelated; weak poses; exact-zero key-point
+    scores) through the reference's pose_nms (tools/make_golden_edges.py): same number of surviving poses, same merged
+    key points / scores / proposal scores / boxes, for the product's numpy pose_nms and for the oracle."""
+    import torch
+    from betapose_amd.pPose_nms import pose_nms
+    from oracle import post_ref
+    g = helpers.golden("edges.npz")
+    counts = []
+    for t in range(int(g["nms_n"])):
+        args = (g["nms%d_boxes" % t], g["nms%d_bsc" % t], g["nms%d_poses" % t], g["nms%d_psc" % t])
+        keep = [a.copy() for a in args]
+        for fn in (pose_nms, lambda *a: post_ref.pose_nms(*[torch.from_numpy(x.copy()) for x in a])):
+            res = fn(*args)
+            n = int(g["nms%d_n" % t])
+            assert len(res) == n, (t, len(res), n)
+            for j, r in enumerate(res):
+                np.testing.assert_allclose(np.asarray(r["keypoints"]), g["nms%d_o%d_kp" % (t, j)], atol=2e-4, rtol=0)
+                np.testing.assert_allclose(np.asarray(r["kp_score"]), g["nms%d_o%d_score" % (t, j)], atol=2e-6, rtol=0)
+                assert abs(float(np.asarray(r["proposal_score"]).reshape(-1)[0]) - float(g["nms%d_o%d_prop" % (t, j)])) < 1e-5
+                np.testing.assert_allclose(np.asarray(r["bbox"]), g["nms%d_o%d_bbox" % (t, j)], atol=1e-5, rtol=0)
+        for a, k in zip(args, keep):
+            np.testing.assert_array_equal(a, k)          # inputs are not mutated (the reference squeezes/deletes in place)
+        counts.append(n)
+    assert min(counts) == 1 and max(counts) >= 4

@@ -121,5 +121,40 @@ a_, b_, c_ = getPrediction(torch.from_numpy(hm), torch.from_numpy(pt1), torch.fr
 out["gpe_hms"], out["gpe_pt1"], out["gpe_pt2"] = hm.astype(np.float16), pt1, pt2
 out["gpe_preds_hm"], out["gpe_preds_img"], out["gpe_maxval"] = a_.numpy(), b_.numpy(), c_.numpy()
 print("getPrediction planted:", a_.shape)
+# ---------------------------------------------------------------- pose_nms on seeded candidate sets
+import pPose_nms as ref_nms  # noqa: E402
+n_nms = 24
+out["nms_n"] = np.array(n_nms)
+for t in range(n_nms):
+    npose = int(g.integers(1, 7))
+    base = g.uniform(100, 300, (50, 2)).astype(np.float32)
+    poses, boxes_, bsc_ = [], [], []
+    for j in range(npose):
+        kind = int(g.integers(0, 4))
+        if kind == 0:   pose = base + g.normal(0, 0.7, (50, 2))                 # near-duplicate of the base pose
+        elif kind == 1: pose = base + g.normal(0, 6.0, (50, 2))                 # loosely similar
+        elif kind == 2: pose = base + g.uniform(40, 120)                        # shifted away
+        else:           pose = g.uniform(50, 400, (50, 2))                      # unrelated
+        poses.append(pose.astype(np.float32))
+        lo, hi = pose.min(0) - 5, pose.max(0) + 5
+        boxes_.append([lo[0], lo[1], hi[0], hi[1]])
+        bsc_.append([float(g.uniform(0.3, 0.99))])
+    poses = np.stack(poses).astype(np.float32)
+    psc = g.uniform(0.05, 0.95, (npose, 50, 1)).astype(np.float32)
+    if t % 5 == 0:
+        psc[int(g.integers(0, npose))] *= 0.2                                   # a weak pose (max score < 0.3)
+    if t % 6 == 0:
+        psc[0, :5] = 0.0                                                        # exact zeros -> 1e-5 (pPose_nms.py:36)
+    bxs = np.array(boxes_, np.float32); bsc = np.array(bsc_, np.float32)
+    res = ref_nms.pose_nms(torch.from_numpy(bxs.copy()), torch.from_numpy(bsc.copy()), torch.from_numpy(poses.copy()),
+                           torch.from_numpy(psc.copy()))
+    out["nms%d_boxes" % t], out["nms%d_bsc" % t], out["nms%d_poses" % t], out["nms%d_psc" % t] = bxs, bsc, poses, psc
+    out["nms%d_n" % t] = np.array(len(res))
+    for j, r in enumerate(res):
+        out["nms%d_o%d_kp" % (t, j)] = r["keypoints"].numpy()
+        out["nms%d_o%d_score" % (t, j)] = r["kp_score"].numpy()
+        out["nms%d_o%d_prop" % (t, j)] = np.array(float(r["proposal_score"]))
+        out["nms%d_o%d_bbox" % (t, j)] = np.asarray(r["bbox"].numpy() if hasattr(r["bbox"], "numpy") else r["bbox"])
+print("pose_nms:", n_nms, "cases, outputs", [int(out["nms%d_n" % t]) for t in range(n_nms)])
 np.savez_compressed(os.path.join(ROOT, "tests", "golden", "edges.npz"), **out)
 print(os.path.getsize(os.path.join(ROOT, "tests", "golden", "edges.npz")), "bytes")
