@@ -15,7 +15,7 @@ import helpers  # noqa: E402
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("mode", [[], ["--fused"]])
+@pytest.mark.parametrize("mode", [[], ["--fused"], ["--detbatch", "3"]])   # staged, fused, staged with a ragged last batch
 def test_evaluate_synthetic_matches_reference_json(tmp_path, mode):
     out = tmp_path / "out"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "evaluate.py"), "--synthetic", "4", "--outdir", str(out),
