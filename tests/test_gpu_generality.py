@@ -170,3 +170,27 @@ def test_engines_of_several_objects_coexist(cuda):
     torch.cuda.synchronize()
     for i in range(3):
         assert torch.equal(outs[i], alone[i]), "object %d" % i
+
+
+def test_inferennet_fast_loads_the_reference_pkl_layout(tmp_path, cuda, monkeypatch):
+    """``InferenNet_fast(kernel_size, obj_id, dataset)`` as the harness constructs it (betapose_evaluate.py:124-130):
+    reads ``./exp/final_model/<name of obj_id>.pkl`` = ``torch.save(model.state_dict())`` of the reference's FastPose,
+    i.e. torch tensors including the 106 ``num_batches_tracked`` counters, which must be ignored."""
+    from betapose_amd.kpd import ALLPATHS, InferenNet_fast
+    sd = helpers.kpd_state_dict()
+    full = {}
+    for k, v in sd.items():
+        full[k] = torch.from_numpy(np.asarray(v))
+        if k.endswith("running_var"):
+            full[k[:-len("running_var")] + "num_batches_tracked"] = torch.tensor(12345, dtype=torch.long)
+    assert sum(k.endswith("num_batches_tracked") for k in full) == 106
+    d = tmp_path / "exp" / "final_model"
+    d.mkdir(parents=True)
+    torch.save(full, d / (ALLPATHS[6] + ".pkl"))
+    monkeypatch.chdir(tmp_path)
+    net = InferenNet_fast(4 * 1 + 1, 6, None).cuda().eval()
+    x = torch.rand(1, 3, 320, 256, generator=torch.Generator().manual_seed(4)) - 0.45
+    ref = FastPoseHIP(sd).cuda()(x).cpu()
+    assert torch.equal(net(x).cpu(), ref)
+    with pytest.raises((FileNotFoundError, OSError)):
+        InferenNet_fast(5, 1, None)                      # no checkpoint for object 1 in this directory
