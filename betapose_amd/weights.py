@@ -207,9 +207,21 @@ def fastpose_stream_size(n_classes: int = 50) -> int:
 
 
 def load_kpd_pkl(path: str) -> Dict[str, np.ndarray]:
-    """``torch.load`` of a FastPose ``state_dict`` -> numpy dict (host only)."""
+    """``torch.load`` of a FastPose ``state_dict`` -> numpy dict (host only).
+
+    Checkpoints are loaded with torch's restricted unpickler (tensors and plain containers only).  A file that needs
+    arbitrary pickled classes -- e.g. a whole pickled module -- is refused unless ``BP_TRUST_PKL=1`` is set, because
+    unpickling executes code from the file (the reference's ``torch.load`` does so unconditionally)."""
+    import os
+    import pickle
     import torch
-    sd = torch.load(path, map_location="cpu")
+    try:
+        sd = torch.load(path, map_location="cpu", weights_only=True)
+    except pickle.UnpicklingError as e:
+        if os.environ.get("BP_TRUST_PKL") != "1":
+            raise ValueError("%s is not a plain tensor state_dict (%s); set BP_TRUST_PKL=1 to unpickle it anyway "
+                             "(runs code from the file)" % (path, str(e).splitlines()[0])) from e
+        sd = torch.load(path, map_location="cpu", weights_only=False)
     if hasattr(sd, "state_dict"):
         sd = sd.state_dict()
     return {k: v.detach().cpu().numpy() for k, v in sd.items() if hasattr(v, "detach")}

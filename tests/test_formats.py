@@ -153,3 +153,21 @@ def test_product_package_does_not_import_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+
+
+def test_kpd_pkl_loader_is_restricted(tmp_path, monkeypatch):
+    """.pkl checkpoints: a tensor state_dict loads (counters included); a pickled module is refused unless the operator
+    opts in, since unpickling it runs code from the file."""
+    import torch
+    ok = tmp_path / "ok.pkl"
+    torch.save({"conv.weight": torch.ones(2, 3), "bn.num_batches_tracked": torch.tensor(3)}, ok)
+    sd = W.load_kpd_pkl(str(ok))
+    assert set(sd) == {"conv.weight", "bn.num_batches_tracked"} and sd["conv.weight"].shape == (2, 3)
+    mod = tmp_path / "module.pkl"
+    torch.save(torch.nn.Linear(2, 2), mod)
+    monkeypatch.delenv("BP_TRUST_PKL", raising=False)
+    with pytest.raises(ValueError, match="BP_TRUST_PKL"):
+        W.load_kpd_pkl(str(mod))
+    monkeypatch.setenv("BP_TRUST_PKL", "1")
+    sd = W.load_kpd_pkl(str(mod))                       # a module: its state_dict is taken
+    assert set(sd) == {"weight", "bias"}
