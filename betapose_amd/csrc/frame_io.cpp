@@ -43,7 +43,8 @@ void parse_header(const uint8_t* d, size_t n, PngHeader* hd) {
     hd->w = be32(p); hd->h = be32(p + 4);
     hd->depth = p[8]; hd->ctype = p[9]; hd->interlace = p[12];
     if (p[10] != 0 || p[11] != 0) throw IoError("PNG: unknown compression / filter method");
-    if (hd->w == 0 || hd->h == 0 || hd->w > 32768 || hd->h > 32768) throw IoError("PNG: bad dimensions");
+    if (hd->w == 0 || hd->h == 0 || hd->w > 32768 || hd->h > 32768 || (uint64_t)hd->w * hd->h > (1ull << 26))
+        throw IoError("PNG: bad dimensions (limit: 32768 per side, 64 Mpixel)");
     const int dep = hd->depth;
     bool ok = false;
     switch (hd->ctype) {
