@@ -171,3 +171,20 @@ def test_kpd_pkl_loader_is_restricted(tmp_path, monkeypatch):
     monkeypatch.setenv("BP_TRUST_PKL", "1")
     sd = W.load_kpd_pkl(str(mod))                       # a module: its state_dict is taken
     assert set(sd) == {"weight", "bias"}
+
+
+def test_headers_compile_as_plain_c_and_as_a_reference_consumer(tmp_path):
+    """include/betapose_hip.h is a C header (gcc -std=c99 -pedantic -Werror) and include/yolo_v2_class_compat.h serves
+    a C++ consumer of the reference's detector library; both programs link the .so and run without a GPU."""
+    import subprocess
+    _lib.lib()                                                   # make sure the library is built
+    libdir = os.path.join(ROOT, "betapose_amd")
+    env = dict(os.environ, LD_LIBRARY_PATH=libdir + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    for cc, std, src in (("gcc", "-std=c99", "c_abi_check.c"), ("g++", "-std=c++11", "compat_check.cpp")):
+        exe = str(tmp_path / src.split(".")[0])
+        cmd = [cc, std, "-pedantic", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+               os.path.join(ROOT, "examples", src), "-o", exe, "-L" + libdir, "-lbetapose_hip", "-Wl,-rpath," + libdir]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        r = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=120)
+        assert r.returncode == 0, (src, r.returncode, r.stdout, r.stderr)
