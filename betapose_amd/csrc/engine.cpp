@@ -50,45 +50,45 @@ float* Net::upload_weights(const float* host, size_t count) {
 // (tools/tune_conv.py, 64x64 tile): {M, CoutPad, K-chunks, slices}.  Other shapes use the heuristic below.
 struct SplitEntry { int M, CoutPad, nchunks, splits; };
 static const SplitEntry kSplitTable[] = {
-    {80, 512, 64, 6},
-    {80, 512, 144, 10},
-    {80, 2048, 16, 3},
-    {80, 2048, 32, 4},
-    {169, 64, 32, 8},
-    {169, 256, 16, 5},
-    {169, 512, 32, 5},
-    {169, 1024, 144, 5},
-    {320, 256, 32, 5},
-    {320, 256, 72, 6},
-    {320, 512, 32, 5},
-    {320, 1024, 8, 1},
-    {320, 1024, 16, 3},
-    {320, 1024, 144, 6},
-    {676, 64, 16, 4},
-    {676, 128, 8, 3},
-    {676, 256, 16, 3},
-    {676, 256, 24, 5},
-    {676, 512, 72, 5},
-    {1280, 128, 16, 4},
-    {1280, 128, 36, 5},
-    {1280, 256, 16, 3},
-    {1280, 512, 4, 1},
-    {1280, 512, 8, 1},
-    {1280, 512, 72, 3},
-    {2704, 64, 8, 1},
-    {2704, 128, 8, 1},
-    {2704, 128, 12, 2},
-    {2704, 256, 36, 4},
-    {5120, 64, 2, 1},
-    {5120, 64, 8, 1},
-    {5120, 64, 18, 3},
-    {5120, 64, 36, 3},
-    {5120, 128, 8, 1},
-    {5120, 256, 2, 1},
-    {10816, 64, 4, 1},
-    {10816, 128, 18, 3},
-    {43264, 64, 2, 1},
-    {43264, 64, 9, 1}
+    {    80,   512,   64,  6},
+    {    80,   512,  144, 12},
+    {    80,  2048,   16,  3},
+    {    80,  2048,   32,  3},
+    {   169,    64,   32,  8},
+    {   169,   256,   16,  5},
+    {   169,   512,   32,  5},
+    {   169,  1024,  144,  5},
+    {   320,   256,   32,  5},
+    {   320,   256,   72,  8},
+    {   320,   512,   32,  5},
+    {   320,  1024,    8,  1},
+    {   320,  1024,   16,  3},
+    {   320,  1024,  144,  6},
+    {   676,    64,   16,  4},
+    {   676,   128,    8,  3},
+    {   676,   256,   16,  3},
+    {   676,   256,   24,  5},
+    {   676,   512,   72,  5},
+    {  1280,   128,   16,  3},
+    {  1280,   128,   36,  5},
+    {  1280,   256,   16,  3},
+    {  1280,   512,    4,  1},
+    {  1280,   512,    8,  1},
+    {  1280,   512,   72,  3},
+    {  2704,    64,    8,  1},
+    {  2704,   128,    8,  1},
+    {  2704,   128,   12,  2},
+    {  2704,   256,   36,  4},
+    {  5120,    64,    2,  1},
+    {  5120,    64,    8,  1},
+    {  5120,    64,   18,  3},
+    {  5120,    64,   36,  3},
+    {  5120,   128,    8,  1},
+    {  5120,   256,    2,  1},
+    { 10816,    64,    4,  1},
+    { 10816,   128,   18,  3},
+    { 43264,    64,    2,  1},
+    { 43264,    64,    9,  1},
 };
 
 // fp16-MFMA kernel: same procedure (tools/tune_conv.py --f16, profiles/r01_splitk_tuning_f16.txt)
@@ -111,7 +111,7 @@ static const SplitEntry kSplitTableF16[] = {
     {   676,   128,    8,  1},
     {   676,   256,   16,  1},
     {   676,   256,   24,  1},
-    {   676,   512,   72,  5},
+    {   676,   512,   72,  3},
     {  1280,   128,   16,  1},
     {  1280,   128,   36,  3},
     {  1280,   256,   16,  1},
@@ -137,10 +137,10 @@ static const SplitEntry kSplitTableF16[] = {
 // bf16x3 kernel: same procedure (tools/tune_conv.py --b3, profiles/r01_splitk_tuning_bf16x3.txt)
 static const SplitEntry kSplitTableB3[] = {
     {    80,   512,   64,  6},
-    {    80,   512,  144, 10},
+    {    80,   512,  144, 12},
     {    80,  2048,   16,  3},
     {    80,  2048,   32,  3},
-    {   169,    64,   32, 10},
+    {   169,    64,   32,  8},
     {   169,   256,   16,  5},
     {   169,   512,   32,  5},
     {   169,  1024,  144,  5},
