@@ -79,7 +79,7 @@ enum ConvTile : int { TILE_64x64 = 0, TILE_128x64 = 1 };
 // when non-null, launch_conv brackets the implicit-GEMM kernel itself (not the split-K reduce) with these events
 struct ConvProfHook { hipEvent_t e0, e1; };
 extern thread_local ConvProfHook* g_conv_prof;
-bool conv_f16_eligible(const ConvParams& p);
+bool conv_h16_eligible(const ConvParams& p);   // layer can run on the 16-bit-operand kernels (w16 present, Cin % 32 == 0)
 int conv_vec_mode(const ConvParams& p);   // 0 scalar gather, 1 Cin % 32 == 0, 2 four-channel-packed stem
 
 void launch_conv(const ConvParams& p, int tile, hipStream_t s);

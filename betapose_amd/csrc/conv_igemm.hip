@@ -653,7 +653,7 @@ int conv_vec_mode(const ConvParams& p) {
     return 0;
 }
 
-bool conv_f16_eligible(const ConvParams& p) {
+bool conv_h16_eligible(const ConvParams& p) {
     return p.w16 != nullptr && (p.Cin % 32 == 0) && (p.in_ld % 4 == 0) && p.ksize <= 8;
 }
 
@@ -667,12 +667,12 @@ void launch_conv(const ConvParams& p, int tile, hipStream_t s) {
     BP_CHECK(p.Kpad % BK == 0 && p.nchunks == p.Kpad / BK, "Kpad");
     BP_CHECK(p.splits >= 1 && (p.splits == 1 || (p.partial != nullptr && p.tickets != nullptr)), "split-K workspace");
     BP_CHECK((long long)p.N * p.H * p.W * p.in_ld * 4 < (long long)OOB, "activation tensor too large for 32-bit offsets");
-    if (p.mfma_mode == PREC_F16 && conv_f16_eligible(p)) {
+    if (p.mfma_mode == PREC_F16 && conv_h16_eligible(p)) {
         switch (tile) {
             case TILE_128x64: launch_h_t<2, 1, 1>(p, s); break;
             default: launch_h_t<1, 1, 1>(p, s); break;
         }
-    } else if (p.mfma_mode == PREC_BF16X3 && conv_f16_eligible(p)) {
+    } else if (p.mfma_mode == PREC_BF16X3 && conv_h16_eligible(p)) {
         BP_CHECK(tile == TILE_64x64, "the bf16x3 kernel is built for the 64x64 tile");
         launch_h_t<1, 1, 3>(p, s);
     } else {

@@ -411,7 +411,7 @@ int Net::profile(int batch, int iters, float* ms, int* info, int cap, hipStream_
             if (conv) {
                 choose_launch(ops_[i], batch, force_tile_, sk_target_, sk_min_chunks_, sk_max_splits_, &tile, &splits, &cps);
                 vec = conv_vec_mode(ops_[i].conv) ? 1 : 0;
-                if (ops_[i].conv.mfma_mode != PREC_F32 && conv_f16_eligible(ops_[i].conv))
+                if (ops_[i].conv.mfma_mode != PREC_F32 && conv_h16_eligible(ops_[i].conv))
                     vec = 1 + ops_[i].conv.mfma_mode;   // 2 fp16-MFMA kernel, 3 bf16x3 kernel
             }
             info[4 * i] = conv; info[4 * i + 1] = tile; info[4 * i + 2] = vec; info[4 * i + 3] = splits;
