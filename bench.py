@@ -247,6 +247,7 @@ def main():
     from betapose_amd.weights import fastpose_stream_from_state_dict
 
     _lib.require_gpu()
+    bpd.limit_host_threads()
     rank, world, local = bpd.init_from_env()
     dev = torch.device("cuda", local)
 

@@ -26,6 +26,8 @@ class ImageLoader:
     def __init__(self, im_names, batchSize=1, format='yolo', queueSize=50, reso=608):
         if format != 'yolo':
             raise NotImplementedError(format)
+        from .dist import limit_host_threads
+        limit_host_threads()      # stage threads + a per-core intra-op pool collapse on many-core hosts
         self.img_dir = opt.inputpath
         self.imglist = im_names
         self.reso = int(reso)
@@ -39,23 +41,36 @@ class ImageLoader:
         p.start()
         return self
 
-    def getitem_yolo(self):
+    def _load_one(self, k):
+        """One frame: (tensor [1,3,reso,reso] RGB 0..1, BGR u8 frame, path, (w, h))."""
         import torch
         from PIL import Image
-        for i in range(self.num_batches):
-            img, orig_img, im_name, im_dim_list = [], [], [], []
-            for k in range(i * self.batchSize, min((i + 1) * self.batchSize, self.datalen)):
-                name = os.path.join(self.img_dir, self.imglist[k].rstrip('\n').rstrip('\r'))
-                orig = load_frame_bgr(name)
-                pil = Image.fromarray(np.ascontiguousarray(orig[:, :, ::-1])).resize((self.reso, self.reso), 3)
-                t = torch.from_numpy(np.asarray(pil, dtype=np.uint8).transpose(2, 0, 1).copy()).float().div(255)
-                img.append(t.unsqueeze(0))
-                orig_img.append(orig)
-                im_name.append(name)
-                im_dim_list.append((orig.shape[1], orig.shape[0]))
-            img = torch.cat(img)
-            im_dim_list = torch.FloatTensor(im_dim_list).repeat(1, 2)
-            self.Q.put((img, orig_img, im_name, im_dim_list))
+        name = os.path.join(self.img_dir, self.imglist[k].rstrip('\n').rstrip('\r'))
+        orig = load_frame_bgr(name)
+        pil = Image.fromarray(np.ascontiguousarray(orig[:, :, ::-1])).resize((self.reso, self.reso), 3)
+        t = torch.from_numpy(np.asarray(pil, dtype=np.uint8).transpose(2, 0, 1).copy()).float().div(255)
+        return t.unsqueeze(0), orig, name, (orig.shape[1], orig.shape[0])
+
+    def getitem_yolo(self):
+        # the reference decodes and resizes on this one thread; decode and Pillow's resize release the GIL, so a few
+        # workers run ahead (bounded), results are consumed strictly in list order
+        import torch
+        from collections import deque
+        from concurrent.futures import ThreadPoolExecutor
+        ahead = max(2 * self.batchSize, 8)
+        with ThreadPoolExecutor(max_workers=4) as pool:
+            pending, nxt = deque(), 0
+            for i in range(self.num_batches):
+                lo, hi = i * self.batchSize, min((i + 1) * self.batchSize, self.datalen)
+                while nxt < self.datalen and nxt < hi + ahead:
+                    pending.append(pool.submit(self._load_one, nxt))
+                    nxt += 1
+                items = [pending.popleft().result() for _ in range(lo, hi)]
+                img = torch.cat([it[0] for it in items])
+                orig_img = [it[1] for it in items]
+                im_name = [it[2] for it in items]
+                im_dim_list = torch.FloatTensor([it[3] for it in items]).repeat(1, 2)
+                self.Q.put((img, orig_img, im_name, im_dim_list))
 
     def getitem(self):
         return self.Q.get()

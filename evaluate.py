@@ -71,6 +71,7 @@ def main():
     from betapose_amd.weights import fastpose_stream_from_state_dict, load_kpd_pkl, read_darknet_weights
 
     _lib.require_gpu()
+    bpd.limit_host_threads()
     rank, world, local = bpd.init_from_env()
     obj_id = args.obj_id
     # key points handed to PnP: all 50 on LineMod (betapose_evaluate.py:139), the --left_keypoints best on Occlusion
