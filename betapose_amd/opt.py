@@ -1,5 +1,5 @@
 """Flags of the hot path -- same names and defaults as the reference's argparse singleton
-(3_6Dpose_estimator/opt.py:1-150), restricted to what the inference path reads.  ``opt`` is a module-level
+(3_6Dpose_estimator/opt.py:1-150): the flags the inference path reads, plus the remaining ones accepted and ignored.  ``opt`` is a module-level
 namespace like the reference's; ``parse_args`` refreshes it from a command line."""
 from __future__ import annotations
 
@@ -39,14 +39,42 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument('--synthetic', type=int, default=0, help='run on N seeded synthetic frames / weights')
     p.add_argument('--synth_weights', default=False, action='store_true',
                    help='seeded synthetic weights with real frames / ground truth (plumbing runs without checkpoints)')
-    p.add_argument('--precision', choices=['f32', 'f16'], default='f32',
-                   help='matrix-core operand precision (f16: fp16 MFMA operands, fp32 accumulate; see DESIGN.md)')
+    p.add_argument('--precision', choices=['f32', 'bf16x3', 'f16'], default='f32',
+                   help='matrix-core operand precision: f32 (default), bf16x3 (fp32-accurate split), f16 (fp16 operands, '
+                        'fp32 accumulate); see DESIGN.md 3.1b/c')
     p.add_argument('--streams', type=int, default=4, help='--fused: frames in flight (HIP streams / engine clones)')
     p.add_argument('--load_threads', type=int, default=8, help='--fused: PNG decode threads')
     p.add_argument('--sixd_base', default='/media/data_2/SIXD/hinterstoisser')
     p.add_argument('--yolo_weights', default='')
     p.add_argument('--kpd_weights', default='')
+    # the rest of the reference's flag set (training, visualisation, video input: opt.py:9-150) -- accepted with the
+    # reference's names, types and defaults so that existing command lines and scripts keep parsing; nothing on the
+    # inference path reads them
+    for name, default, typ in _COMPAT_FLAGS:
+        kw = {"default": default, "help": argparse.SUPPRESS}
+        if typ is not None:
+            kw["type"] = typ
+        p.add_argument(name, **kw)
+    p.add_argument('--dist', dest='dist', type=int, default=1, help=argparse.SUPPRESS)
+    p.add_argument('--backend', dest='backend', type=str, default='gloo', help=argparse.SUPPRESS)
+    p.add_argument('--port', dest='port', default=None, help=argparse.SUPPRESS)
+    p.add_argument('--net', dest='demo_net', default='res152', help=argparse.SUPPRESS)
+    p.add_argument('--video', dest='video', default="", help=argparse.SUPPRESS)
+    p.add_argument('--webcam', dest='webcam', type=str, default='0', help=argparse.SUPPRESS)
+    p.add_argument('--vis_fast', dest='vis_fast', default=False, action='store_true', help=argparse.SUPPRESS)
     return p
+
+
+_COMPAT_FLAGS = [
+    ('--expID', 'default', str), ('--dataset', 'coco', str), ('--nThreads', 40, int), ('--debug', False, bool),
+    ('--snapshot', 1, int), ('--addDPG', False, bool), ('--netType', 'hgPRM', str), ('--loadModel', None, str),
+    ('--Continue', False, bool), ('--nFeats', 256, int), ('--nStack', 4, int), ('--use_pyranet', True, bool),
+    ('--LR', 2.5e-4, float), ('--momentum', 0, float), ('--weightDecay', 0, float), ('--crit', 'MSE', str),
+    ('--optMethod', 'rmsprop', str), ('--nEpochs', 200, int), ('--epoch', 0, int), ('--trainBatch', 40, int),
+    ('--validBatch', 20, int), ('--trainIters', 0, int), ('--valIters', 0, int), ('--init', None, str),
+    ('--scale', 0.25, float), ('--rotate', 30, float), ('--hmGauss', 1, int), ('--baseWidth', 9, int),
+    ('--cardinality', 5, int), ('--nResidual', 1, int),
+]
 
 
 opt = build_parser().parse_args([])

@@ -188,3 +188,26 @@ def test_headers_compile_as_plain_c_and_as_a_reference_consumer(tmp_path):
         assert r.returncode == 0, r.stderr
         r = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=120)
         assert r.returncode == 0, (src, r.returncode, r.stdout, r.stderr)
+
+
+def test_every_reference_flag_parses_with_its_default():
+    """The reference's whole flag set (opt.py:9-150; names, dests and defaults recorded here) is accepted, so existing
+    command lines keep parsing; defaults are the reference's."""
+    from betapose_amd.opt import build_parser
+    ref = {"expID": "default", "dataset": "coco", "nThreads": 40, "debug": False, "snapshot": 1, "addDPG": False,
+           "netType": "hgPRM", "loadModel": None, "Continue": False, "nFeats": 256, "nClasses": 50, "nStack": 4,
+           "fast_inference": True, "use_pyranet": True, "LR": 2.5e-4, "momentum": 0, "weightDecay": 0, "crit": "MSE",
+           "optMethod": "rmsprop", "nEpochs": 200, "epoch": 0, "trainBatch": 40, "validBatch": 20, "trainIters": 0,
+           "valIters": 0, "init": None, "inputResH": 320, "inputResW": 256, "outputResH": 80, "outputResW": 64,
+           "scale": 0.25, "rotate": 30, "hmGauss": 1, "baseWidth": 9, "cardinality": 5, "nResidual": 1, "dist": 1,
+           "backend": "gloo", "port": None, "demo_net": "res152", "inputpath": "", "inputlist": "", "mode": "normal",
+           "outputpath": "examples/res/", "inp_dim": "416", "confidence": 0.01, "nms_thesh": 0.6, "save_img": False,
+           "vis": False, "profile": False, "format": None, "detbatch": 1, "posebatch": 80, "video": "", "webcam": "0",
+           "save_video": False, "vis_fast": False, "sp": False, "obj_id": 5, "left_keypoints": 10}
+    ns = build_parser().parse_args([])
+    for k, v in ref.items():
+        assert hasattr(ns, k), k
+        assert getattr(ns, k) == v, (k, getattr(ns, k), v)
+    ns = build_parser().parse_args("--nClasses 50 --indir in --outdir out --sp --profile --conf 0.9 --obj_id 9 "
+                                   "--nThreads 4 --vis_fast --net res50 --webcam 1".split())
+    assert (ns.inputpath, ns.outputpath, ns.confidence, ns.obj_id, ns.demo_net, ns.webcam) == ("in", "out", 0.9, 9, "res50", "1")
