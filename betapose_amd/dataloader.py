@@ -72,6 +72,9 @@ class ImageLoader:
                 im_dim_list = torch.FloatTensor([it[3] for it in items]).repeat(1, 2)
                 self.Q.put((img, orig_img, im_name, im_dim_list))
 
+    def getitem_ssd(self):
+        raise NotImplementedError("the SSD input format (dataloader.py:111-148) is not part of this path; use format='yolo'")
+
     def getitem(self):
         return self.Q.get()
 
@@ -187,7 +190,10 @@ class DetectionProcessor:
 class DataWriter:
     """dataloader.py:649-763: heat-maps -> key points -> pPose-NMS -> key-point pruning -> PnP."""
 
-    def __init__(self, cam_K, left_number, kp_model_vertices, save_video=False, queueSize=1024):
+    def __init__(self, cam_K, left_number, kp_model_vertices, save_video=False, savepath='examples/res/1.avi',
+                 fourcc=0, fps=25, frameSize=(640, 480), queueSize=1024):
+        # same positional signature as the reference (dataloader.py:650-653); the video-writer arguments are accepted
+        # and unused
         if save_video:
             raise NotImplementedError("video output is outside the hot path")
         self.stopped = False
