@@ -12,7 +12,7 @@ import numpy as np
 
 from .darknet import Darknet
 from .eval import getPrediction
-from .img import crop_from_dets_frame, load_frame_bgr
+from .img import crop_from_dets, crop_from_dets_frame, load_frame_bgr  # noqa: F401  (crop_from_dets: reference name)
 from .ops import solve_pnp
 from .opt import opt
 from .pPose_nms import pose_nms

@@ -36,3 +36,21 @@ def crop_from_dets_frame(frame_bgr_u8, boxes, inputResH: int = 320, inputResW: i
     inps, pts = ops.crop(frames, boxes=b, oh=inputResH, ow=inputResW)
     pts = pts.cpu()
     return inps, pts[:, 0:2].clone(), pts[:, 2:4].clone()
+
+
+def crop_from_dets(img, boxes, inps, pt1, pt2):
+    """The reference's signature and side effects (dataloader.py:794-835): ``img`` is the RGB float CHW frame in 0..1
+    that ``im_to_torch`` made from the u8 frame; the per-channel means are subtracted from it IN PLACE, ``inps`` /
+    ``pt1`` / ``pt2`` (pre-allocated by the caller) are filled per box and returned.  The crop itself runs in the HIP
+    kernel on the u8 frame recovered from ``img`` (x * 255 is exact for values that came from u8)."""
+    import torch
+    frame = (img.detach().cpu() * 255.0).round().clamp_(0, 255).to(torch.uint8)          # RGB u8 CHW
+    frame_bgr = frame.flip(0).permute(1, 2, 0).contiguous().numpy()
+    img[0].add_(-0.406)
+    img[1].add_(-0.457)
+    img[2].add_(-0.480)
+    out, p1, p2 = crop_from_dets_frame(frame_bgr, boxes, inps.shape[2], inps.shape[3])
+    inps.copy_(out.to(inps.device))
+    pt1.copy_(p1)
+    pt2.copy_(p2)
+    return inps, pt1, pt2

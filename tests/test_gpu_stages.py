@@ -292,3 +292,23 @@ def test_crop_and_select_match_reference_edge_goldens(cuda):
     np.testing.assert_array_equal(a, e["gpe_preds_hm"])
     np.testing.assert_allclose(b, e["gpe_preds_img"], rtol=0, atol=1e-4)
     np.testing.assert_array_equal(c, e["gpe_maxval"])
+
+
+def test_crop_from_dets_reference_signature(cuda):
+    """dataloader.crop_from_dets(img, boxes, inps, pt1, pt2) with the reference's arguments and side effects, against the
+    reference's own outputs on the edge-box fixture."""
+    from betapose_amd.dataloader import crop_from_dets
+    from betapose_amd.img import im_to_torch
+    e = helpers.golden("edges.npz")
+    fr = synth.synth_frame(int(e["crop_frame_seed"]))
+    idx = [0, 7, 19, 41, 50, 63]
+    boxes = torch.from_numpy(e["crop_boxes"][idx])
+    img = im_to_torch(np.ascontiguousarray(fr[:, :, ::-1]))
+    before = img.clone()
+    inps, pt1, pt2 = torch.zeros(len(idx), 3, 320, 256), torch.zeros(len(idx), 2), torch.zeros(len(idx), 2)
+    r = crop_from_dets(img, boxes, inps, pt1, pt2)
+    assert r[0] is inps and r[1] is pt1 and r[2] is pt2
+    np.testing.assert_array_equal(pt1.numpy(), e["crop_pt1"][idx])
+    np.testing.assert_array_equal(pt2.numpy(), e["crop_pt2"][idx])
+    assert np.abs(inps.reshape(len(idx), -1).numpy()[:, e["crop_samp_idx"]] - e["crop_samples"][idx]).max() <= 2e-6
+    np.testing.assert_allclose((before - img)[:, 0, 0].numpy(), [0.406, 0.457, 0.480], atol=1e-6)   # in-place means
