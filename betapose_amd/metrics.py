@@ -103,3 +103,19 @@ def evaluate_results(final_result: List[dict], gt_frames: Dict[int, dict], model
             "mean_2d_acc": float(np.mean(np.array(proj) < pixel_thresh)) if proj else float("nan"),
             "mean_iou": float(np.mean(np.array(ious) > 0.5)) if ious else float("nan"),
             "mean_add_err_mm": float(np.mean(add_errs)) if add_errs else float("nan"), "n": len(ious)}
+
+
+class Model3D:
+    """The two methods of the reference's ``Model3D`` the harness uses (utils/model.py:29-46,79-85;
+    betapose_evaluate.py:65-81): ``load(path, scale=...)`` of an ASCII .ply into ``vertices`` and ``refine(total_kp)``."""
+
+    def __init__(self, file_to_load=None):
+        self.vertices = None
+        if file_to_load:
+            self.load(file_to_load)
+
+    def load(self, path, demean=False, scale=1.0):
+        self.vertices = load_ply_vertices(path) * scale
+
+    def refine(self, total_kp=30, save=False, save_path="test.ply"):
+        self.vertices = refine_keypoints(self.vertices, total_kp)

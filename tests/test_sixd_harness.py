@@ -109,3 +109,15 @@ def test_refine_matches_reference_model3d():
     for k in "abcd":
         got = metrics.refine_keypoints(g[k + "_in"], int(g[k + "_keep"]))
         np.testing.assert_array_equal(got, g[k + "_out"], err_msg="case " + k)
+
+
+def test_model3d_load_and_refine(tmp_path):
+    """``Model3D().load(path, scale=0.001)`` + ``.refine(K)`` as betapose_evaluate.py:78-81 uses them."""
+    from helpers import golden
+    g = golden("refine.npz")
+    synth._write_ply(str(tmp_path / "obj_01.ply"), g["b_in"] * 1000.0)            # millimetres on disk (%.6f)
+    m = metrics.Model3D()
+    m.load(str(tmp_path / "obj_01.ply"), scale=0.001)
+    assert m.vertices.shape == g["b_in"].shape and np.abs(m.vertices - g["b_in"]).max() < 1e-9
+    m.refine(int(g["b_keep"]), save=True)
+    assert m.vertices.shape == g["b_out"].shape and np.abs(m.vertices - g["b_out"]).max() < 1e-9
