@@ -33,24 +33,64 @@ def iou(gt_box, est_box):
     return inter / float(A + B - inter)
 
 
+_PLY_TYPES = {"char": "i1", "int8": "i1", "uchar": "u1", "uint8": "u1", "short": "i2", "int16": "i2", "ushort": "u2",
+              "uint16": "u2", "int": "i4", "int32": "i4", "uint": "u4", "uint32": "u4", "float": "f4", "float32": "f4",
+              "double": "f8", "float64": "f8"}
+
+
 def load_ply_vertices(path: str) -> np.ndarray:
-    """ASCII PLY vertex x,y,z (the designated key-point / model files are ASCII)."""
+    """Vertex x, y, z of a .ply file as float64 [n, 3] -- what ``Model3D.load`` takes from plyfile
+    (utils/model.py:79-85).  ASCII and binary (little / big endian) files; the vertex element must come first, as in
+    the SIXD models and the designator's key-point files."""
     with open(path, "rb") as f:
         head = b""
-        while not head.endswith(b"end_header\n"):
+        while not head.rstrip().endswith(b"end_header"):
             line = f.readline()
             if not line:
                 raise ValueError("%s: no end_header" % path)
             head += line
-        text = head.decode("ascii", "replace")
-        if "format ascii" not in text:
-            raise NotImplementedError("%s: only ASCII PLY is supported" % path)
-        n = 0
-        for ln in text.split("\n"):
-            if ln.startswith("element vertex"):
-                n = int(ln.split()[2])
-        rows = [f.readline().split()[:3] for _ in range(n)]
-    return np.array(rows, dtype=np.float64)
+        lines = [ln.strip() for ln in head.decode("ascii", "replace").split("\n") if ln.strip()]
+        if not lines or lines[0] != "ply":
+            raise ValueError("%s: not a PLY file" % path)
+        fmt, n, props, elem_order, cur = None, 0, [], [], None
+        for ln in lines[1:]:
+            tok = ln.split()
+            if tok[0] == "format":
+                fmt = tok[1]
+            elif tok[0] == "element":
+                cur = tok[1]
+                elem_order.append(cur)
+                if cur == "vertex":
+                    n = int(tok[2])
+            elif tok[0] == "property" and cur == "vertex":
+                if tok[1] == "list":
+                    raise ValueError("%s: list property in the vertex element" % path)
+                if tok[1] not in _PLY_TYPES:
+                    raise ValueError("%s: unknown property type %s" % (path, tok[1]))
+                props.append((tok[2], _PLY_TYPES[tok[1]]))
+        if fmt is None or not elem_order or elem_order[0] != "vertex":
+            raise ValueError("%s: the vertex element must be the first element" % path)
+        names = [p_[0] for p_ in props]
+        if not all(a in names for a in ("x", "y", "z")):
+            raise ValueError("%s: vertex element without x, y, z" % path)
+        if fmt == "ascii":
+            ix = [names.index(a) for a in ("x", "y", "z")]
+            rows = []
+            for _ in range(n):
+                tok = f.readline().split()
+                if len(tok) < len(names):
+                    raise ValueError("%s: truncated vertex list" % path)
+                rows.append([float(tok[i]) for i in ix])
+            return np.array(rows, dtype=np.float64).reshape(n, 3)
+        if fmt not in ("binary_little_endian", "binary_big_endian"):
+            raise ValueError("%s: unknown PLY format %s" % (path, fmt))
+        end = "<" if fmt == "binary_little_endian" else ">"
+        dt = np.dtype([(nm, end + t) for nm, t in props])
+        buf = f.read(n * dt.itemsize)
+        if len(buf) < n * dt.itemsize:
+            raise ValueError("%s: truncated vertex data" % path)
+        v = np.frombuffer(buf, dtype=dt, count=n)
+        return np.stack([v["x"], v["y"], v["z"]], axis=1).astype(np.float64)
 
 
 def refine_keypoints(vertices: np.ndarray, keep: int) -> np.ndarray:

@@ -121,3 +121,43 @@ def test_model3d_load_and_refine(tmp_path):
     assert m.vertices.shape == g["b_in"].shape and np.abs(m.vertices - g["b_in"]).max() < 1e-9
     m.refine(int(g["b_keep"]), save=True)
     assert m.vertices.shape == g["b_out"].shape and np.abs(m.vertices - g["b_out"]).max() < 1e-9
+
+
+def test_ply_reader_ascii_and_binary(tmp_path):
+    """ASCII (extra properties, comments), binary little- and big-endian vertex data with mixed property types, and the
+    refusals: vertex element not first, list property, truncated data."""
+    import pytest
+    rng = np.random.default_rng(8)
+    pts = rng.normal(size=(17, 3)).astype(np.float32)
+    col = rng.integers(0, 256, (17, 3), dtype=np.uint8)
+    a = tmp_path / "a.ply"
+    with open(a, "w") as f:
+        f.write("ply\nformat ascii 1.0\ncomment made by hand\nelement vertex 17\nproperty float x\nproperty float y\n"
+                "property float z\nproperty uchar red\nproperty uchar green\nproperty uchar blue\nelement face 0\n"
+                "property list uchar int vertex_indices\nend_header\n")
+        for p_, c in zip(pts, col):
+            f.write("%r %r %r %d %d %d\n" % (float(p_[0]), float(p_[1]), float(p_[2]), c[0], c[1], c[2]))
+    np.testing.assert_allclose(metrics.load_ply_vertices(str(a)), pts.astype(np.float64), rtol=0, atol=0)
+    for fmt, end in (("binary_little_endian", "<"), ("binary_big_endian", ">")):
+        b = tmp_path / (fmt + ".ply")
+        dt = np.dtype([("nx", end + "f4"), ("x", end + "f8"), ("red", "u1"), ("y", end + "f4"), ("z", end + "f4")])
+        rec = np.zeros(17, dt)
+        rec["x"], rec["y"], rec["z"], rec["red"], rec["nx"] = pts[:, 0], pts[:, 1], pts[:, 2], col[:, 0], 1.5
+        with open(b, "wb") as f:
+            f.write(("ply\nformat %s 1.0\nelement vertex 17\nproperty float nx\nproperty double x\nproperty uchar red\n"
+                     "property float y\nproperty float z\nend_header\n" % fmt).encode())
+            f.write(rec.tobytes())
+        np.testing.assert_array_equal(metrics.load_ply_vertices(str(b)), pts.astype(np.float64))
+        with open(b, "rb") as f:
+            data = f.read()
+        (tmp_path / "short.ply").write_bytes(data[:-9])
+        with pytest.raises(ValueError, match="truncated"):
+            metrics.load_ply_vertices(str(tmp_path / "short.ply"))
+    (tmp_path / "face_first.ply").write_text("ply\nformat ascii 1.0\nelement face 0\nproperty list uchar int vertex_indices\n"
+                                             "element vertex 1\nproperty float x\nproperty float y\nproperty float z\n"
+                                             "end_header\n0 0 0\n")
+    with pytest.raises(ValueError, match="first element"):
+        metrics.load_ply_vertices(str(tmp_path / "face_first.ply"))
+    (tmp_path / "junk.ply").write_text("solid not a ply\nend_header\n")
+    with pytest.raises(ValueError, match="not a PLY"):
+        metrics.load_ply_vertices(str(tmp_path / "junk.ply"))
