@@ -42,8 +42,8 @@ def test_dynamic_write_results_convention(cuda):
     assert dynamic_write_results(pred, 0.95, 80) == 0
 
 
-@pytest.mark.parametrize("occlusion", [False, True])
-def test_evaluate_dataset_layout_closed_loop(tmp_path, cuda, occlusion):
+@pytest.mark.parametrize("occlusion,staged", [(False, False), (True, False), (False, True)])
+def test_evaluate_dataset_layout_closed_loop(tmp_path, cuda, occlusion, staged):
     """The non-synthetic route of the harness (--indir frames + --sixd_base ground truth, LineMod and Occlusion
     protocol): the ground-truth tree is written from the pipeline's own poses and boxes, so the three printed
     numbers must all be 1.000 -- this exercises frame files -> engines -> JSON -> gt.yml / models / kpmodels
@@ -85,8 +85,8 @@ def test_evaluate_dataset_layout_closed_loop(tmp_path, cuda, occlusion):
     script = "occlusion_evaluate.py" if occlusion else "evaluate.py"
     out = tmp_path / "out"
     r = subprocess.run([sys.executable, os.path.join(ROOT, script), "--indir", str(indir), "--outdir", str(out),
-                        "--sixd_base", str(tmp_path / "sixd"), "--synth_weights", "--fused",
-                        "--obj_id", str(obj_id), "--left_keypoints", "10"],
+                        "--sixd_base", str(tmp_path / "sixd"), "--synth_weights"] + (["--sp"] if staged else ["--fused"]) +
+                       ["--obj_id", str(obj_id), "--left_keypoints", "10"],
                        capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stdout + r.stderr
     nums = dict(re.findall(r"(Mean add accuracy|2d reprojection accuracy|Mean IoU) for seq \d+ is: ([\d.nan]+)", r.stdout))
