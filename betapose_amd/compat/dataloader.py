@@ -1,0 +1,3 @@
+"""``from dataloader import ImageLoader, DetectionLoader, DetectionProcessor, DataWriter, Mscoco, crop_from_dets``."""
+from betapose_amd.dataloader import (DataWriter, DetectionLoader, DetectionProcessor, ImageLoader, Mscoco,  # noqa: F401
+                                     crop_from_dets)

@@ -22,6 +22,19 @@ def projection_error_2d(gt_pose, est_pose, model, cam):
     return float(np.mean(np.linalg.norm(g[:2].T - e[:2].T, axis=1)))
 
 
+def rot_error(gt_pose, est_pose):
+    """Angle of the relative rotation in degrees, 0..180 (utils/metrics.py:35-67 computes the same angle through
+    quaternions)."""
+    R = np.asarray(gt_pose)[:3, :3] @ np.asarray(est_pose)[:3, :3].T
+    return float(np.degrees(np.arccos(np.clip((np.trace(R) - 1.0) / 2.0, -1.0, 1.0))))
+
+
+def trans_error(gt_pose, est_pose):
+    """(norm, per-axis absolute) translation error (utils/metrics.py:70-74)."""
+    d = np.asarray(gt_pose)[:3, 3] - np.asarray(est_pose)[:3, 3]
+    return float(np.linalg.norm(d)), np.abs(d)
+
+
 def iou(gt_box, est_box):
     xA, yA = max(gt_box[0], est_box[0]), max(gt_box[1], est_box[1])
     xB, yB = min(gt_box[2], est_box[2]), min(gt_box[3], est_box[3])
