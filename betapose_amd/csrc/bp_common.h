@@ -74,7 +74,8 @@ struct ConvParams {
 // arithmetic of the matrix-core operands (accumulation and activations are always fp32)
 enum Precision : int { PREC_F32 = 0, PREC_F16 = 1, PREC_BF16X3 = 2 };
 
-enum ConvTile : int { TILE_64x64 = 0, TILE_128x64 = 1 };
+// TILE_W64_<WM>x<WN>: conv_w64.hip, WM x WN waves of 64x64 each (16-bit precision modes only)
+enum ConvTile : int { TILE_64x64 = 0, TILE_128x64 = 1, TILE_W64_1x1 = 2, TILE_W64_1x2 = 3, TILE_W64_2x1 = 5, TILE_W64_2x2 = 6 };
 
 // when non-null, launch_conv brackets the implicit-GEMM kernel itself (not the split-K reduce) with these events
 struct ConvProfHook { hipEvent_t e0, e1; };
@@ -83,6 +84,8 @@ bool conv_h16_eligible(const ConvParams& p);   // layer can run on the 16-bit-op
 int conv_vec_mode(const ConvParams& p);   // 0 scalar gather, 1 Cin % 32 == 0, 2 four-channel-packed stem
 
 void launch_conv(const ConvParams& p, int tile, hipStream_t s);
+void launch_conv_w64(const ConvParams& p, int tile, hipStream_t s);   // conv_w64.hip
+bool conv_tile_is_w64(int tile);
 int conv_tiles(const ConvParams& p, int tile);   // blocks per K-slice
 int conv_tile_bm(int tile);
 int conv_tile_bn(int tile);

@@ -318,7 +318,7 @@ int bp_kpd_tap_copy(bp_kpd* k, int i, int batch, float* d_out, void* stream) {
 int bp_yolo_set_policy(bp_yolo* y, int t, int mc, int ms, int ft) {
     BP_TRY
     BP_CHECK(y, "null argument");
-    BP_CHECK(t >= 1 && mc >= 1 && ms >= 1 && ft >= -1 && ft <= bp::TILE_128x64, "policy values out of range");
+    BP_CHECK(t >= 1 && mc >= 1 && ms >= 1 && ft >= -1 && ft <= bp::TILE_W64_2x2, "policy values out of range");
     y->net->set_splitk_policy(t, mc);
     y->net->set_max_splits(ms);
     y->net->set_force_tile(ft);
@@ -344,7 +344,7 @@ int bp_kpd_set_precision(bp_kpd* k, int prec) {
 int bp_kpd_set_policy(bp_kpd* k, int t, int mc, int ms, int ft) {
     BP_TRY
     BP_CHECK(k, "null argument");
-    BP_CHECK(t >= 1 && mc >= 1 && ms >= 1 && ft >= -1 && ft <= bp::TILE_128x64, "policy values out of range");
+    BP_CHECK(t >= 1 && mc >= 1 && ms >= 1 && ft >= -1 && ft <= bp::TILE_W64_2x2, "policy values out of range");
     k->net->set_splitk_policy(t, mc);
     k->net->set_max_splits(ms);
     k->net->set_force_tile(ft);
@@ -447,14 +447,15 @@ int bp_conv2d(const float* d_in, int N, int H, int W, int Cin, const float* h_w,
         t -= t >= 32 ? 32 : 16;
         net.set_precision(prec);
         BP_CHECK(net.ops_[0].conv.mfma_mode == prec, "layer is not eligible for the 16-bit MFMA paths (needs Cin % 32 == 0)");
+    } else {
+        BP_CHECK(!bp::conv_tile_is_w64(t), "w64 tiles need a 16-bit precision mode (tile + 16 / + 32)");
     }
     bp::ConvParams p = net.ops_[0].conv;
     p.N = N; p.M = N * OH * OW;
     if (t < 0) t = bp::TILE_64x64;
     int sp = splits;
     if (sp <= 0) {
-        const int bm = bp::conv_tile_bm(t);
-        const long long blocks = (long long)((p.M + bm - 1) / bm) * (p.CoutPad / 64);
+        const long long blocks = bp::conv_tiles(p, t);
         sp = 1;
         while (blocks * sp < 512 && p.nchunks / (sp + 1) >= 4 && sp < 64) ++sp;
     }
@@ -463,7 +464,7 @@ int bp_conv2d(const float* d_in, int N, int H, int W, int Cin, const float* h_w,
     p.splits = sp; p.chunks_per_split = per;
     if (sp > 1) {
         const int tiles = bp::conv_tiles(p, t);
-        p.partial = net.arena_.alloc((size_t)sp * tiles * bp::conv_tile_bm(t) * 64);
+        p.partial = net.arena_.alloc((size_t)sp * tiles * bp::conv_tile_bm(t) * bp::conv_tile_bn(t));
         p.tickets = (int*)net.arena_.alloc_bytes((size_t)tiles * sizeof(int));
         BP_HIP(hipMemset(p.tickets, 0, (size_t)tiles * sizeof(int)));
     }
@@ -481,19 +482,27 @@ int bp_conv2d(const float* d_in, int N, int H, int W, int Cin, const float* h_w,
         unsigned long long t0 = ~0ull;
         for (int b = 0; b < nb; ++b)
             if (h[(size_t)b * 8]) t0 = std::min(t0, h[(size_t)b * 8]);
-        double acc[5] = {0, 0, 0, 0, 0}, last = 0;
-        int cnt[5] = {0, 0, 0, 0, 0};
+        double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last = 0;
+        int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int b = 0; b < nb; ++b)
-            for (int k = 0; k < 5; ++k) {
+            for (int k = 0; k < 8; ++k) {
                 const unsigned long long v = h[(size_t)b * 8 + k];
                 if (!v) continue;
-                acc[k] += (double)(v - t0); ++cnt[k];
+                acc[k] += (double)(v - h[(size_t)b * 8]); ++cnt[k];      // relative to the block's own entry
                 last = std::max(last, (double)(v - t0));
             }
-        std::fprintf(stderr, "[stamps] blocks=%d  mean cycles after the first block entered: entry %.0f | index math done %.0f | "
-                     "chunk 0 in LDS %.0f | K loop done %.0f | stores done %.0f (unsplit only) | last mark %.0f\n", nb,
-                     cnt[0] ? acc[0] / cnt[0] : 0, cnt[1] ? acc[1] / cnt[1] : 0, cnt[2] ? acc[2] / cnt[2] : 0,
-                     cnt[3] ? acc[3] / cnt[3] : 0, cnt[4] ? acc[4] / cnt[4] : 0, last);
+        auto mean = [&](int k) { return cnt[k] ? acc[k] / cnt[k] : 0.0; };
+        if (std::getenv("BP_W64_ABLATE") && (std::atoi(std::getenv("BP_W64_ABLATE")) & 64)) {
+            double sum[4] = {0, 0, 0, 0};
+            for (int b = 0; b < nb; ++b) for (int k = 0; k < 4; ++k) sum[k] += (double)h[(size_t)b * 8 + 4 + k];
+            const double stages = 2.0 * p.chunks_per_split * nb;
+            std::fprintf(stderr, "[stage timing] cycles per stage: issue slots 0..UPW %.0f | slots ..SYNC %.0f | wait+barrier %.0f | SYNC..end %.0f\n",
+                         sum[0] / stages, sum[1] / stages, sum[2] / stages, sum[3] / stages);
+        }
+        std::fprintf(stderr, "[stamps] blocks=%d  mean cycles since the block's entry: index math done %.0f | chunk 0 in LDS %.0f | "
+                     "K loop done %.0f | slab parked + ticket %.0f (%d blocks) | slices combined %.0f (%d) | stores done %.0f (%d) | "
+                     "last mark of the grid %.0f after the first entry\n", nb, mean(1), mean(2), mean(3), mean(5), cnt[5], mean(6),
+                     cnt[6], mean(4), cnt[4], last);
     }
     if (iters > 0 && ms_per_iter) {
         hipEvent_t e0, e1;

@@ -1,0 +1,181 @@
+// Device-side helpers shared by the implicit-GEMM convolution kernels (conv_igemm.hip, conv_w64.hip): vector types,
+// the element-wise epilogue for the store modes the staged 16-B path does not cover, raw-buffer loads, exact fast division.
+#pragma once
+#include <hip/hip_ext.h>
+
+#include <type_traits>
+#include <utility>
+
+#include "bp_common.h"
+
+namespace bp {
+
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N-1>{}) -- for bodies whose
+// inner loop bounds and register-array indices must be constants (a 48-trip `#pragma unroll` body was left rolled by
+// hipcc, which put the operand fragments in scratch)
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// native vector types: they stay in VGPRs (HIP's float4 struct made hipcc park the prefetch registers in scratch)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static constexpr int BK = 32;
+static constexpr int LDS_LD = 36;
+static constexpr unsigned OOB = 0x7fffff00u;   // byte offset beyond any descriptor's num_records -> load returns 0
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == ACT_LEAKY) return v > 0.f ? v : 0.1f * v;
+    if (act == ACT_RELU) return v > 0.f ? v : 0.f;
+    return v;
+}
+
+// v = raw accumulator for output element (m, n); bias = p.bias[n] (loaded once per lane by the caller: the
+// epilogue's stores may alias p.bias as far as the compiler knows, so an in-loop load is re-issued and waited
+// for after every store -- 16 serialized L2 round trips per tile, measured as the dominant cost of short layers)
+__device__ __forceinline__ void epilogue_store(const ConvParams& p, int m, int n, float v, float bias) {
+    v += bias;
+    int b = 0, pix = m;
+    const int hw = p.OH * p.OW;
+    const bool need_pix = p.store_mode != ST_NHWC || p.res_scale != nullptr;
+    if (need_pix) {
+        b = m / hw;
+        pix = m - b * hw;
+    }
+    float r = 0.f;
+    if (p.res) {
+        r = p.res[(long long)m * p.res_ld + n];
+        if (p.res_scale) r *= p.res_scale[b * p.Cout + n];
+    }
+    if (!p.res_after_act) v += r;
+    v = apply_act(v, p.act);
+    if (p.res_after_act) v += r;
+    switch (p.store_mode) {
+        case ST_NHWC:
+            p.out[(long long)m * p.out_ld + n] = v;
+            break;
+        case ST_UP2: {
+            const int oy = pix / p.OW, ox = pix - oy * p.OW;
+            const int W2 = 2 * p.OW;
+            float* o = p.out + ((long long)(b * 2 * p.OH + 2 * oy) * W2 + 2 * ox) * p.out_ld + n;
+            o[0] = v;
+            o[p.out_ld] = v;
+            o[(long long)W2 * p.out_ld] = v;
+            o[(long long)(W2 + 1) * p.out_ld] = v;
+        } break;
+        case ST_PIXSHUF: {
+            const int oy = pix / p.OW, ox = pix - oy * p.OW;
+            const int cq = p.Cout >> 2;
+            const int ij = n / cq, c = n - ij * cq;
+            const int y = 2 * oy + (ij >> 1), x = 2 * ox + (ij & 1);
+            p.out[((long long)(b * 2 * p.OH + y) * (2 * p.OW) + x) * p.out_ld + c] = v;
+        } break;
+        case ST_NCHW:
+            p.out[((long long)b * p.Cout + n) * hw + pix] = v;
+            break;
+    }
+}
+
+// 16 accumulators of one lane: column n, rows m_base + (r&3) + 8*(r>>2) -- element-wise epilogue for the store
+// modes / alignments the staged float4 path does not cover (heads with 18 channels, upsample, PixelShuffle, NCHW)
+__device__ __forceinline__ void epilogue_tile(const ConvParams& p, const float* v, int m_base, int n) {
+    if (n >= p.Cout) return;
+    const float bias = p.bias[n];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int m = m_base + (e & 3) + 8 * (e >> 2);
+        if (m < p.M) epilogue_store(p, m, n, v[e], bias);
+    }
+}
+
+__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, int soff) {
+    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, soff, 0);
+    return f32x4{__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w)};
+}
+
+// a - b as ONE v_sub_f32.  Opaque to the optimizer on purpose: hipcc packs neighbouring f32 subtractions into
+// v_pk_add_f32, which is slow beside MFMAs (MI355X_MICROARCH.md, price of fillers).  Kept in a __device__ function: an
+// asm statement with register constraints directly in a __global__ template silently drops the kernel's host stub.
+__device__ __forceinline__ float sub_f32(float a, float b) {
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// exact for 0 <= m < 2^24, d > 0: quotient by float reciprocal + one correction step (a 32-bit integer division
+// costs ~40 VALU instructions; the tile prologue needs 2 per row)
+__device__ __forceinline__ int fast_div(int m, int d, float rcp) {
+    int q = (int)((float)m * rcp);
+    const int r = m - q * d;
+    if (r < 0) --q;
+    else if (r >= d) ++q;
+    return q;
+}
+
+
+// Row loop of the staged (16-B per lane) epilogue: each pass reads 4 consecutive channels of one tile row from the
+// LDS staging tile, applies bias / residual / activation and stores 16 B.  ACT and RES are compile-time (the caller
+// switches once per block): RES 0 none, 1 add before the activation (ResNet), 2 add after it (YOLO shortcut).
+// Output and residual go through raw buffer descriptors whose range ends at row M, so rows past the tensor are dropped
+// by the hardware -- no per-pass branch.
+template <int ACT, int RES>
+__device__ __forceinline__ void epilogue_rows(const float* srow, int s_step, int passes, f32x4 bias4,
+                                              __amdgpu_buffer_rsrc_t rsrcO, unsigned off_o, unsigned step_o,
+                                              __amdgpu_buffer_rsrc_t rsrcR, unsigned off_r, unsigned step_r) {
+#pragma unroll 4
+    for (int pass = 0; pass < passes; ++pass) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(srow);
+        f32x4 r4 = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (RES != 0) r4 = buf_load4(rsrcR, off_r, 0);
+        v += bias4;
+        if constexpr (RES == 1) v += r4;
+        if constexpr (ACT == ACT_LEAKY) {
+            v.x = v.x > 0.f ? v.x : 0.1f * v.x; v.y = v.y > 0.f ? v.y : 0.1f * v.y;
+            v.z = v.z > 0.f ? v.z : 0.1f * v.z; v.w = v.w > 0.f ? v.w : 0.1f * v.w;
+        } else if constexpr (ACT == ACT_RELU) {
+            v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
+            v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+        }
+        if constexpr (RES == 2) v += r4;
+        const u32x4 o = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+        __builtin_amdgcn_raw_buffer_store_b128(o, rsrcO, (int)off_o, 0, 0);
+        srow += s_step;
+        off_o += step_o;
+        off_r += step_r;
+    }
+}
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// LDS rows of the 16-bit kernels are 32 elements = 64 B, unpadded; the four 16-B granules of row r are stored at
+// granule index g ^ ((r >> 1) & 3), so the 16-B fragment reads of 8 consecutive lanes (8 rows, same logical granule)
+// hit all 32 banks once
+static constexpr int LDH = 32;
+
+template <int NP> struct HalfOps;
+template <> struct HalfOps<1> {
+    typedef f16x8 frag;
+    static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct HalfOps<3> {
+    typedef bf16x8 frag;
+    static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+};
+
+}  // namespace bp

@@ -32,99 +32,9 @@
 // Fragment trick: lane l reads A[row=l&31][4h..4h+3] (h=l>>5) as one b128 and feeds
 // component j to MFMA j, so MFMA j contracts k = {j, 4+j} of the 8-wide sub-chunk;
 // B uses the same k mapping, and the sum over k is order-free.
-#include <hip/hip_ext.h>
-
-#include "bp_common.h"
+#include "conv_dev.h"
 
 namespace bp {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-// native vector types: they stay in VGPRs (HIP's float4 struct made hipcc park the prefetch registers in scratch)
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-static constexpr int BK = 32;
-static constexpr int LDS_LD = 36;
-static constexpr unsigned OOB = 0x7fffff00u;   // byte offset beyond any descriptor's num_records -> load returns 0
-
-__device__ __forceinline__ float apply_act(float v, int act) {
-    if (act == ACT_LEAKY) return v > 0.f ? v : 0.1f * v;
-    if (act == ACT_RELU) return v > 0.f ? v : 0.f;
-    return v;
-}
-
-// v = raw accumulator for output element (m, n); bias = p.bias[n] (loaded once per lane by the caller: the
-// epilogue's stores may alias p.bias as far as the compiler knows, so an in-loop load is re-issued and waited
-// for after every store -- 16 serialized L2 round trips per tile, measured as the dominant cost of short layers)
-__device__ __forceinline__ void epilogue_store(const ConvParams& p, int m, int n, float v, float bias) {
-    v += bias;
-    int b = 0, pix = m;
-    const int hw = p.OH * p.OW;
-    const bool need_pix = p.store_mode != ST_NHWC || p.res_scale != nullptr;
-    if (need_pix) {
-        b = m / hw;
-        pix = m - b * hw;
-    }
-    float r = 0.f;
-    if (p.res) {
-        r = p.res[(long long)m * p.res_ld + n];
-        if (p.res_scale) r *= p.res_scale[b * p.Cout + n];
-    }
-    if (!p.res_after_act) v += r;
-    v = apply_act(v, p.act);
-    if (p.res_after_act) v += r;
-    switch (p.store_mode) {
-        case ST_NHWC:
-            p.out[(long long)m * p.out_ld + n] = v;
-            break;
-        case ST_UP2: {
-            const int oy = pix / p.OW, ox = pix - oy * p.OW;
-            const int W2 = 2 * p.OW;
-            float* o = p.out + ((long long)(b * 2 * p.OH + 2 * oy) * W2 + 2 * ox) * p.out_ld + n;
-            o[0] = v;
-            o[p.out_ld] = v;
-            o[(long long)W2 * p.out_ld] = v;
-            o[(long long)(W2 + 1) * p.out_ld] = v;
-        } break;
-        case ST_PIXSHUF: {
-            const int oy = pix / p.OW, ox = pix - oy * p.OW;
-            const int cq = p.Cout >> 2;
-            const int ij = n / cq, c = n - ij * cq;
-            const int y = 2 * oy + (ij >> 1), x = 2 * ox + (ij & 1);
-            p.out[((long long)(b * 2 * p.OH + y) * (2 * p.OW) + x) * p.out_ld + c] = v;
-        } break;
-        case ST_NCHW:
-            p.out[((long long)b * p.Cout + n) * hw + pix] = v;
-            break;
-    }
-}
-
-// 16 accumulators of one lane: column n, rows m_base + (r&3) + 8*(r>>2) -- element-wise epilogue for the store
-// modes / alignments the staged float4 path does not cover (heads with 18 channels, upsample, PixelShuffle, NCHW)
-__device__ __forceinline__ void epilogue_tile(const ConvParams& p, const float* v, int m_base, int n) {
-    if (n >= p.Cout) return;
-    const float bias = p.bias[n];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int m = m_base + (e & 3) + 8 * (e >> 2);
-        if (m < p.M) epilogue_store(p, m, n, v[e], bias);
-    }
-}
-
-__device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, int soff) {
-    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, soff, 0);
-    return f32x4{__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w)};
-}
-
-// exact for 0 <= m < 2^24, d > 0: quotient by float reciprocal + one correction step (a 32-bit integer division
-// costs ~40 VALU instructions; the tile prologue needs 2 per row)
-__device__ __forceinline__ int fast_div(int m, int d, float rcp) {
-    int q = (int)((float)m * rcp);
-    const int r = m - q * d;
-    if (r < 0) --q;
-    else if (r >= d) ++q;
-    return q;
-}
 
 // VEC: how a thread fetches its 4 consecutive K elements of an A row --
 //   0  scalar gather (any Cin): 4 address computations + 4 dword loads per element group;
@@ -370,7 +280,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     __syncthreads();
     BP_STAMP(3);   // K loop done
 
+    const int w_row0 = wm * (BM / 2), w_col0 = wn * (BN / 2);
+    __shared__ int s_last;
+#define BP_NT 256
+#define BP_SLAST s_last
+#define BP_TAIL_STAMP(k_)
 #include "conv_tail.inc"
+#undef BP_TAIL_STAMP
+#undef BP_NT
+#undef BP_SLAST
     if (p.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); BP_STAMP(4); }
 }
 
@@ -388,30 +306,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 //           relative to an fp64 conv) -- at 6/16 of the fp32-MFMA cycles.  LDS carries three planes per operand.
 // Fragment layout of the 32x32x16 forms: lane l supplies row (l & 31), k = 8*(l>>5) .. 8*(l>>5)+7 (one 16-B LDS read).
 // =====================================================================================================================
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
-// LDS rows of the 16-bit kernels are 32 elements = 64 B, unpadded; the four 16-B granules of row r are stored at
-// granule index g ^ ((r >> 1) & 3), so the 16-B fragment reads of 8 consecutive lanes (8 rows, same logical granule)
-// hit all 32 banks once
-static constexpr int LDH = 32;
-
-template <int NP> struct HalfOps;
-template <> struct HalfOps<1> {
-    typedef f16x8 frag;
-    static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-    }
-};
-template <> struct HalfOps<3> {
-    typedef bf16x8 frag;
-    static __device__ __forceinline__ f32x16 mfma(frag a, frag b, f32x16 c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-    }
-};
-
 template <int TM, int TN, int NP>
 __global__ __launch_bounds__(256) void conv_igemm_h_kernel(const ConvParams p) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
@@ -599,7 +493,15 @@ __global__ __launch_bounds__(256) void conv_igemm_h_kernel(const ConvParams p) {
     }
     __syncthreads();
 
+    const int w_row0 = wm * (BM / 2), w_col0 = wn * (BN / 2);
+    __shared__ int s_last;
+#define BP_NT 256
+#define BP_SLAST s_last
+#define BP_TAIL_STAMP(k_)
 #include "conv_tail.inc"
+#undef BP_TAIL_STAMP
+#undef BP_NT
+#undef BP_SLAST
 #undef BH_AS
 #undef BH_BS
 #undef BH_ADDR
@@ -610,8 +512,13 @@ __global__ __launch_bounds__(256) void conv_igemm_h_kernel(const ConvParams p) {
 
 thread_local ConvProfHook* g_conv_prof = nullptr;
 
-int conv_tile_bm(int tile) { return tile == TILE_128x64 ? 128 : 64; }
-int conv_tile_bn(int tile) { return 64; }
+int conv_tile_bm(int tile) { return (tile == TILE_128x64 || tile == TILE_W64_2x1 || tile == TILE_W64_2x2) ? 128 : 64; }
+int conv_tile_bn(int tile) {
+    switch (tile) {
+        case TILE_W64_1x2: case TILE_W64_2x2: return 128;
+        default: return 64;
+    }
+}
 
 template <int TM, int TN>
 static void launch_t(const ConvParams& p, hipStream_t s) {
@@ -658,8 +565,8 @@ bool conv_h16_eligible(const ConvParams& p) {
 }
 
 int conv_tiles(const ConvParams& p, int tile) {
-    const int bm = conv_tile_bm(tile);
-    return ((p.M + bm - 1) / bm) * (p.CoutPad / 64);
+    const int bm = conv_tile_bm(tile), bn = conv_tile_bn(tile);
+    return ((p.M + bm - 1) / bm) * ((p.CoutPad + bn - 1) / bn);
 }
 
 void launch_conv(const ConvParams& p, int tile, hipStream_t s) {
@@ -667,7 +574,9 @@ void launch_conv(const ConvParams& p, int tile, hipStream_t s) {
     BP_CHECK(p.Kpad % BK == 0 && p.nchunks == p.Kpad / BK, "Kpad");
     BP_CHECK(p.splits >= 1 && (p.splits == 1 || (p.partial != nullptr && p.tickets != nullptr)), "split-K workspace");
     BP_CHECK((long long)p.N * p.H * p.W * p.in_ld * 4 < (long long)OOB, "activation tensor too large for 32-bit offsets");
-    if (p.mfma_mode == PREC_F16 && conv_h16_eligible(p)) {
+    if (conv_tile_is_w64(tile)) {
+        launch_conv_w64(p, tile, s);
+    } else if (p.mfma_mode == PREC_F16 && conv_h16_eligible(p)) {
         switch (tile) {
             case TILE_128x64: launch_h_t<2, 1, 1>(p, s); break;
             default: launch_h_t<1, 1, 1>(p, s); break;

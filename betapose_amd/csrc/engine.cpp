@@ -54,7 +54,7 @@ static const SplitEntry kSplitTable[] = {
     {    80,   512,  144, 12},
     {    80,  2048,   16,  3},
     {    80,  2048,   32,  3},
-    {   169,    64,   32,  8},
+    {   169,    64,   32, 10},
     {   169,   256,   16,  5},
     {   169,   512,   32,  5},
     {   169,  1024,  144,  5},
@@ -91,117 +91,138 @@ static const SplitEntry kSplitTable[] = {
     { 43264,    64,    9,  1},
 };
 
-// fp16-MFMA kernel: same procedure (tools/tune_conv.py --f16, profiles/r01_splitk_tuning_f16.txt)
-static const SplitEntry kSplitTableF16[] = {
-    {    80,   512,   64,  5},
-    {    80,   512,  144,  6},
-    {    80,  2048,   16,  1},
-    {    80,  2048,   32,  3},
-    {   169,    64,   32,  4},
-    {   169,   256,   16,  1},
-    {   169,   512,   32,  3},
-    {   169,  1024,  144,  5},
-    {   320,   256,   32,  3},
-    {   320,   256,   72,  5},
-    {   320,   512,   32,  3},
-    {   320,  1024,    8,  1},
-    {   320,  1024,   16,  1},
-    {   320,  1024,  144,  5},
-    {   676,    64,   16,  1},
-    {   676,   128,    8,  1},
-    {   676,   256,   16,  1},
-    {   676,   256,   24,  1},
-    {   676,   512,   72,  3},
-    {  1280,   128,   16,  1},
-    {  1280,   128,   36,  3},
-    {  1280,   256,   16,  1},
-    {  1280,   512,    4,  1},
-    {  1280,   512,    8,  1},
-    {  1280,   512,   72,  3},
-    {  2704,    64,    8,  1},
-    {  2704,   128,    8,  1},
-    {  2704,   128,   12,  1},
-    {  2704,   256,   36,  1},
-    {  5120,    64,    2,  1},
-    {  5120,    64,    8,  1},
-    {  5120,    64,   18,  1},
-    {  5120,    64,   36,  3},
-    {  5120,   128,    8,  1},
-    {  5120,   256,    2,  1},
-    { 10816,    64,    4,  1},
-    { 10816,   128,   18,  1},
-    { 43264,    64,    2,  1},
-    { 43264,    64,    9,  1},
+// 16-bit precision modes: {M, CoutPad, K-chunks} -> {tile, slices}, measured one kernel at a time over both kernel
+// families (tools/tune_conv.py [--f16], profiles/r02_tune_{b3,f16}.txt: at batch 1 the 64x64-block kernels of
+// conv_igemm.hip win every shape of the two networks); other shapes use the heuristic in choose_h16.
+struct PlanEntry { int M, CoutPad, nchunks, tile, splits; };
+static const PlanEntry kPlanB3[] = {
+    {    80,   512,   64, 0,  6},
+    {    80,   512,  144, 0, 10},
+    {    80,  2048,   16, 0,  3},
+    {    80,  2048,   32, 0,  3},
+    {   169,    64,   32, 0, 10},
+    {   169,   256,   16, 0,  5},
+    {   169,   512,   32, 0,  5},
+    {   169,  1024,  144, 0,  5},
+    {   320,   256,   32, 0,  5},
+    {   320,   256,   72, 0,  8},
+    {   320,   512,   32, 0,  5},
+    {   320,  1024,    8, 0,  1},
+    {   320,  1024,   16, 0,  3},
+    {   320,  1024,  144, 0,  6},
+    {   676,    64,   16, 0,  5},
+    {   676,   128,    8, 0,  1},
+    {   676,   256,   16, 0,  3},
+    {   676,   256,   24, 0,  5},
+    {   676,   512,   72, 0,  5},
+    {  1280,   128,   16, 0,  3},
+    {  1280,   128,   36, 0,  5},
+    {  1280,   256,   16, 0,  3},
+    {  1280,   512,    4, 0,  1},
+    {  1280,   512,    8, 0,  1},
+    {  1280,   512,   72, 0,  3},
+    {  2704,    64,    8, 0,  1},
+    {  2704,   128,    8, 0,  1},
+    {  2704,   128,   12, 0,  1},
+    {  2704,   256,   36, 0,  4},
+    {  5120,    64,    2, 0,  1},
+    {  5120,    64,    8, 0,  1},
+    {  5120,    64,   18, 0,  3},
+    {  5120,    64,   36, 0,  3},
+    {  5120,   128,    8, 0,  1},
+    {  5120,   256,    2, 0,  1},
+    { 10816,    64,    4, 0,  1},
+    { 10816,   128,   18, 0,  2},
+    { 43264,    64,    2, 0,  1},
+    { 43264,    64,    9, 0,  1},
+    {0, 0, 0, 0, 0},
+};
+static const PlanEntry kPlanF16[] = {
+    {    80,   512,   64, 0,  5},
+    {    80,   512,  144, 0,  6},
+    {    80,  2048,   16, 0,  1},
+    {    80,  2048,   32, 0,  3},
+    {   169,    64,   32, 0,  4},
+    {   169,   256,   16, 0,  1},
+    {   169,   512,   32, 0,  3},
+    {   169,  1024,  144, 0,  5},
+    {   320,   256,   32, 0,  3},
+    {   320,   256,   72, 0,  5},
+    {   320,   512,   32, 0,  3},
+    {   320,  1024,    8, 0,  1},
+    {   320,  1024,   16, 0,  1},
+    {   320,  1024,  144, 0,  5},
+    {   676,    64,   16, 0,  1},
+    {   676,   128,    8, 0,  1},
+    {   676,   256,   16, 0,  1},
+    {   676,   256,   24, 0,  1},
+    {   676,   512,   72, 0,  5},
+    {  1280,   128,   16, 0,  1},
+    {  1280,   128,   36, 0,  3},
+    {  1280,   256,   16, 0,  1},
+    {  1280,   512,    4, 0,  1},
+    {  1280,   512,    8, 0,  1},
+    {  1280,   512,   72, 0,  3},
+    {  2704,    64,    8, 0,  1},
+    {  2704,   128,    8, 0,  1},
+    {  2704,   128,   12, 0,  1},
+    {  2704,   256,   36, 0,  1},
+    {  5120,    64,    2, 0,  1},
+    {  5120,    64,    8, 0,  1},
+    {  5120,    64,   18, 0,  1},
+    {  5120,    64,   36, 0,  3},
+    {  5120,   128,    8, 0,  1},
+    {  5120,   256,    2, 0,  1},
+    { 10816,    64,    4, 0,  1},
+    { 10816,   128,   18, 0,  1},
+    { 43264,    64,    2, 0,  1},
+    { 43264,    64,    9, 0,  1},
+    {0, 0, 0, 0, 0},
 };
 
-// bf16x3 kernel: same procedure (tools/tune_conv.py --b3, profiles/r01_splitk_tuning_bf16x3.txt)
-static const SplitEntry kSplitTableB3[] = {
-    {    80,   512,   64,  6},
-    {    80,   512,  144, 12},
-    {    80,  2048,   16,  3},
-    {    80,  2048,   32,  3},
-    {   169,    64,   32,  8},
-    {   169,   256,   16,  5},
-    {   169,   512,   32,  5},
-    {   169,  1024,  144,  5},
-    {   320,   256,   32,  5},
-    {   320,   256,   72,  5},
-    {   320,   512,   32,  5},
-    {   320,  1024,    8,  1},
-    {   320,  1024,   16,  3},
-    {   320,  1024,  144,  6},
-    {   676,    64,   16,  4},
-    {   676,   128,    8,  1},
-    {   676,   256,   16,  3},
-    {   676,   256,   24,  5},
-    {   676,   512,   72,  5},
-    {  1280,   128,   16,  3},
-    {  1280,   128,   36,  5},
-    {  1280,   256,   16,  3},
-    {  1280,   512,    4,  1},
-    {  1280,   512,    8,  1},
-    {  1280,   512,   72,  3},
-    {  2704,    64,    8,  1},
-    {  2704,   128,    8,  1},
-    {  2704,   128,   12,  1},
-    {  2704,   256,   36,  4},
-    {  5120,    64,    2,  1},
-    {  5120,    64,    8,  1},
-    {  5120,    64,   18,  3},
-    {  5120,    64,   36,  3},
-    {  5120,   128,    8,  1},
-    {  5120,   256,    2,  1},
-    { 10816,    64,    4,  1},
-    { 10816,   128,   18,  2},
-    { 43264,    64,    2,  1},
-    { 43264,    64,    9,  1},
-};
+static void choose_h16(const ConvParams& c, long long M, int mode, int sk_max, int* tile, int* splits) {
+    for (const PlanEntry& e : (mode == PREC_F16 ? kPlanF16 : kPlanB3)) {
+        if (e.M == 0) break;
+        if (e.M == (int)M && e.CoutPad == c.CoutPad && e.nchunks == c.nchunks) { *tile = e.tile; *splits = e.splits; return; }
+    }
+    // heuristic from the batch-4 / batch-28 sweeps (profiles/r02_tune_b3_batch{4,28}.txt): the 128x128 block of
+    // conv_w64.hip (64x64 per wave, half the filter re-reads) wins once its tile grid covers about half the CUs;
+    // below that the 64x64-block kernels, which reach the same block count with fewer K slices
+    const long long tiles128 = ((M + 127) / 128) * ((c.CoutPad + 127) / 128);
+    int t = (c.CoutPad >= 128 && tiles128 >= 128) ? TILE_W64_2x2 : TILE_64x64;
+    const int bm = conv_tile_bm(t), bn = conv_tile_bn(t);
+    const long long blocks = ((M + bm - 1) / bm) * ((c.CoutPad + bn - 1) / bn);
+    const int target = t == TILE_W64_2x2 ? 256 : (mode == PREC_F16 ? 128 : 512);
+    const int min_chunks = mode == PREC_F16 ? 8 : 4;
+    int s = 1;
+    while (blocks * s < target && c.nchunks / (s + 1) >= min_chunks && s < sk_max) ++s;
+    *tile = t; *splits = s;
+}
 
 static void choose_launch(const Op& op, int batch, int force_tile, int sk_target, int sk_min_chunks, int sk_max,
                           int* tile, int* splits, int* cps) {
     const int mode = op.conv.mfma_mode;
     const ConvParams& c = op.conv;
     const long long M = (long long)batch * c.OH * c.OW;
-    const int nt = c.CoutPad / 64;
-    int t = TILE_64x64;   // 128x64 measured slower on every layer of both networks (tools/bench_conv.py)
-    if (force_tile >= 0) t = force_tile;
-    const int bm = conv_tile_bm(t);
-    const long long blocks = ((M + bm - 1) / bm) * nt;
+    int t = TILE_64x64;   // fp32 MFMA kernel: 128x64 measured slower on every layer of both networks (tools/bench_conv.py)
     int s = 1;
-    while (blocks * s < sk_target && c.nchunks / (s + 1) >= sk_min_chunks && s < sk_max) ++s;
-    if (t == TILE_64x64 && sk_target == 512 && sk_min_chunks == 4 && sk_max == 8) {   // default policy: measured tables
-        if (mode == PREC_F16) {
-            s = 1;   // the fp16 K loop is ~5x shorter: unlisted shapes (other batch sizes) run unsplit unless tiny
-            while (blocks * s < 128 && c.nchunks / (s + 1) >= 8 && s < sk_max) ++s;
-            for (const SplitEntry& e : kSplitTableF16)
-                if (e.M == (int)M && e.CoutPad == c.CoutPad && e.nchunks == c.nchunks) { s = e.splits; break; }
-        } else if (mode == PREC_BF16X3) {
-            for (const SplitEntry& e : kSplitTableB3)
-                if (e.M == (int)M && e.CoutPad == c.CoutPad && e.nchunks == c.nchunks) { s = e.splits; break; }
-        } else {
+    if (mode != PREC_F32) {
+        choose_h16(c, M, mode, sk_max, &t, &s);
+        if (force_tile >= 0) t = force_tile;
+        if (!(sk_target == 512 && sk_min_chunks == 4 && sk_max == 8)) {   // explicit policy (tests, sweeps)
+            const long long blocks = ((M + conv_tile_bm(t) - 1) / conv_tile_bm(t)) *
+                                     ((c.CoutPad + conv_tile_bn(t) - 1) / conv_tile_bn(t));
+            s = 1;
+            while (blocks * s < sk_target && c.nchunks / (s + 1) >= sk_min_chunks && s < sk_max) ++s;
+        }
+    } else {
+        if (force_tile >= 0 && !conv_tile_is_w64(force_tile)) t = force_tile;
+        const int bm = conv_tile_bm(t);
+        const long long blocks = ((M + bm - 1) / bm) * (c.CoutPad / 64);
+        while (blocks * s < sk_target && c.nchunks / (s + 1) >= sk_min_chunks && s < sk_max) ++s;
+        if (t == TILE_64x64 && sk_target == 512 && sk_min_chunks == 4 && sk_max == 8)   // default policy: measured table
             for (const SplitEntry& e : kSplitTable)
                 if (e.M == (int)M && e.CoutPad == c.CoutPad && e.nchunks == c.nchunks) { s = e.splits; break; }
-        }
     }
     int per = (c.nchunks + s - 1) / s;
     s = (c.nchunks + per - 1) / per;
@@ -276,7 +297,7 @@ void Net::finalize() {
             // worst case over policies that may be set later: allow up to 64 splits at batch 1
             if (splits > 1) {
                 ConvParams q = op.conv; q.M = b * q.OH * q.OW;
-                need = std::max(need, (size_t)splits * conv_tiles(q, tile) * conv_tile_bm(tile) * 64);
+                need = std::max(need, (size_t)splits * conv_tiles(q, tile) * conv_tile_bm(tile) * conv_tile_bn(tile));
             }
         }
     }
@@ -335,7 +356,7 @@ void Net::run_op(const Op& op, int batch, hipStream_t s) {
             p.M = batch * p.OH * p.OW;
             int tile, splits, cps;
             choose_launch(op, batch, force_tile_, sk_target_, sk_min_chunks_, sk_max_splits_, &tile, &splits, &cps);
-            while (splits > 1 && (size_t)splits * conv_tiles(p, tile) * conv_tile_bm(tile) * 64 > partial_floats_) {
+            while (splits > 1 && (size_t)splits * conv_tiles(p, tile) * conv_tile_bm(tile) * conv_tile_bn(tile) > partial_floats_) {
                 --splits;
                 cps = (p.nchunks + splits - 1) / splits;
                 splits = (p.nchunks + cps - 1) / cps;
@@ -412,7 +433,7 @@ int Net::profile(int batch, int iters, float* ms, int* info, int cap, hipStream_
                 choose_launch(ops_[i], batch, force_tile_, sk_target_, sk_min_chunks_, sk_max_splits_, &tile, &splits, &cps);
                 vec = conv_vec_mode(ops_[i].conv) ? 1 : 0;
                 if (ops_[i].conv.mfma_mode != PREC_F32 && conv_h16_eligible(ops_[i].conv))
-                    vec = 1 + ops_[i].conv.mfma_mode;   // 2 fp16-MFMA kernel, 3 bf16x3 kernel
+                    vec = 1 + ops_[i].conv.mfma_mode;   // 2 fp16-MFMA kernel, 3 bf16x3 kernel (conv_w64.hip)
             }
             info[4 * i] = conv; info[4 * i + 1] = tile; info[4 * i + 2] = vec; info[4 * i + 3] = splits;
         }

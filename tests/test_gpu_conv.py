@@ -179,3 +179,82 @@ def test_conv_bf16x3_is_fp32_accurate(cuda, case, splits):
     e32 = float((out32.double() - ref64).abs().max()) / scale
     assert e3 <= max(1.5 * e32, 2e-6), (e3, e32)           # no less accurate than the fp32-MFMA kernel
     _check(out3, ref32, tol=2e-5 * max(1.0, scale))
+
+
+# ---- conv_w64.hip: 64x64 accumulator tile per wave, WM x WN waves per block, filters by LDS-DMA.  Same bars as the
+# kernels above: bf16x3 must be fp32-accurate, fp16 must match a conv on fp16-rounded operands to accumulation order.
+W64_TILES = ["w1x1", "w1x2", "w2x1", "w2x2"]
+
+
+@pytest.mark.parametrize("case", F16_CASES)
+@pytest.mark.parametrize("tile", W64_TILES)
+@pytest.mark.parametrize("splits", [1, 3])
+def test_conv_w64_bf16x3_is_fp32_accurate(cuda, case, tile, splits):
+    N, H, W, Cin, Cout, k, st, pad, act = case
+    g = torch.Generator().manual_seed(700 + CASES.index(case))
+    x = torch.randn(N, H, W, Cin, generator=g) * torch.exp(2 * torch.randn(N, H, W, 1, generator=g))   # wide dynamic range
+    w = torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g)
+    if splits > 1 and Cin * k * k // 32 < 2 * splits:
+        pytest.skip("too few K-chunks to split")
+    OH, OW = (H + 2 * pad - k) // st + 1, (W + 2 * pad - k) // st + 1
+    res = torch.randn(N, OH, OW, Cout, generator=g)
+    ref64 = _ref(x.double(), w.double(), b.double(), st, pad, act, res.double(), True)
+    out3 = ops.conv2d_nhwc(x.to(cuda), w, b, stride=st, pad=pad, act=act, res=res.to(cuda), res_after_act=True,
+                           tile=tile + "_b3", splits=splits)
+    out32 = ops.conv2d_nhwc(x.to(cuda), w, b, stride=st, pad=pad, act=act, res=res.to(cuda), res_after_act=True,
+                            tile="64x64", splits=splits)
+    out3, out32 = out3.cpu().permute(0, 3, 1, 2), out32.cpu().permute(0, 3, 1, 2)
+    scale = float(ref64.abs().mean())
+    e3 = float((out3.double() - ref64).abs().max()) / scale
+    e32 = float((out32.double() - ref64).abs().max()) / scale
+    assert e3 <= max(1.5 * e32, 2e-6), (e3, e32)
+    _check(out3, ref64.float(), tol=2e-5 * max(1.0, scale))
+
+
+@pytest.mark.parametrize("case", F16_CASES)
+@pytest.mark.parametrize("tile", W64_TILES)
+def test_conv_w64_f16_operands(cuda, case, tile):
+    N, H, W, Cin, Cout, k, st, pad, act = case
+    g = torch.Generator().manual_seed(900 + CASES.index(case))
+    x = torch.randn(N, H, W, Cin, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g)
+    ref16 = _ref(x.half().float(), w.half().float(), b, st, pad, act, None, False)
+    out = ops.conv2d_nhwc(x.to(cuda), w, b, stride=st, pad=pad, act=act, tile=tile + "_f16", splits=1)
+    _check(out.cpu().permute(0, 3, 1, 2), ref16)
+
+
+@pytest.mark.parametrize("tile", W64_TILES)
+def test_conv_w64_store_modes(cuda, tile):
+    g = torch.Generator().manual_seed(15)
+    x = torch.randn(2, 10, 8, 64, generator=g)
+    w = torch.randn(128, 64, 3, 3, generator=g) / 24
+    b = torch.randn(128, generator=g)
+    ref = _ref(x, w, b, 1, 1, "relu", None, False)
+    xd = x.to(cuda)
+    t = tile + "_b3"
+    up = ops.conv2d_nhwc(xd, w, b, pad=1, act="relu", store="up2", tile=t).cpu().permute(0, 3, 1, 2)
+    _check(up, F.interpolate(ref, scale_factor=2, mode="nearest"))
+    ps = ops.conv2d_nhwc(xd, w, b, pad=1, act="relu", store="pixshuf", tile=t).cpu().permute(0, 3, 1, 2)
+    _check(ps, F.pixel_shuffle(ref, 2))
+    nc = ops.conv2d_nhwc(xd, w, b, pad=1, act="relu", store="nchw", tile=t, splits=2).cpu()
+    _check(nc, ref)
+
+
+def test_conv_w64_full_size_layers(cuda):
+    """Full-size layers of both networks on their planned tiles: spot-check against the definition (fp64) and the
+    size-independent linearity property."""
+    g = torch.Generator().manual_seed(21)
+    for (H, W, Cin, Cout, k, tile) in [(52, 52, 128, 256, 3, "w1x2"), (13, 13, 512, 1024, 3, "w1x2"),
+                                        (104, 104, 64, 128, 3, "w2x2"), (20, 16, 1024, 256, 1, "w1x2"),
+                                        (208, 208, 64, 32, 1, "w2x1")]:
+        x1 = torch.randn(1, H, W, Cin, generator=g)
+        x2 = torch.randn(1, H, W, Cin, generator=g)
+        w = torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k)
+        y1 = ops.conv2d_nhwc(x1.to(cuda), w, None, pad=k // 2, tile=tile + "_b3")
+        y2 = ops.conv2d_nhwc(x2.to(cuda), w, None, pad=k // 2, tile=tile + "_b3")
+        y3 = ops.conv2d_nhwc((2.0 * x1 + x2).to(cuda), w, None, pad=k // 2, tile=tile + "_b3")
+        assert float((y3 - (2.0 * y1 + y2)).abs().max()) < 5e-5
+        ref = F.conv2d(x1.double().permute(0, 3, 1, 2), w.double(), padding=k // 2).float()
+        _check(y1.cpu().permute(0, 3, 1, 2), ref)

@@ -16,11 +16,13 @@ ap.add_argument("--sk-min", type=int, default=4)
 ap.add_argument("--tile", type=int, default=-1)
 ap.add_argument("--sk-max", type=int, default=8)
 ap.add_argument("--top", type=int, default=400)
+ap.add_argument("--precision", default="f32")
 a = ap.parse_args()
 blocks = C.parse_cfg_text(C.yolov3_single_cfg_text())
 det = Darknet("yolov3-single.cfg", max_batch=a.batch).load_stream(synth.synth_yolo_stream(1, blocks)).cuda()
 pose = FastPoseHIP(synth.synth_fastpose_state_dict(2), max_batch=a.batch).cuda()
 for name, net in (("yolo", det), ("kpd", pose)):
+    net.set_precision(a.precision)
     net.set_policy(a.sk_target, a.sk_min, a.sk_max, a.tile)
     ms, info = net.profile(a.batch, 20)
     fl, by = net.op_stats()

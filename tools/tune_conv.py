@@ -45,28 +45,42 @@ for planes, nb, st in W.FASTPOSE_STAGES:
         h, w_, inpl = h2, w2, planes * 4
 add(20, 16, 512, 1024, 3, 1); add(40, 32, 256, 512, 3, 1); add(80, 64, 128, 50, 3, 1)
 
-F16 = "--f16" in sys.argv          # tune the fp16-MFMA kernel instead
-B3 = "--b3" in sys.argv            # ... or the bf16x3 kernel
-TILE = "64x64_f16" if F16 else ("64x64_b3" if B3 else "64x64")
+F16 = "--f16" in sys.argv          # tune the fp16-operand kernels instead of the bf16x3 (fp32-accurate) ones
+FP32 = "--fp32" in sys.argv        # ... or the fp32-MFMA kernel (64x64 tile, slices only)
+SUF = "_f16" if F16 else "_b3"
+TILES = ["64x64"] if FP32 else ["64x64" + SUF, "w1x1" + SUF, "w1x2" + SUF, "w2x1" + SUF, "w2x2" + SUF]
+TILE_ID = {"64x64": 0, "w1x1": 2, "w1x2": 3, "w2x1": 5, "w2x2": 6}
+BMN = {"64x64": (64, 64), "w1x1": (64, 64), "w1x2": (64, 128), "w2x1": (128, 64), "w2x2": (128, 128)}
+BATCH = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else 1
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
-print("// {M, CoutPad, nchunks, splits}  (count, us_best, us_default)")
-tot_best = tot_def = 0.0
+print("// {M, CoutPad, nchunks, tile, splits}  (count, us_best | per tile: best splits:us)")
+tot_best = 0.0
 for (h, w_, cin, co, k, st), cnt in sorted(shapes.items()):
     if cin % 32:
         continue
-    x = torch.randn(1, h, w_, cin, generator=g).to(dev)
+    x = torch.randn(BATCH, h, w_, cin, generator=g).to(dev)
     wt = torch.randn(co, cin, k, k, generator=g) / np.sqrt(cin * k * k)
     oh = (h + 2 * ((k - 1) // 2) - k) // st + 1; ow = (w_ + 2 * ((k - 1) // 2) - k) // st + 1
-    M = oh * ow; nch = cin * k * k // 32; cpad = (co + 63) // 64 * 64
-    res = {}
-    for sp in (0, 1, 2, 3, 4, 5, 6, 8, 10, 12, 16):
-        if sp > 1 and nch // sp < 2:
-            continue
-        _, ms = ops.conv2d_nhwc(x, wt, None, stride=st, pad=(k - 1) // 2, act="leaky", splits=sp, iters=30, tile=TILE)
-        res[sp] = ms * 1e3
-    best = min((v, s) for s, v in res.items() if s > 0)
-    tot_best += best[0] * cnt; tot_def += res[0] * cnt
-    print("    {%6d, %5d, %4d, %2d},   // x%d  %.1f us (auto %.1f)  %s" % (M, cpad, nch, best[1], cnt, best[0], res[0],
-          " ".join("%d:%.1f" % (s, v) for s, v in sorted(res.items()))))
-print("// sum best %.1f us, sum auto %.1f us" % (tot_best, tot_def))
+    M = BATCH * oh * ow; nch = cin * k * k // 32; cpad = (co + 63) // 64 * 64
+    best = (1e9, None, None); per_tile = []
+    for tile in TILES:
+        base = tile.split("_")[0]
+        bm, bn = BMN[base]
+        if bn > 64 and cpad < bn and base != "w1x2":
+            continue                       # a tile twice as wide as the layer
+        tiles = -(-M // bm) * -(-cpad // bn)
+        tb = (1e9, None)
+        for sp in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 24):
+            if sp > 1 and (nch // sp < 2 or tiles * sp > 1400 or BATCH > 4):
+                continue
+            _, ms = ops.conv2d_nhwc(x, wt, None, stride=st, pad=(k - 1) // 2, act="leaky", splits=sp, iters=30, tile=tile)
+            if ms * 1e3 < tb[0]:
+                tb = (ms * 1e3, sp)
+        per_tile.append("%s %d:%.1f" % (base, tb[1], tb[0]))
+        if tb[0] < best[0]:
+            best = (tb[0], base, tb[1])
+    tot_best += best[0] * cnt
+    print("    {%6d, %5d, %4d, %d, %2d},   // x%d  %.1f us %s | %s" % (M, cpad, nch, TILE_ID[best[1]], best[2], cnt, best[0], best[1],
+          "  ".join(per_tile)), flush=True)
+print("// sum best %.1f us" % tot_best)
