@@ -76,10 +76,12 @@ static std::string read_text(const char* path) {
     return ss.str();
 }
 
-// BP_PRECISION=f32|bf16x3|f16 overrides the built-in default of newly created engines (bp_*_set_precision still wins)
+// Built-in default of newly created engines: bf16x3 = fp32-accurate convolution on the bf16 matrix pipe (exact 3-way
+// operand split, passes the whole parity suite at the fp32 bars).  BP_PRECISION=f32|bf16x3|f16 overrides
+// it (bp_*_set_precision still wins).
 static int default_precision() {
     const char* e = std::getenv("BP_PRECISION");
-    if (!e || !*e) return bp::PREC_F32;
+    if (!e || !*e) return bp::PREC_BF16X3;
     const std::string v(e);
     if (v == "f32") return bp::PREC_F32;
     if (v == "f16") return bp::PREC_F16;

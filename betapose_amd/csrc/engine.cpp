@@ -518,10 +518,15 @@ YoloNet::YoloNet(const std::string& cfg_text, const float* stream, size_t n_floa
         alias[i] = i;
         if (b.type == "convolutional") {
             const int k = b.geti("size", 1), st = b.geti("stride", 1);
+            BP_CHECK(k >= 1 && k <= 15 && st >= 1 && b.geti("filters", 1) >= 1, "convolutional: size / stride / filters out of range");
             const int pad = b.has("pad") && !b.gets("pad").empty() ? (k - 1) / 2 : 0;   // string truthiness, darknet.py:250
+            BP_CHECK(prev.H + 2 * pad >= k && prev.W + 2 * pad >= k, "convolutional: kernel larger than its input");
             shp[i] = {b.geti("filters", 1), (prev.H + 2 * pad - k) / st + 1, (prev.W + 2 * pad - k) / st + 1};
         } else if (b.type == "shortcut") {
             BP_CHECK(i >= 1, "shortcut at layer 0");
+            const int src = i + b.geti("from", -3);          // always relative (darknet.py:338)
+            BP_CHECK(src >= 0 && src < i, "shortcut source out of range");
+            BP_CHECK(shp[src].C == prev.C && shp[src].H == prev.H && shp[src].W == prev.W, "shortcut shape mismatch");
             shp[i] = prev;
         } else if (b.type == "upsample") {
             BP_CHECK(b.geti("stride", 2) == 2, "only x2 upsample");
@@ -542,6 +547,7 @@ YoloNet::YoloNet(const std::string& cfg_text, const float* stream, size_t n_floa
                 members[i] = {alias[a], alias[c]};
             }
         } else if (b.type == "yolo") {
+            BP_CHECK(i >= 1, "yolo at layer 0");
             shp[i] = prev;
             alias[i] = alias[i - 1];                        // outputs[i] = outputs[i-1]
         } else {
@@ -685,7 +691,7 @@ YoloNet::YoloNet(const std::string& cfg_text, const float* stream, size_t n_floa
             YoloHead h{};
             h.t = t.p; h.g = t.H; h.row_off = row_off;
             for (int a = 0; a < 3; ++a) {
-                BP_CHECK(2 * mask[a] + 1 < (int)an.size(), "anchor mask");
+                BP_CHECK(mask[a] >= 0 && 2 * mask[a] + 1 < (int)an.size(), "anchor mask");
                 h.aw[a] = (float)an[2 * mask[a]];
                 h.ah[a] = (float)an[2 * mask[a] + 1];
             }

@@ -58,6 +58,12 @@ class ImageLoader:
         from collections import deque
         from concurrent.futures import ThreadPoolExecutor
         ahead = max(2 * self.batchSize, 8)
+        try:
+            self._produce(ahead, torch, deque, ThreadPoolExecutor)
+        except BaseException as e:   # an unreadable frame must not leave the consumers blocked on an empty queue
+            self.Q.put(e)
+
+    def _produce(self, ahead, torch, deque, ThreadPoolExecutor):
         with ThreadPoolExecutor(max_workers=4) as pool:
             pending, nxt = deque(), 0
             for i in range(self.num_batches):
@@ -76,7 +82,11 @@ class ImageLoader:
         raise NotImplementedError("the SSD input format (dataloader.py:111-148) is not part of this path; use format='yolo'")
 
     def getitem(self):
-        return self.Q.get()
+        item = self.Q.get()
+        if isinstance(item, BaseException):
+            self.Q.put(item)          # every later reader sees it too
+            raise RuntimeError("ImageLoader: frame input failed: %s" % item) from item
+        return item
 
     def length(self):
         return len(self.imglist)

@@ -18,8 +18,14 @@ def im_to_torch(img):
 
 def load_frame_bgr(path: str) -> np.ndarray:
     """cv2.imread replacement: BGR u8 HWC (8-bit PNG/JPEG decode via Pillow is bit-identical)."""
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:8] == b"\x89PNG\r\n\x1a\n":   # same decoder as the fused path (16-bit / palette / alpha handled one way)
+        from .frame_loader import decode_png
+        return decode_png(data)
+    import io
     from PIL import Image
-    return np.ascontiguousarray(np.asarray(Image.open(path).convert("RGB"))[:, :, ::-1])
+    return np.ascontiguousarray(np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))[:, :, ::-1])
 
 
 def crop_from_dets_frame(frame_bgr_u8, boxes, inputResH: int = 320, inputResW: int = 256):

@@ -141,7 +141,7 @@ class FastPoseHIP:
         self._ensure()
         _lib.check(_lib.lib().bp_kpd_set_policy(self._h, sk_target_blocks, sk_min_chunks, sk_max_splits, force_tile))
 
-    def set_precision(self, precision: str = "f32"):
+    def set_precision(self, precision: str = "bf16x3"):
         """'f32' (fp32 MFMA), 'bf16x3' (fp32-accurate: exact 3-way bf16 operand split on the bf16 MFMA) or 'f16'
         (fp16 operands, fp32 accumulate: carries fp16 rounding)."""
         self._ensure()
@@ -153,9 +153,9 @@ class FastPoseHIP:
         """Second engine over the same device filters (own activations): one per concurrent stream."""
         import copy
         self._ensure()
-        other = copy.copy(self)
         h = C.c_void_p()
-        _lib.check(_lib.lib().bp_kpd_clone(self._h, C.byref(h)))
+        _lib.check(_lib.lib().bp_kpd_clone(self._h, C.byref(h)))   # first: a failed clone must not leave a copy owning self._h
+        other = copy.copy(self)
         other._h = h
         return other
 

@@ -39,8 +39,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument('--synthetic', type=int, default=0, help='run on N seeded synthetic frames / weights')
     p.add_argument('--synth_weights', default=False, action='store_true',
                    help='seeded synthetic weights with real frames / ground truth (plumbing runs without checkpoints)')
-    p.add_argument('--precision', choices=['f32', 'bf16x3', 'f16'], default='f32',
-                   help='matrix-core operand precision: f32 (default), bf16x3 (fp32-accurate split), f16 (fp16 operands, '
+    p.add_argument('--precision', choices=['f32', 'bf16x3', 'f16'], default='bf16x3',
+                   help='matrix-core operand precision: bf16x3 (default: fp32-accurate 3-way bf16 split), f32 (fp32 MFMA), f16 (fp16 operands, '
                         'fp32 accumulate); see DESIGN.md 3.1b/c')
     p.add_argument('--streams', type=int, default=4, help='--fused: frames in flight (HIP streams / engine clones)')
     p.add_argument('--load_threads', type=int, default=8, help='--fused: PNG decode threads')

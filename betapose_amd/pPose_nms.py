@@ -122,6 +122,9 @@ def results_to_json_list(all_results, for_eval=False):
 def write_json(all_results, outputpath, for_eval=False, form=None):
     """Default ('coco'-like list) format of the reference's write_json; the 'cmu'/'open' body-pose
     re-mappings (pPose_nms.py:316-347) index 17/18 human joints and do not apply to 50 object key points."""
+    if form is None:   # the reference reads opt.format (pPose_nms.py:287)
+        from .opt import opt as _opt
+        form = getattr(_opt, "format", None)
     if form in ("cmu", "open"):
         raise NotImplementedError("cmu/open formats are human-pose layouts; not used on the 6D path")
     text = json.dumps(results_to_json_list(all_results, for_eval))

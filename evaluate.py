@@ -125,18 +125,21 @@ def main():
         from betapose_amd.frame_loader import FrameLoader
         from betapose_amd.pipeline import StreamedRunner, finish_record
         mine = bpd.shard_indices(len(im_names), rank, world)
-        loader = FrameLoader([os.path.join(args.inputpath, im_names[i]) for i in mine], threads=args.load_threads,
-                             depth=max(16, 2 * args.streams + args.load_threads))
-        runner = StreamedRunner(det, pose_model, loader.height, loader.width, streams=args.streams,
-                                confidence=args.confidence, num_classes=args.num_classes)
         recs = np.zeros((len(mine), 316), np.float32)
 
         def keep(j, rec):
             recs[j] = rec
         t_dev = time.time()
-        runner.run(loader, keep)
+        if len(mine):   # a rank beyond the frame count has nothing to load (its share of the gather is empty)
+            # decode threads are a per-GPU budget: ranks of one node share the host cores
+            threads = max(1, min(args.load_threads, (os.cpu_count() or 8) // max(1, world)))
+            loader = FrameLoader([os.path.join(args.inputpath, im_names[i]) for i in mine], threads=threads,
+                                 depth=max(16, 2 * args.streams + threads))
+            runner = StreamedRunner(det, pose_model, loader.height, loader.width, streams=args.streams,
+                                    confidence=args.confidence, num_classes=args.num_classes)
+            runner.run(loader, keep)
+            loader.close()
         t_dev = time.time() - t_dev
-        loader.close()
         print("rank %d: %d frames, files -> records %.1f frames/sec (%d frames in flight, %d decode threads)" % (
             rank, len(mine), len(mine) / max(t_dev, 1e-9), args.streams, args.load_threads))
         allrec = bpd.gather_records(recs, mine, len(im_names))

@@ -194,3 +194,18 @@ def test_inferennet_fast_loads_the_reference_pkl_layout(tmp_path, cuda, monkeypa
     assert torch.equal(net(x).cpu(), ref)
     with pytest.raises((FileNotFoundError, OSError)):
         InferenNet_fast(5, 1, None)                      # no checkpoint for object 1 in this directory
+
+
+@pytest.mark.parametrize("bad", [
+    "[convolutional]\nfilters=8\nsize=3\nstride=1\npad=1\nactivation=leaky\n[shortcut]\nfrom=-5\nactivation=linear\n",
+    "[yolo]\nmask=0,1,2\nanchors=1,2,3,4,5,6\nclasses=1\n",
+    "[convolutional]\nfilters=18\nsize=1\nstride=1\nactivation=linear\n[yolo]\nmask=0,-1,2\nanchors=1,2,3,4,5,6\nclasses=1\n",
+    "[convolutional]\nfilters=8\nsize=0\nstride=1\nactivation=leaky\n",
+])
+def test_malformed_cfg_is_a_clean_error(cuda, bad):
+    """Out-of-range shortcut sources, a [yolo] at layer 0, negative anchor masks: bp::Error through the C-ABI, no
+    out-of-bounds indexing on the host."""
+    h = C.c_void_p()
+    stream = np.zeros(4096, np.float32)
+    rc = _lib.lib().bp_yolo_create_from_memory(bad.encode(), stream.ctypes.data, stream.size, 64, 1, 0, C.byref(h))
+    assert rc != 0 and _lib.lib().bp_last_error()

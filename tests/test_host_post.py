@@ -2,6 +2,7 @@
 import json
 
 import numpy as np
+import pytest
 import torch
 
 import helpers
@@ -104,3 +105,35 @@ def test_pose_nms_seeded_candidate_sets_match_reference():
             np.testing.assert_array_equal(a, k)          # inputs are not mutated (the reference squeezes/deletes in place)
         counts.append(n)
     assert min(counts) == 1 and max(counts) >= 4
+
+
+def test_write_json_honours_opt_format(tmp_path):
+    """pPose_nms.py:287 reads opt.format; the human-pose layouts must fail loudly, not fall back to the default."""
+    from betapose_amd import pPose_nms
+    from betapose_amd.opt import opt
+    old = getattr(opt, "format", None)
+    try:
+        opt.format = "cmu"
+        with pytest.raises(NotImplementedError):
+            pPose_nms.write_json([], str(tmp_path))
+        opt.format = old
+        pPose_nms.write_json([], str(tmp_path))
+        assert (tmp_path / "Betapose-results.json").read_text() == "[]"
+    finally:
+        opt.format = old
+
+
+def test_image_loader_forwards_decode_errors(tmp_path):
+    """A corrupt frame must surface in the consumer instead of leaving it blocked on the queue (dataloader.py:150-179
+    dies silently in its thread)."""
+    from betapose_amd.dataloader import ImageLoader
+    (tmp_path / "bad.png").write_bytes(b"\x89PNG\r\n\x1a\nnot a png")
+    from betapose_amd.opt import opt
+    old = opt.inputpath
+    opt.inputpath = str(tmp_path)
+    try:
+        loader = ImageLoader(["bad.png"], batchSize=1, format="yolo", reso=416).start()
+        with pytest.raises(RuntimeError, match="frame input failed"):
+            loader.getitem()
+    finally:
+        opt.inputpath = old

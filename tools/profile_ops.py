@@ -16,7 +16,7 @@ ap.add_argument("--sk-min", type=int, default=4)
 ap.add_argument("--tile", type=int, default=-1)
 ap.add_argument("--sk-max", type=int, default=8)
 ap.add_argument("--top", type=int, default=400)
-ap.add_argument("--precision", default="f32")
+ap.add_argument("--precision", default="bf16x3")
 a = ap.parse_args()
 blocks = C.parse_cfg_text(C.yolov3_single_cfg_text())
 det = Darknet("yolov3-single.cfg", max_batch=a.batch).load_stream(synth.synth_yolo_stream(1, blocks)).cuda()

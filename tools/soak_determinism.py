@@ -14,7 +14,7 @@ from betapose_amd.pipeline import FramePipeline
 ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=3000)
 ap.add_argument("--streams", type=int, default=4)
-ap.add_argument("--precision", default="f32", choices=["f32", "bf16x3", "f16"])
+ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3", "f16"])
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 blocks = C.parse_cfg_text(C.yolov3_single_cfg_text())
