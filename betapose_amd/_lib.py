@@ -70,6 +70,9 @@ PROTOTYPES = {
     "bp_pipeline_run": (C.c_int, [vp, C.c_int, vp]),
     "bp_heatmap_argmax": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "bp_solve_pnp": (C.c_int, [vp, vp, C.c_int, vp, vp, vp]),
+    "bp_solve_pnp_refined": (C.c_int, [vp, vp, C.c_int, vp, vp, vp]),
+    "bp_solve_pnp_ransac": (C.c_int, [vp, vp, C.c_int, vp, C.c_double, C.c_int, C.c_double, vp, vp, vp]),
+    "bp_pose_nms": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]),
     "bp_darknet_last_error": (C.c_char_p, []),
     "bp_darknet_create": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(vp)]),
     "bp_darknet_destroy": (None, [vp]),

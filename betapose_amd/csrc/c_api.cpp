@@ -12,8 +12,13 @@
 #include "engine.h"
 #include "frame_io.h"
 
-namespace bp {
+namespace bp {   // host_post.cpp
 int solve_pnp(const double* P, const double* U, int n, const double* K, double* R, double* t);
+int solve_pnp_refined(const double* P, const double* U, int n, const double* K, double* R, double* t);
+int solve_pnp_ransac(const double* P, const double* U, int n, const double* K, double reproj_err, int max_trials,
+                     double confidence, double* R, double* t, unsigned char* inlier_mask);
+int pose_nms(const float* bboxes, const float* bbox_scores, const float* preds, const float* scores, int n, int K,
+             int* out_pick, float* out_pose, float* out_score, float* out_prop);
 }
 
 static thread_local std::string g_err;
@@ -646,8 +651,37 @@ int bp_solve_pnp(const double* pts3d, const double* pts2d, int n, const double* 
     BP_TRY
     BP_CHECK(pts3d && pts2d && K && R && t, "null argument");
     const int rc = bp::solve_pnp(pts3d, pts2d, n, K, R, t);
-    if (rc != 0) throw bp::Error("solve_pnp failed (need >= 6 non-degenerate points)");
+    if (rc != 0) throw bp::Error("solve_pnp failed (need >= 6 non-degenerate points, or >= 4 coplanar ones)");
     return 0;
+    BP_CATCH
+}
+
+int bp_solve_pnp_refined(const double* pts3d, const double* pts2d, int n, const double* K, double* R, double* t) {
+    BP_TRY
+    BP_CHECK(pts3d && pts2d && K && R && t, "null argument");
+    const int rc = bp::solve_pnp_refined(pts3d, pts2d, n, K, R, t);
+    if (rc != 0) throw bp::Error("solve_pnp_refined failed (need >= 6 non-degenerate points)");
+    return 0;
+    BP_CATCH
+}
+
+int bp_solve_pnp_ransac(const double* pts3d, const double* pts2d, int n, const double* K, double reproj_err,
+                        int max_trials, double confidence, double* R, double* t, unsigned char* inliers) {
+    BP_TRY
+    BP_CHECK(pts3d && pts2d && K && R && t, "null argument");
+    BP_CHECK(reproj_err > 0 && max_trials >= 1 && confidence > 0 && confidence < 1, "RANSAC parameters out of range");
+    const int rc = bp::solve_pnp_ransac(pts3d, pts2d, n, K, reproj_err, max_trials, confidence, R, t, inliers);
+    if (rc != 0) throw bp::Error("solve_pnp_ransac failed (need >= 6 points and a 6-point consensus)");
+    return 0;
+    BP_CATCH
+}
+
+int bp_pose_nms(const float* bboxes, const float* bbox_scores, const float* preds, const float* scores, int n, int K,
+                int* out_pick, float* out_pose, float* out_score, float* out_prop) {
+    BP_TRY
+    BP_CHECK(n >= 0 && K >= 1, "bad sizes");
+    BP_CHECK(n == 0 || (bboxes && bbox_scores && preds && scores && out_pick && out_pose && out_score && out_prop), "null argument");
+    return bp::pose_nms(bboxes, bbox_scores, preds, scores, n, K, out_pick, out_pose, out_score, out_prop);
     BP_CATCH
 }
 

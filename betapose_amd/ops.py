@@ -86,17 +86,36 @@ def resize_bicubic(frames_u8, oh: int = 416, ow: int = 416, swap_rb: bool = True
     return out
 
 
-def solve_pnp(points_3d, points_2d, K):
-    """utils/utils.py:17-41 ``pnp``: returns (R [3,3], t [3,1]) f64.  Host-only (no GPU needed)."""
+def solve_pnp(points_3d, points_2d, K, method: str = "iterative"):
+    """utils/utils.py:17-41 ``pnp``: returns (R [3,3], t [3,1]) f64.  Host-only (no GPU needed).
+    ``method``: 'iterative' = the restatement of cv2.solvePnP's SOLVEPNP_ITERATIVE (what the reference calls);
+    'refined' = conditioned DLT + converged minimiser (opt-in, csrc/host_post.cpp)."""
     p3 = np.ascontiguousarray(points_3d, dtype=np.float64)
     p2 = np.ascontiguousarray(np.asarray(points_2d)[:, :2], dtype=np.float64)
     assert p3.shape[0] == p2.shape[0], "points 3D and points 2D must have same number of vertices"
     Kc = np.ascontiguousarray(K, dtype=np.float64)
     R = np.empty((3, 3), np.float64)
     t = np.empty(3, np.float64)
-    _lib.check(_lib.lib().bp_solve_pnp(p3.ctypes.data, p2.ctypes.data, p3.shape[0], Kc.ctypes.data, R.ctypes.data,
-                                       t.ctypes.data))
+    fn = {"iterative": _lib.lib().bp_solve_pnp, "refined": _lib.lib().bp_solve_pnp_refined}[method]
+    _lib.check(fn(p3.ctypes.data, p2.ctypes.data, p3.shape[0], Kc.ctypes.data, R.ctypes.data, t.ctypes.data))
     return R, t.reshape(3, 1)
+
+
+def solve_pnp_ransac(points_3d, points_2d, K, reprojection_error: float = 12.0, iterations: int = 100,
+                     confidence: float = 0.99):
+    """The variant utils/utils.py:32-36 keeps commented out (cv2.solvePnPRansac, reprojectionError=12.0): returns
+    (R [3,3], t [3,1], inlier mask [n] bool).  Host-only."""
+    p3 = np.ascontiguousarray(points_3d, dtype=np.float64)
+    p2 = np.ascontiguousarray(np.asarray(points_2d)[:, :2], dtype=np.float64)
+    assert p3.shape[0] == p2.shape[0], "points 3D and points 2D must have same number of vertices"
+    Kc = np.ascontiguousarray(K, dtype=np.float64)
+    R = np.empty((3, 3), np.float64)
+    t = np.empty(3, np.float64)
+    inl = np.zeros(p3.shape[0], np.uint8)
+    _lib.check(_lib.lib().bp_solve_pnp_ransac(p3.ctypes.data, p2.ctypes.data, p3.shape[0], Kc.ctypes.data,
+                                              float(reprojection_error), int(iterations), float(confidence),
+                                              R.ctypes.data, t.ctypes.data, inl.ctypes.data))
+    return R, t.reshape(3, 1), inl.astype(bool)
 
 
 def heatmap_argmax(hm):

@@ -23,6 +23,8 @@
  *   bp_pipeline_*          DetectionLoader.update -> DetectionProcessor.update -> main loop
  *                          (dataloader.py:330-401,438-457; betapose_evaluate.py:145-176) fused on device
  *   bp_solve_pnp           pnp (cv2.solvePnP + cv2.Rodrigues)                 utils/utils.py:17-41
+ *   bp_solve_pnp_ransac    the commented-out cv2.solvePnPRansac variant       utils/utils.py:32-36
+ *   bp_pose_nms            pose_nms                                           pPose_nms.py:24-122
  *   bp_png_*, bp_loader_*  cv2.imread on ImageLoader's thread (PNG frames)   dataloader.py:150-179
  *   bp_upload              the H2D of a frame (img.cuda())                    dataloader.py:339
  *   bp_darknet_*           Detector(cfg, weights, gpu) / Detector::detect    train_YOLO/src/yolo_v2_class.cpp:95-317
@@ -158,10 +160,24 @@ float* bp_pipeline_heatmaps(bp_pipeline* p);    /* device [batch][50][80][64] */
 int bp_pipeline_set_fixed_box(bp_pipeline* p, const float* box_xyxy_or_null);
 int bp_pipeline_run(bp_pipeline* p, int use_graph, void* stream);
 
-/* ---- host post-processing (f64, no device work) ---- */
-/* SOLVEPNP_ITERATIVE-style: DLT initialisation + Levenberg-Marquardt on the reprojection error.
- * pts3d [n][3], pts2d [n][2], K [9] row-major; outputs R [9] row-major, t [3]. */
+/* ---- host post-processing (no device work) ---- */
+/* pnp (utils/utils.py:17-41): a restatement of cv2.solvePnP's default SOLVEPNP_ITERATIVE (planar / DLT initialisation,
+ * CvLevMarq on (Rodrigues vector, t): <= 20 steps, FLT_EPSILON) followed by cv2.Rodrigues; f64.
+ * pts3d [n][3], pts2d [n][2], K [9] row-major; outputs R [9] row-major, t [3].  n >= 6 (>= 4 for a planar model). */
 int bp_solve_pnp(const double* pts3d, const double* pts2d, int n, const double* K, double* R, double* t);
+/* opt-in, NOT what the reference calls: Hartley-conditioned DLT + the same reprojection objective minimised to
+ * convergence -- for callers who want the optimum where the raw-DLT start of SOLVEPNP_ITERATIVE lands in a wrong basin
+ * (small distant objects).  n >= 6, non-planar. */
+int bp_solve_pnp_refined(const double* pts3d, const double* pts2d, int n, const double* K, double* R, double* t);
+/* the variant utils/utils.py:32-36 keeps commented out (cv2.solvePnPRansac, reprojectionError = 12): 6-point
+ * hypotheses through the solver above, reproducible sampler; inliers [n] (nullable) receives the consensus mask. */
+int bp_solve_pnp_ransac(const double* pts3d, const double* pts2d, int n, const double* K, double reproj_err,
+                        int max_trials, double confidence, double* R, double* t, unsigned char* inliers);
+/* pose_nms (pPose_nms.py:24-122), f32: bboxes [n][4], bbox_scores [n], preds [n][K][2], scores [n][K] -> returns m <= n
+ * merged poses (or a negative status): pick [m] (candidate kept), pose [m][K][2] (the - 0.3 applied), score [m][K],
+ * proposal score [m].  Output arrays sized for n. */
+int bp_pose_nms(const float* bboxes, const float* bbox_scores, const float* preds, const float* scores, int n, int K,
+                int* out_pick, float* out_pose, float* out_score, float* out_prop);
 
 /* ---- Darknet-API-compatible detector (replaces the reference's CPU/CUDA Detector, train_YOLO/src/yolo_v2_class.cpp) ----
  * cfg WITH a [net] block (width == height); BatchNorm folded the Darknet-C way; detections as Detector::detect makes

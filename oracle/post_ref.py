@@ -246,6 +246,142 @@ def pnp_least_squares(points_3d, points_2d, K, R0=None, t0=None):
     return Rot.from_rotvec(s.x[:3]).as_matrix(), s.x[3:].reshape(3, 1), float((s.fun ** 2).sum())
 
 
+def _rodrigues_vec_to_mat(r):
+    """cvRodrigues2, vector input, with dR/dr_i (3 matrices) -- the closed form OpenCV differentiates."""
+    r = np.asarray(r, np.float64)
+    th = float(np.linalg.norm(r))
+    I = np.eye(3)
+
+    def skew(v):
+        return np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0.0]])
+    if th < 1e-12:
+        return I + skew(r), [skew(e) for e in I]
+    u = r / th
+    c, s_, c1 = np.cos(th), np.sin(th), 1 - np.cos(th)
+    uut, ux = np.outer(u, u), skew(u)
+    R = c * I + c1 * uut + s_ * ux
+    dR = []
+    for i in range(3):
+        du = (I[i] - u * u[i]) / th
+        dR.append(-s_ * u[i] * I + s_ * u[i] * uut + c1 * (np.outer(du, u) + np.outer(u, du)) + c * u[i] * ux + s_ * skew(du))
+    return R, dR
+
+
+def _rodrigues_mat_to_vec(R):
+    from scipy.spatial.transform import Rotation as Rot
+    U, _, Vt = np.linalg.svd(np.asarray(R, np.float64))
+    return Rot.from_matrix(U @ Vt).as_rotvec()
+
+
+def solve_pnp_iterative_ref(points_3d, points_2d, K):
+    """Independent numpy restatement of cv2.solvePnP(flags=SOLVEPNP_ITERATIVE) + cv2.Rodrigues as the reference calls
+    it (utils/utils.py:17-41; OpenCV calib3d cvFindExtrinsicCameraParams2, 2.4 ... 4.6): planar / DLT initialisation,
+    CvLevMarq on (rvec, tvec) with <= 20 accepted steps and FLT_EPSILON.  Same steps as csrc/host_post.cpp, different
+    linear algebra (LAPACK SVD instead of Jacobi sweeps, OpenCV's closed-form dR/dr instead of the SO(3) right
+    Jacobian).  OpenCV itself is not available here: "parity unpinned" against a real cv2 build."""
+    P = np.asarray(points_3d, np.float64)
+    U = np.asarray(points_2d, np.float64)[:, :2]
+    K = np.asarray(K, np.float64)
+    n = P.shape[0]
+    fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+    mn = np.stack([(U[:, 0] - cx) / fx, (U[:, 1] - cy) / fy], 1)
+    Mc = P.mean(0)
+    MM = (P - Mc).T @ (P - Mc)
+    _, W, Vt = np.linalg.svd(MM)
+    if W[2] / W[1] < 1e-3:
+        Rt = Vt.copy()
+        if Rt[2, 0] ** 2 + Rt[2, 1] ** 2 < 1e-10:
+            Rt = np.eye(3)
+        if np.linalg.det(Rt) < 0:
+            Rt = -Rt
+        Tt = -Rt @ Mc
+        xy = (P @ Rt.T + Tt)[:, :2]
+
+        def norm_pts(q):
+            c = q.mean(0)
+            d = np.linalg.norm(q - c, axis=1).mean()
+            s = np.sqrt(2) / d
+            return (q - c) * s, np.array([[s, 0, -s * c[0]], [0, s, -s * c[1]], [0, 0, 1.0]])
+        a, T0 = norm_pts(xy)
+        b, T1 = norm_pts(mn)
+        rows = []
+        for (x, y), (u, v) in zip(a, b):
+            rows.append([x, y, 1, 0, 0, 0, -u * x, -u * y, -u])
+            rows.append([0, 0, 0, x, y, 1, -v * x, -v * y, -v])
+        H = np.linalg.svd(np.asarray(rows))[2][-1].reshape(3, 3)
+        H = np.linalg.inv(T1) @ H @ T0
+        H = H / H[2, 2]
+        h1, h2, h3 = H[:, 0], H[:, 1], H[:, 2]
+        n1, n2 = np.linalg.norm(h1), np.linalg.norm(h2)
+        t = h3 * 2.0 / (n1 + n2)
+        h1, h2 = h1 / n1, h2 / n2
+        Hm = np.stack([h1, h2, np.cross(h1, h2)], 1)
+        Hm = _rodrigues_vec_to_mat(_rodrigues_mat_to_vec(Hm))[0]
+        t = Hm @ Tt + t
+        R = Hm @ Rt
+    else:
+        L = np.zeros((2 * n, 12))
+        for i in range(n):
+            x, y = mn[i]
+            X = np.r_[P[i], 1.0]
+            L[2 * i, 0:4], L[2 * i, 8:12] = X, -x * X
+            L[2 * i + 1, 4:8], L[2 * i + 1, 8:12] = X, -y * X
+        v = np.linalg.svd(L.T @ L)[2][-1].reshape(3, 4)
+        RR, tt = v[:, :3], v[:, 3]
+        if np.linalg.det(RR) < 0:
+            RR, tt = -RR, -tt
+        sc = np.linalg.norm(RR)
+        Uu, _, Vv = np.linalg.svd(RR)
+        R = Uu @ Vv
+        t = tt * (np.linalg.norm(R) / sc)
+    prm = np.r_[_rodrigues_mat_to_vec(R), t]
+
+    def project(prm, want_J):
+        R, dR = _rodrigues_vec_to_mat(prm[:3])
+        Y = P @ R.T + prm[3:]
+        iz = np.where(Y[:, 2] != 0, 1.0 / np.where(Y[:, 2] != 0, Y[:, 2], 1.0), 1.0)
+        err = np.stack([fx * Y[:, 0] * iz + cx - U[:, 0], fy * Y[:, 1] * iz + cy - U[:, 1]], 1).ravel()
+        if not want_J:
+            return err, None
+        J = np.zeros((2 * n, 6))
+        dproj = np.zeros((n, 2, 3))
+        dproj[:, 0, 0], dproj[:, 0, 2] = fx * iz, -fx * Y[:, 0] * iz * iz
+        dproj[:, 1, 1], dproj[:, 1, 2] = fy * iz, -fy * Y[:, 1] * iz * iz
+        for i in range(3):
+            dY = P @ dR[i].T
+            J[:, i] = np.einsum("nij,nj->ni", dproj, dY).ravel()
+            J[:, 3 + i] = dproj[:, :, i].ravel()
+        return err, J
+
+    lam10, iters, prev_err = -3, 0, 0.0
+    while True:
+        err, J = project(prm, True)
+        JtJ, JtE = J.T @ J, J.T @ err
+        prev = prm.copy()
+        if iters == 0:
+            prev_err = np.linalg.norm(err)
+
+        def step():
+            A = JtJ.copy()
+            A[np.diag_indices(6)] *= 1.0 + 10.0 ** lam10
+            return prev - np.linalg.solve(A, JtE)
+        prm = step()
+        while True:
+            err_n = np.linalg.norm(project(prm, False)[0])
+            if err_n > prev_err:
+                lam10 += 1
+                if lam10 <= 16:
+                    prm = step()
+                    continue
+            break
+        lam10 = max(lam10 - 1, -16)
+        iters += 1
+        if iters >= 20 or np.linalg.norm(prm - prev) / max(np.linalg.norm(prev), 1e-300) < float(np.finfo(np.float32).eps):
+            break
+        prev_err = err_n
+    return _rodrigues_vec_to_mat(prm[:3])[0], prm[3:].reshape(3, 1)
+
+
 # ----------------------------------------------------------------------------- JSON + metrics (a12)
 def results_to_json(all_results) -> str:
     out = []

@@ -1,12 +1,18 @@
-"""Pose solve (bp_solve_pnp, host C++ f64) -- known-answer tests (OpenCV is not available, so
-cv2.solvePnP parity is pinned by synthetic poses and an independent scipy minimiser). CPU only."""
+"""Pose solve (bp_solve_pnp & friends, host C++ f64).  The reference calls cv2.solvePnP (SOLVEPNP_ITERATIVE) +
+cv2.Rodrigues (utils/utils.py:17-41); OpenCV is not available here, so parity is pinned the way SURVEY §8 a11 allows:
+ * the product's restatement of that algorithm against an INDEPENDENT numpy restatement of the same published steps in
+   the oracle (different linear algebra, different rotation Jacobian) -- on clean, noisy, outlier-laden, near-planar,
+   planar and few-point inputs, including the inputs where the algorithm itself lands in a wrong basin;
+ * known answers (noise-free poses) and an independent scipy minimiser where the start is good;
+ * the opt-in refined solver and the RANSAC variant against the optimum / the planted outliers.
+"parity unpinned" against a real cv2 build.  CPU only."""
 import os
 
 import numpy as np
 import pytest
 from scipy.spatial.transform import Rotation as Rot
 
-from betapose_amd.ops import solve_pnp
+from betapose_amd.ops import solve_pnp, solve_pnp_ransac
 from betapose_amd.synth import CAM_K, synth_kp3d
 from oracle import post_ref
 
@@ -25,22 +31,115 @@ def _poses(n, seed):
         yield R, t, rng
 
 
-@pytest.mark.parametrize("npts", [50, 10, 6])
+def _same(a, b, tol):
+    (Ra, ta), (Rb, tb) = a, b
+    return np.abs(Ra - Rb).max() < tol and np.abs(np.ravel(ta) - np.ravel(tb)).max() < tol
+
+
+@pytest.mark.parametrize("npts", [50, 10, 8, 6])
 def test_noise_free_pose_is_recovered(npts):
+    """--left_keypoints keeps 6..50 points (dataloader.py:718-722)."""
     P = synth_kp3d(50)[:npts]
     for R, t, _ in _poses(50, 1):
         R1, t1 = solve_pnp(P, _project(P, R, t), CAM_K)
-        assert np.abs(R1 - R).max() < 1e-8 and np.abs(t1[:, 0] - t).max() < 1e-8
+        assert np.abs(R1 - R).max() < 1e-6 and np.abs(t1[:, 0] - t).max() < 1e-6   # a FLT_EPSILON-terminated minimiser
         assert abs(np.linalg.det(R1) - 1) < 1e-12
 
 
-def test_noisy_pose_matches_independent_minimiser():
+@pytest.mark.parametrize("scale", [1.0, 1000.0])       # key-point models in metres (the reference, sixd.py) or millimetres
+@pytest.mark.parametrize("sigma", [0.0, 0.3, 1.0, 3.0])
+def test_product_restatement_equals_oracle_restatement(scale, sigma):
+    """Same published steps, two implementations: equal to solver tolerance on every input, also where the raw-DLT start
+    puts both into the same wrong basin."""
+    P = synth_kp3d(50) * scale
+    worst = 0.0
+    for R, t, rng in _poses(60, 2):
+        uv = _project(P, R, t * scale) + rng.normal(0, sigma, (50, 2))
+        a = solve_pnp(P, uv, CAM_K)
+        b = post_ref.solve_pnp_iterative_ref(P, uv, CAM_K)
+        worst = max(worst, np.abs(a[0] - b[0]).max(), np.abs(a[1] - b[1]).max() / scale)
+    assert worst < 1e-6, worst
+
+
+def test_outliers_few_points_and_near_planar_models_follow_the_oracle():
+    rng = np.random.default_rng(5)
     P = synth_kp3d(50)
-    for R, t, rng in _poses(40, 2):
-        uv = _project(P, R, t) + rng.normal(0, 1.0, (50, 2))
+    for R, t, _ in _poses(30, 6):
+        uv = _project(P, R, t) + rng.normal(0, 0.5, (50, 2))
+        uv_out = uv.copy()
+        bad = rng.choice(50, 8, replace=False)
+        uv_out[bad] += rng.uniform(-80, 80, (8, 2))                      # gross outliers, as a random-weight KPD emits
+        assert _same(solve_pnp(P, uv_out, CAM_K), post_ref.solve_pnp_iterative_ref(P, uv_out, CAM_K), 1e-4)
+        for n in (6, 7, 8, 9, 10):                                       # --left_keypoints 6..10
+            assert _same(solve_pnp(P[:n], uv[:n], CAM_K), post_ref.solve_pnp_iterative_ref(P[:n], uv[:n], CAM_K), 1e-4)
+        flat = P * np.array([1.0, 1.0, 0.06])                            # near-planar, still on the DLT branch
+        uvf = _project(flat, R, t) + rng.normal(0, 0.3, (50, 2))
+        # ill-conditioned: 20 unconverged steps amplify the last bits of the two eigen-solvers
+        assert _same(solve_pnp(flat, uvf, CAM_K), post_ref.solve_pnp_iterative_ref(flat, uvf, CAM_K), 2e-3)
+
+
+def test_planar_model_takes_the_homography_branch():
+    P = synth_kp3d(50).copy()
+    P[:, 2] = 0.01                                                       # W[2]/W[1] < 1e-3: cvFindExtrinsicCameraParams2's planar start
+    tilt = Rot.from_rotvec([0.3, -0.2, 0.1]).as_matrix()
+    P = P @ tilt.T
+    for R, t, rng in _poses(30, 7):
+        uv = _project(P, R, t)
         R1, t1 = solve_pnp(P, uv, CAM_K)
-        R2, t2, _ = post_ref.pnp_least_squares(P, uv, CAM_K, R, t)   # scipy LM started at the truth
-        assert np.abs(R1 - R2).max() < 1e-6 and np.abs(t1 - t2).max() < 1e-6
+        assert np.abs(R1 - R).max() < 1e-6 and np.abs(t1[:, 0] - t).max() < 1e-6
+        uvn = uv + rng.normal(0, 0.5, uv.shape)
+        assert _same(solve_pnp(P, uvn, CAM_K), post_ref.solve_pnp_iterative_ref(P, uvn, CAM_K), 1e-6)
+        R4, t4 = solve_pnp(P[:4], uv[:4], CAM_K)                         # 4 coplanar points are enough on this branch
+        assert np.abs(_project(P[:4], R4, t4[:, 0]) - uv[:4]).max() < 1e-4
+
+
+def test_good_start_reaches_the_optimum_and_refined_always_does():
+    """Where the raw DLT starts in the right basin the 20-step minimiser agrees with an independent converged one; the
+    opt-in refined solver (conditioned DLT) agrees on EVERY pose -- and the share of poses on which the restated
+    SOLVEPNP_ITERATIVE start fails at 1 px noise on a 6 cm model is what DESIGN.md 3.3 quotes."""
+    P = synth_kp3d(50)
+    wrong = 0
+    for R, t, rng in _poses(80, 2):
+        uv = _project(P, R, t) + rng.normal(0, 1.0, (50, 2))
+        R2, t2, _ = post_ref.pnp_least_squares(P, uv, CAM_K, R, t)       # scipy LM started at the truth
+        Rr, tr = solve_pnp(P, uv, CAM_K, method="refined")
+        assert np.abs(Rr - R2).max() < 1e-6 and np.abs(tr - t2).max() < 1e-6
+        Ri, ti = solve_pnp(P, uv, CAM_K)
+        if np.abs(Ri - R2).max() < 1e-5 and np.abs(ti - t2).max() < 1e-5:
+            continue
+        wrong += 1                       # another basin of the same objective (often the mirrored pose behind the camera:
+        cost_i = ((_project(P, Ri, ti[:, 0]) - uv) ** 2).sum()           # the DLT's sign is fixed by det(RR), not by t_z > 0)
+        cost_o = ((_project(P, R2, t2[:, 0]) - uv) ** 2).sum()
+        assert cost_i > cost_o
+    assert 0 < wrong < 40, wrong
+
+
+def test_ransac_variant_rejects_planted_outliers():
+    """utils/utils.py:32-36 (commented out in the reference): reprojectionError = 12."""
+    P = synth_kp3d(50) * 3.0                                             # a 20 cm object: the raw DLT start is reliable
+    for R, t, rng in _poses(20, 8):
+        uv = _project(P, R, t) + rng.normal(0, 0.5, (50, 2))
+        bad = rng.choice(50, 10, replace=False)
+        uv[bad] += rng.uniform(30, 120, (10, 2)) * rng.choice([-1, 1], (10, 2))
+        R1, t1, inl = solve_pnp_ransac(P, uv, CAM_K, reprojection_error=12.0)
+        assert not inl[bad].any() and inl.sum() >= 38
+        assert np.abs(R1 - R).max() < 2e-2 and np.abs(t1[:, 0] - t).max() < 2e-2
+        R2, t2, inl2 = solve_pnp_ransac(P, uv, CAM_K, reprojection_error=12.0)
+        assert np.array_equal(R1, R2) and np.array_equal(inl, inl2)      # reproducible sampler
+
+
+def test_golden_frame_keypoints_product_equals_oracle():
+    """The key points the REFERENCE's stage classes produced for the golden frames (tests/golden/pipeline.npz: random
+    weights, so they are no consistent projection -- the input class the pipeline tests feed the solver), all 50 and
+    pruned to --left_keypoints 10 / 6 (dataloader.py:718-722)."""
+    import helpers
+    pipe = helpers.golden("pipeline.npz")
+    kp3d = synth_kp3d(50)
+    for i in range(int(pipe["n_frames"])):
+        kp, sc = pipe["f%d_nms_kp" % i], pipe["f%d_nms_score" % i][:, 0]
+        for left in (50, 10, 6):
+            k2, k3, _ = post_ref.prune_keypoints(kp, kp3d, sc, left)
+            assert _same(solve_pnp(k3, k2, CAM_K), post_ref.solve_pnp_iterative_ref(k3, k2, CAM_K), 1e-5)
 
 
 def test_designated_keypoints_from_reference_assets():
@@ -55,7 +154,7 @@ def test_designated_keypoints_from_reference_assets():
     assert pts.shape == (50, 3)
     for R, t, _ in _poses(10, 3):
         R1, t1 = solve_pnp(pts, _project(pts, R, t), CAM_K)
-        assert np.abs(R1 - R).max() < 1e-7 and np.abs(t1[:, 0] - t).max() < 1e-7
+        assert np.abs(R1 - R).max() < 1e-6 and np.abs(t1[:, 0] - t).max() < 1e-6
 
 
 def test_rejects_too_few_points():
@@ -63,3 +162,5 @@ def test_rejects_too_few_points():
     P = synth_kp3d(5)
     with pytest.raises(BetaposeHipError):
         solve_pnp(P, np.zeros((5, 2)), CAM_K)
+    with pytest.raises(BetaposeHipError):
+        solve_pnp_ransac(P, np.zeros((5, 2)), CAM_K)
