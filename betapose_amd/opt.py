@@ -35,6 +35,10 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument('--occlusion', default=False, action='store_true',
                    help='Occlusion-LineMod protocol (occlusion_betapose_evaluate.py): GT sequence 02, every GT object of a '
                         'frame, --left_keypoints for PnP, 20 px reprojection threshold')
+    p.add_argument('--obj_ids', default='', type=str,
+                   help='occlusion_evaluate.py: comma-separated object ids evaluated in ONE run, e.g. 1,5,6,8,9,10,11,12 -- '
+                        'units of work are (frame, object) pairs, every object keeps its weights resident, frames are '
+                        'decoded once')
     p.add_argument('--fused', default=False, action='store_true', help='one hipGraph per frame instead of stage threads')
     p.add_argument('--synthetic', type=int, default=0, help='run on N seeded synthetic frames / weights')
     p.add_argument('--synth_weights', default=False, action='store_true',

@@ -25,7 +25,8 @@ RESULT_FLOATS = _lib.RESULT_FLOATS
 
 class FramePipeline:
     def __init__(self, det_model, pose_model, frame_h: int = 480, frame_w: int = 640, batch: int = 1,
-                 confidence: float = 0.01, num_classes: int = 80, use_graph: bool = True, keep_heatmaps: bool = False):
+                 confidence: float = 0.01, num_classes: int = 80, use_graph: bool = True, keep_heatmaps: bool = False,
+                 frames=None):
         import torch
         _lib.require_gpu()
         self.det, self.pose = det_model, getattr(pose_model, "pyranet", pose_model)
@@ -35,7 +36,9 @@ class FramePipeline:
         self.det.cuda()
         self.pose.cuda()
         dev = "cuda:%d" % self.det._device
-        self.frames = torch.zeros((self.batch, self.H, self.W, 3), dtype=torch.uint8, device=dev)
+        # ``frames``: a device frame buffer shared with other pipelines (several objects looking at the same frame)
+        self.frames = frames if frames is not None else torch.zeros((self.batch, self.H, self.W, 3), dtype=torch.uint8, device=dev)
+        assert tuple(self.frames.shape) == (self.batch, self.H, self.W, 3) and self.frames.dtype == torch.uint8
         self.results = torch.zeros((self.batch, RESULT_FLOATS), dtype=torch.float32, device=dev)
         self.heatmaps = torch.zeros((self.batch, 50, 80, 64), dtype=torch.float32, device=dev) if keep_heatmaps else None
         h = C.c_void_p()
@@ -143,6 +146,100 @@ class StreamedRunner:
                 for st in self.streams:
                     st.synchronize()
                 for _, idx in inflight:
+                    try:
+                        source.release(idx)
+                    except Exception:
+                        pass
+                inflight.clear()
+        return j
+
+
+class MultiObjectRunner:
+    """Occlusion-LineMod as a multi-object workload (occlusion_betapose_evaluate.py:89-90,204,218-257 runs ONE object
+    per process and re-decodes every frame per object): the unit of work is a (frame, object) pair.  Every
+    object keeps its own detector + key-point weights resident; a frame is decoded ONCE (loader slot), and each of its
+    units uploads it from that slot to the stream it lands on and runs that object's graph.  ``streams`` units are in
+    flight; unit u = frame_position * n_objects + object_position, and only the units in ``owned`` are run (the caller
+    shards them ``u % world``).
+
+    ``engines``: {obj_id: (Darknet, FastPoseHIP)} for the objects this rank owns units of."""
+
+    def __init__(self, engines: dict, obj_ids: List[int], frame_h: int = 480, frame_w: int = 640, streams: int = 4,
+                 confidence: float = 0.01, num_classes: int = 80, use_graph: bool = True):
+        import torch
+        self.obj_ids = list(obj_ids)
+        S = max(1, int(streams))
+        self.S, self.H, self.W = S, int(frame_h), int(frame_w)
+        self.pipes = {}            # (stream, obj_id) -> FramePipeline over the stream's shared frame buffer
+        dev = None
+        self.frame_bufs = []
+        for k in range(S):
+            buf = None
+            for oid, (det, pose) in engines.items():
+                pose = getattr(pose, "pyranet", pose)
+                d, p_ = (det, pose) if k == 0 else (det.clone(), pose.clone())
+                fp = FramePipeline(d, p_, frame_h, frame_w, batch=1, confidence=confidence, num_classes=num_classes,
+                                   use_graph=use_graph, frames=buf)
+                buf = fp.frames
+                dev = buf.device
+                self.pipes[(k, oid)] = fp
+            self.frame_bufs.append(buf)
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if dev is not None else []
+        self._pinned = [torch.empty((1, RESULT_FLOATS), dtype=torch.float32).pin_memory() for _ in range(2 * S)]
+        self._events = [torch.cuda.Event() for _ in range(2 * S)]
+
+    def run(self, source, frame_positions: List[int], owned, on_record) -> int:
+        """``source``: FrameLoader over the frames this rank touches (in ``frame_positions`` order: position of each
+        in the global frame list); ``owned(u)`` tells whether unit u belongs to this rank;
+        ``on_record(u, rec[316])`` receives every owned unit's record.  Returns the number of units run."""
+        import torch
+        L = _lib.lib()
+        S, NS, nbytes, K = self.S, 2 * self.S, self.H * self.W * 3, len(self.obj_ids)
+        inflight = []              # (sequence number, unit, loader index or None when this is not the frame's last unit)
+        pending = {}               # loader index -> units still in flight
+
+        def finish():
+            j, u, idx = inflight.pop(0)
+            self._events[j % NS].synchronize()
+            rec = self._pinned[j % NS].numpy()[0].copy()
+            pending[idx] -= 1
+            if pending[idx] == 0:
+                del pending[idx]
+                source.release(idx)
+            on_record(u, rec)
+
+        j = 0
+        try:
+            for idx, frame, addr in source:
+                if frame.shape != (self.H, self.W, 3):
+                    source.release(idx)
+                    raise ValueError("frame %d is %s, pipeline was built for %s" % (idx, frame.shape, (self.H, self.W, 3)))
+                units = [frame_positions[idx] * K + oi for oi in range(K) if owned(frame_positions[idx] * K + oi)]
+                if not units:
+                    source.release(idx)
+                    continue
+                pending[idx] = len(units)
+                for u in units:
+                    k = j % S
+                    st = self.streams[k]
+                    # the stream's frame buffer is only rewritten after the stream's previous unit finished reading it
+                    # (same stream: in order)
+                    with torch.cuda.stream(st):
+                        _lib.check(L.bp_upload(self.frame_bufs[k].data_ptr(), addr, nbytes, st.cuda_stream))
+                        self.pipes[(k, self.obj_ids[u % K])].enqueue(st.cuda_stream)
+                        self._pinned[j % NS].copy_(self.pipes[(k, self.obj_ids[u % K])].results, non_blocking=True)
+                        self._events[j % NS].record(st)
+                    inflight.append((j, u, idx))
+                    j += 1
+                    if len(inflight) > S:
+                        finish()
+            while inflight:
+                finish()
+        finally:
+            if inflight:
+                for st in self.streams:
+                    st.synchronize()
+                for idx in list(pending):
                     try:
                         source.release(idx)
                     except Exception:

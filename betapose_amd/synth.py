@@ -99,6 +99,12 @@ def synth_fastpose_state_dict(seed: int = 2, n_classes: int = 50,
     return sd
 
 
+def object_seeds(obj_id: int):
+    """(detector seed, key-point-net seed) of the seeded synthetic weights of object ``obj_id``: (1, 2) for object 1
+    (the fixtures' weights), distinct streams for the others so several resident objects really differ."""
+    return (1, 2) if int(obj_id) == 1 else (1 + 16 * int(obj_id), 2 + 16 * int(obj_id))
+
+
 def synth_frame(seed: int = 1234, h: int = 480, w: int = 640) -> np.ndarray:
     """LineMod-shaped BGR u8 frame: smooth low-res field + noise."""
     rng = _rng(seed)

@@ -107,8 +107,9 @@ def main():
     ys = ks = None
     if rank == 0:
         if (args.synthetic or args.synth_weights) and not args.yolo_weights:
-            ys = synth.synth_yolo_stream(1)
-            ks = fastpose_stream_from_state_dict(synth.synth_fastpose_state_dict(2, args.nClasses), args.nClasses)
+            sy, sk = synth.object_seeds(obj_id) if not args.synthetic else (1, 2)
+            ys = synth.synth_yolo_stream(sy)
+            ks = fastpose_stream_from_state_dict(synth.synth_fastpose_state_dict(sk, args.nClasses), args.nClasses)
         else:
             ys = read_darknet_weights(args.yolo_weights or 'models/yolo/{:02d}.weights'.format(obj_id))[2]
             ks = fastpose_stream_from_state_dict(

@@ -53,3 +53,67 @@ def test_evaluate_fused_two_ranks_equals_one(tmp_path, cuda):
     assert [g["image_id"] for g in outs[0]] == [g["image_id"] for g in outs[1]] and len(outs[0]) == 7
     for a, b in zip(*outs):
         assert a["keypoints"] == b["keypoints"] and a["cam_R"] == b["cam_R"] and a["cam_t"] == b["cam_t"]
+
+
+def test_occlusion_multi_object_units(tmp_path):
+    """Occlusion-LineMod as (frame, object) units (BASELINE configs[4]): a synthetic SIXD tree with three
+    objects per frame whose ground truth is written from each object's own single-object pipeline (closed loop).
+    One run with --obj_ids must (a) print 1.000 for every object, (b) give per-object JSON identical to that
+    object's single-object run, and (c) give identical JSON whether the units run on 1 rank or are sharded over 2."""
+    import re
+    import torch
+    from PIL import Image
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers
+    from betapose_amd import synth
+    from betapose_amd.darknet import Darknet
+    from betapose_amd.kpd import FastPoseHIP
+    from betapose_amd.pipeline import FramePipeline, finish_record
+    from betapose_amd.weights import fastpose_stream_from_state_dict
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    objs, left = [1, 5, 6], 10
+    frames = helpers.frames(3)
+    indir = tmp_path / "rgb"
+    indir.mkdir()
+    for i, fr in enumerate(frames):
+        Image.fromarray(fr[:, :, ::-1].copy()).save(indir / ("%04d.png" % i))
+    kp_mm = {o: np.round(synth.synth_kp3d(50, seed=7 + o) * 1000.0, 6) for o in objs}
+    gt = {i: [(7, np.eye(3), np.array([0.0, 0.0, 800.0]), [5, 5, 20, 20])] for i in range(len(frames))}
+    for o in objs:
+        sy, sk = synth.object_seeds(o)
+        det = Darknet("yolo/cfg/yolov3-single.cfg", reso=416).load_stream(synth.synth_yolo_stream(sy)).cuda()
+        pose = FastPoseHIP.from_stream(fastpose_stream_from_state_dict(synth.synth_fastpose_state_dict(sk, 50), 50), n_classes=50).cuda()
+        pipe = FramePipeline(det, pose, 480, 640, batch=1, confidence=0.01)
+        for i, fr in enumerate(frames):
+            out = finish_record(pipe.run(fr)[0], "%04d.png" % i, kp_mm[o] / 1000.0, synth.CAM_K, left)
+            assert out["boxes"] is not None and len(out["result"]) == 1
+            x1, y1, x2, y2 = [float(v) for v in out["result"][0]["bbox"]]
+            gt[i].append((o, out["cam_R"], np.asarray(out["cam_t"]).reshape(3) * 1000.0, [x1, y1, x2 - x1, y2 - y1]))
+        del pipe, det, pose
+    rng = np.random.default_rng(0)
+    synth.write_sixd_tree(str(tmp_path / "sixd"), 2, gt, {o: rng.normal(size=(300, 3)) * 30.0 for o in objs}, kp_mm,
+                          {o: 100.0 for o in objs})
+    common = ["--indir", str(indir), "--sixd_base", str(tmp_path / "sixd"), "--synth_weights", "--fused",
+              "--left_keypoints", str(left), "--streams", "2"]
+    script = os.path.join(ROOT, "occlusion_evaluate.py")
+
+    def run(nproc, extra, outdir):
+        if nproc == 1:
+            r = subprocess.run([sys.executable, script] + common + extra + ["--outdir", str(outdir)], capture_output=True,
+                               text=True, timeout=900, cwd=ROOT)
+        else:
+            r = _launch(nproc, [script] + common + extra + ["--outdir", str(outdir)])
+        assert r.returncode == 0, r.stdout + r.stderr
+        return r.stdout
+    out1 = run(1, ["--obj_ids", "1,5,6"], tmp_path / "m1")
+    for o in objs:
+        nums = dict(re.findall(r"(Mean add accuracy|2d reprojection accuracy with leftkeypoints \d+|Mean IoU) for seq %02d is: ([\d.nan]+)" % o, out1))
+        assert list(nums.values()) == ["1.000"] * 3, out1
+    run(2, ["--obj_ids", "1,5,6"], tmp_path / "m2")
+    for o in objs:
+        j1 = open(tmp_path / "m1" / ("obj_%02d" % o) / "Betapose-results.json").read()
+        assert j1 == open(tmp_path / "m2" / ("obj_%02d" % o) / "Betapose-results.json").read()       # 1 rank == 2 ranks
+        run(1, ["--obj_id", str(o)], tmp_path / ("s%d" % o))
+        assert j1 == open(tmp_path / ("s%d" % o) / "Betapose-results.json").read()                   # == single-object run
+        assert len(json.loads(j1)) == 3
