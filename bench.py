@@ -5,7 +5,7 @@
 
 One "step" = one pass of the hot path over one batch (default batch 1 = BASELINE.json
 configs[1]) of synthetic 640x480 BGR u8 frames that are already resident in HBM:
-  device (one hipGraph): Pillow-exact bicubic stretch to 416^2 -> YOLOv3 (fp32 MFMA) ->
+  device (one hipGraph): Pillow-exact bicubic stretch to 416^2 -> YOLOv3 (fp32-accurate bf16x3 MFMA) ->
       decode + arg-max objectness -> box rescale + crop 320x256 -> FastPose (SE-ResNet-101 + DUC)
       -> heat-map arg-max -> 316-float record
   host: D2H of the record, key-point decoding, pPose-NMS, PnP  (software-pipelined one step deep)
@@ -13,8 +13,10 @@ Weights are seeded random tensors of the reference architectures (no checkpoints
 Frames shard by image: each rank runs its own frames (weak scaling), weights are broadcast from
 rank 0 over RCCL at start-up and the per-frame result records are all-gathered at the end.
 
-Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel, measured live with
-HIP events) and "cpu_baseline" (oracle on the host cores, N=1 only, bounded sample).
+Prints ONE JSON line (rank 0).  Extra objects: "roofline" (conv FLOPs of the timed region over its wall clock = the
+in-situ figure, plus the dominant kernel alone with HIP events), "latency_ms" (per-frame p50 / p95 with all frames in
+flight and strictly one at a time), "h2d_inclusive" (the same run with every frame uploaded from pinned host memory
+inside the timed region -- never `value`), "rccl" (N > 1) and "cpu_baseline" (oracle on the host cores, N = 1 only).
 """
 from __future__ import annotations
 
@@ -31,7 +33,8 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_F16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: BF16/F16 ~2.5 PF dense (v_mfma_f32_32x32x16_f16)
-TILE_NAMES = {0: "1, 1", 1: "2, 1"}
+PEAK_BF16X3_TFLOPS = 2500.0 / 6  # fp32-accurate mode: six bf16 MFMA products per algorithmic multiply
+TILE_NAMES = {0: "1, 1", 1: "2, 1", 2: "1, 1", 3: "1, 2", 5: "2, 1", 6: "2, 2"}
 
 
 def parse_args():
@@ -47,6 +50,7 @@ def parse_args():
                     help="N=1 only: after the timed region, also time a short run of these matrix-core operand modes on "
                          "the same workload and report them under \"other_precisions\" (never as \"value\"); '' = skip")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-side-runs", action="store_true", help="skip the one-frame-at-a-time and H2D-inclusive runs")
     ap.add_argument("--partition", type=int, default=0,
                     help="give each of the --streams frames in flight its own 1/PARTITION slice of the CUs of every "
                          "XCD (hipExtStreamCreateWithCUMask); 0 = ordinary streams sharing the chip")
@@ -96,7 +100,7 @@ def cpu_baseline(seconds: float, kp3d, cam_K):
         _, preds_img, preds_scores = post_ref.get_prediction(hm, pt1, pt2)
         res = post_ref.pose_nms(boxes, scores, preds_img, preds_scores)
         if res:
-            post_ref.pnp_least_squares(kp3d, res[0]["keypoints"].numpy(), cam_K)
+            post_ref.solve_pnp_iterative_ref(kp3d, res[0]["keypoints"].numpy(), cam_K)
         return res
 
     frames = synth.synth_frames(4, 1234)
@@ -112,7 +116,7 @@ def cpu_baseline(seconds: float, kp3d, cam_K):
     return {"value": n / el, "unit": "frames/sec", "cores": torch.get_num_threads(), "kind": "port",
             "reference_darknet_c": ref,
             "sample": "%d synthetic 640x480 frames through oracle/ (PIL resize, torch-CPU fp32 YOLOv3+FastPose, "
-                      "getPrediction, pose_nms, scipy PnP) in %.1f s" % (n, el),
+                      "getPrediction, pose_nms, SOLVEPNP_ITERATIVE restatement) in %.1f s" % (n, el),
             "cpu_model": _cpu_model()}
 
 
@@ -204,8 +208,9 @@ def roofline(det, pose, batch):
     # rocprofv3 PMC passes (profiles/*_pmc_traffic.json, collected with tools/pmc_traffic.sh, corrections inside)
     traffic, traffic_src = None, None
     mode = {2: "f16", 3: "bf16x3"}.get(key[1], "f32")
+    family = "conv_w64_kernel" if key[0] >= 2 else "conv_igemm_h_kernel"
     want = "bp::conv_igemm_kernel<%s" % TILE_NAMES.get(key[0], "?") if mode == "f32" else \
-        "bp::conv_igemm_h_kernel<%s, %d>" % (TILE_NAMES.get(key[0], "?"), 1 if mode == "f16" else 3)
+        "bp::%s<%s, %d" % (family, TILE_NAMES.get(key[0], "?"), 1 if mode == "f16" else 3)
     try:
         import glob
         for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic*.json")))[::-1]:
@@ -215,25 +220,28 @@ def roofline(det, pose, batch):
                 break
     except Exception:
         pass
-    peak = PEAK_FP32_MFMA_TFLOPS if mode == "f32" else PEAK_F16_MFMA_TFLOPS
+    peak = {"f32": PEAK_FP32_MFMA_TFLOPS, "f16": PEAK_F16_MFMA_TFLOPS, "bf16x3": PEAK_BF16X3_TFLOPS}[mode]
     if mode == "f32":
         name = "bp::conv_igemm_kernel<%s, %d>" % (TILE_NAMES.get(key[0], "?"), key[1])
     else:
-        name = "bp::conv_igemm_h_kernel<%s, %d>" % (TILE_NAMES.get(key[0], "?"), 1 if mode == "f16" else 3)
+        name = "bp::%s<%s, %d>" % (family, TILE_NAMES.get(key[0], "?"), 1 if mode == "f16" else 3)
     extra = {}
     if mode == "bf16x3":
-        # six bf16 partial products per algorithmic multiply: the matrix cores execute 6x the algorithmic FLOPs
-        extra = {"mfma_flops_per_algorithmic_flop": 6, "frac_of_executed_mfma_flops": round(6 * achieved / peak, 4)}
+        # six bf16 partial products per algorithmic multiply: the matrix cores execute 6x the algorithmic FLOPs;
+        # "peak" is the algorithmic roof 2500 / 6 TFLOP/s
+        extra = {"mfma_flops_per_algorithmic_flop": 6, "peak_executed_mfma": PEAK_F16_MFMA_TFLOPS}
     return {
-        "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-        "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+        "bound": "mfma", "peak": round(peak, 1), "unit": "TFLOP/s",
+        "traffic": traffic, "traffic_source": traffic_src,
         "algorithmic_bytes_per_launch": g["bytes"] / g["launches"],
-        "kernel": name,
-        "launches_per_step": g["launches"], "avg_launch_us": round(g["ms"] / g["launches"] * 1e3, 2),
-        "flops_per_launch": g["flops"] / g["launches"],
-        "all_conv": {"achieved": round(conv_flops / (conv_ms * 1e-3) / 1e12, 2), "ms_per_step": round(conv_ms, 4),
-                     "gflop_per_step": round(conv_flops / 1e9, 2)},
-        "device_ms_per_step_eager_sum": round(total_ms, 4), **extra,
+        "kernel": name, "launches_per_step": g["launches"], "flops_per_launch": g["flops"] / g["launches"],
+        # the dominant kernel ALONE (eager pass, hipExtLaunchKernelGGL start/stop events around every launch): its
+        # launches never overlap here, so launches x duration exceeds ms_per_step of the multi-stream timed region
+        "isolated": {"avg_launch_us": round(g["ms"] / g["launches"] * 1e3, 2), "achieved": round(achieved, 2),
+                     "frac": round(achieved / peak, 4),
+                     "all_conv": {"achieved": round(conv_flops / (conv_ms * 1e-3) / 1e12, 2), "ms_per_step": round(conv_ms, 4)},
+                     "device_ms_per_step_eager_sum": round(total_ms, 4)},
+        "gflop_per_step": round(conv_flops / 1e9, 2), **extra,
     }
 
 
@@ -257,7 +265,11 @@ def main():
     if rank == 0:
         ys = synth.synth_yolo_stream(1, blocks)
         ks = fastpose_stream_from_state_dict(synth.synth_fastpose_state_dict(2))
+    t_bc = time.perf_counter()
     ys, ks = bpd.broadcast_stream(ys), bpd.broadcast_stream(ks)
+    if world > 1:
+        torch.cuda.synchronize()
+    t_bc = (time.perf_counter() - t_bc) * 1e3
     det = Darknet("yolo/cfg/yolov3-single.cfg", reso=416, max_batch=a.batch, device=local)
     det.load_stream(ys)
     pose = FastPoseHIP.from_stream(ks, n_classes=50, max_batch=a.batch, device=local)
@@ -292,25 +304,33 @@ def main():
     kp3d, cam_K = synth.synth_kp3d(50), synth.CAM_K
 
     # ---- inputs resident in HBM: a pool of distinct frames per rank
-    pool = [torch.from_numpy(np.stack(synth.synth_frames(a.batch, 1234 + 1000 * rank + 37 * j))).to(dev)
-            for j in range(a.pool)]
+    pool_host = [torch.from_numpy(np.stack(synth.synth_frames(a.batch, 1234 + 1000 * rank + 37 * j))).pin_memory()
+                 for j in range(a.pool)]
+    pool = [f.to(dev) for f in pool_host]
     NS = 2 * S
     pinned = [torch.empty((a.batch, pipe.results.shape[1]), dtype=torch.float32).pin_memory() for _ in range(NS)]
     events = [torch.cuda.Event() for _ in range(NS)]
     records = np.zeros((a.steps, a.batch, pipe.results.shape[1]), np.float32)
     stats = {"det": 0, "pose": 0}
+    t_issue = np.zeros(max(a.steps, 1))
+    lat = {"on": False, "ms": []}
+    src = {"pool": pool}           # frames resident in HBM (the headline) or pinned host memory (h2d_inclusive)
     torch.cuda.synchronize()
 
     def issue(i):
         k = i % S
+        if lat["on"]:
+            t_issue[i] = time.perf_counter()
         with torch.cuda.stream(streams[k]):
-            pipes[k].frames.copy_(pool[i % a.pool], non_blocking=True)
+            pipes[k].frames.copy_(src["pool"][i % a.pool], non_blocking=True)
             pipes[k].enqueue(streams[k].cuda_stream)
             pinned[i % NS].copy_(pipes[k].results, non_blocking=True)
             events[i % NS].record(streams[k])
 
     def finish(i, keep):
         events[i % NS].synchronize()
+        if lat["on"]:
+            lat["ms"].append((time.perf_counter() - t_issue[i]) * 1e3)     # frame handed over -> record on the host
         rec = pinned[i % NS].numpy()
         for b in range(a.batch):
             out = finish_record(rec[b], "%06d.png" % (i * a.batch + b), kp3d, cam_K)
@@ -320,20 +340,24 @@ def main():
         if keep:
             records[i] = rec
 
-    def run(nsteps, keep):
+    def run(nsteps, keep, depth=None):
+        d = S if depth is None else depth          # frames left in flight behind the one just issued (0: one at a time)
         for i in range(nsteps):
             issue(i)
-            if i >= S:
-                finish(i - S, keep)
-        for i in range(max(0, nsteps - S), nsteps):
+            if i >= d:
+                finish(i - d, keep)
+        for i in range(max(0, nsteps - d), nsteps):
             finish(i, keep)
 
     run(max(a.warmup, 1), False)
     torch.cuda.synchronize()
     bpd.barrier()
     torch.cuda.synchronize()
+    lat["on"] = True
     t0 = time.perf_counter()
     run(a.steps, True)
+    t_own = time.perf_counter() - t0
+    lat["on"] = False
     # xGMI gather of detections only: steps*batch records of 316 floats per rank, in global frame order on rank 0
     flat = records.reshape(-1, records.shape[-1])
     gathered = bpd.gather_records(flat, [rank + world * j for j in range(len(flat))], world * len(flat))
@@ -341,6 +365,38 @@ def main():
     bpd.barrier()
     torch.cuda.synchronize()
     el = bpd.max_over_ranks(time.perf_counter() - t0)
+    lat_flight = np.array(lat["ms"]) if lat["ms"] else np.zeros(1)
+    rank_fps = bpd.gather_floats(a.steps * a.batch / t_own)
+
+    # ---- side measurements on the same pipelines (never `value`): strictly one frame at a time, and the same
+    # multi-frame run with every frame uploaded from pinned host memory inside the timed region
+    side = {}
+    if world == 1 and not a.no_side_runs:
+        n1 = min(a.steps, 100)
+        run(4, False, depth=0)
+        torch.cuda.synchronize()
+        lat["ms"], lat["on"] = [], True
+        t1 = time.perf_counter()
+        run(n1, False, depth=0)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter() - t1
+        lat["on"] = False
+        one = np.array(lat["ms"])
+        side["single"] = {"p50": round(float(np.percentile(one, 50)), 4), "p95": round(float(np.percentile(one, 95)), 4),
+                          "frames_per_sec": round(n1 * a.batch / t1, 2)}
+        src["pool"] = pool_host
+        n2 = min(a.steps, 200)
+        run(2 * S, False)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        run(n2, False)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter() - t2
+        src["pool"] = pool
+        side["h2d"] = {"value": round(n2 * a.batch / t2, 2), "unit": "frames/sec", "steps": n2,
+                       "ms_per_step": round(t2 / n2 * 1e3, 4),
+                       "note": "every step uploads its %d-byte frame from pinned host memory (hipMemcpyAsync on the "
+                               "frame's stream) inside the timed region" % (a.batch * 480 * 640 * 3)}
 
     out = None
     if rank == 0:
@@ -361,6 +417,10 @@ def main():
                        "parallelism": "frames sharded by image, 1 process per GPU (dp%d)" % world,
                        "hip_graph": not a.no_graph, "fixed_box": a.fixed_box, "frames_in_flight": S, "cu_partition": a.partition,
                        "graph_nodes": pipe.kernel_count()},
+            "latency_ms": {"frames_in_flight": S, "p50": round(float(np.percentile(lat_flight, 50)), 4),
+                           "p95": round(float(np.percentile(lat_flight, 95)), 4),
+                           "definition": "frame handed to the stream -> its record (post-processing input) on the host",
+                           **({"one_frame_at_a_time": side["single"]} if "single" in side else {})},
             "detections": stats["det"], "poses": stats["pose"],
             "records_gathered": int((gathered[:, 0].view(np.int32) >= -1).sum()) if gathered is not None else 0,
         }
@@ -369,14 +429,25 @@ def main():
         for _ in range(200):
             finish_record(records[0, 0], "x.png", kp3d, cam_K)
         out["host_post_ms_per_frame"] = round((time.perf_counter() - t1) / 200 * 1e3, 4)
+        if "h2d" in side:
+            out["h2d_inclusive"] = side["h2d"]
+        if world > 1:
+            import torch.distributed as tdist
+            out["rccl"] = {"backend": tdist.get_backend(), "ranks": world, "weight_broadcast_ms": round(t_bc, 1),
+                           "per_rank_frames_per_sec": [round(v, 2) for v in rank_fps],
+                           "collectives": "broadcast of 2 fp32 weight streams (246 + 239 MB) at start-up, all_gather of "
+                                          "316-float records, barriers around the timed region"}
     if rank == 0 and not a.no_roofline:
-        out["roofline"] = roofline(det, pose, a.batch)
-        # the same FLOPs over the wall clock of the timed region (all frames in flight, all GPUs): what the chip
-        # sustains on the whole path, as opposed to one kernel running alone
-        gf = out["roofline"]["all_conv"]["gflop_per_step"]
-        agg = gf * a.steps * world / el / 1e3 / world
-        out["roofline"]["timed_region"] = {"achieved_per_gpu": round(agg, 2), "frac": round(agg / out["roofline"]["peak"], 4),
-                                           "unit": "TFLOP/s"}
+        rf = roofline(det, pose, a.batch)
+        # IN-SITU figure = the convolution FLOPs of the timed steps over the wall clock of the timed region (all frames
+        # in flight, per GPU): kernel time per step <= ms_per_step holds by construction
+        agg = rf["gflop_per_step"] * a.steps / el / 1e3
+        out["roofline"] = {"bound": rf["bound"], "achieved": round(agg, 2), "peak": rf["peak"], "unit": rf["unit"],
+                           "frac": round(agg / rf["peak"], 4), "traffic": rf["traffic"],
+                           "definition": "algorithmic conv FLOPs of the timed steps / wall clock of the timed region, per GPU",
+                           **{k: v for k, v in rf.items() if k not in ("bound", "peak", "unit", "traffic")}}
+        if a.precision == "bf16x3":
+            out["roofline"]["frac_of_executed_mfma"] = round(6 * agg / PEAK_F16_MFMA_TFLOPS, 4)
     if rank == 0 and world == 1 and a.other_modes:
         # the opt-in precisions on the same workload, for the record: 4 frames in flight, same
         # graph pipeline (re-captured on the precision change), a short timed run each

@@ -91,6 +91,19 @@ def max_over_ranks(x: float) -> float:
     return float(t[0])
 
 
+def gather_floats(x: float) -> List[float]:
+    """Every rank's value, in rank order (per-rank throughput lines of the bench)."""
+    import torch
+    dist = _dist()
+    if not is_dist() or dist.get_world_size() == 1:
+        return [float(x)]
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([x], dtype=torch.float64, device=dev)
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(v[0]) for v in out]
+
+
 def finalize() -> None:
     if is_dist():
         _dist().barrier()

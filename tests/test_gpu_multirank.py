@@ -24,8 +24,8 @@ def _port():
     return p
 
 
-def _launch(nproc, script_args, timeout=900):
-    env = dict(os.environ, BP_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+def _launch(nproc, script_args, timeout=900, backend="gloo"):
+    env = dict(os.environ, BP_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
            "--master-addr", "127.0.0.1", "--master-port", str(_port())] + script_args
     return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
@@ -41,6 +41,24 @@ def test_bench_two_ranks(cuda):
     assert out["config"]["global_batch"] == 2 and out["value"] > 0
     assert out["records_gathered"] == 48 and out["detections"] == 24     # rank 0's own frames all detected
     assert abs(out["value"] - 2 * 24 / (out["ms_per_step"] * 24 / 1e3)) / out["value"] < 1e-3
+    assert out["rccl"]["ranks"] == 2 and out["rccl"]["backend"] == "gloo" and len(out["rccl"]["per_rank_frames_per_sec"]) == 2
+    assert out["rccl"]["weight_broadcast_ms"] > 0 and 0 < out["latency_ms"]["p50"] <= out["latency_ms"]["p95"]
+
+
+def test_bench_two_ranks_rccl(cuda):
+    """First contact with a multi-GPU node: the SAME command the driver's scaling run issues, collectives over RCCL
+    (backend nccl, one rank per GPU).  Skips on a one-GPU box -- there the gloo test above covers everything but the
+    transport."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (the 1-GPU test box runs the gloo variant)")
+    r = _launch(2, ["bench.py", "--gpus", "2", "--steps", "24", "--warmup", "4", "--no-cpu-baseline", "--no-roofline"],
+                backend="nccl")
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["n_gpus"] == 2 and out["rccl"]["backend"] == "nccl" and out["records_gathered"] == 48
+    r = _launch(2, ["evaluate.py", "--synthetic", "7", "--outdir", "/tmp/bp_rccl_eval", "--fused"], backend="nccl")
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
 
 
 def test_evaluate_fused_two_ranks_equals_one(tmp_path, cuda):
