@@ -299,7 +299,7 @@ void launch_yolo_decode(const YoloHead* heads, int nheads, int N, int reso, int 
 // write_results with nms=False (yolo/util.py:118-223): per image the arg-max objectness row (first on
 // ties) among rows with obj > conf whose arg-max class is 0.  One block per image.
 __global__ __launch_bounds__(1024) void yolo_select_kernel(const float* __restrict__ pred, int rows, int attrs,
-                                                            float conf, int num_classes, float* __restrict__ sel) {
+                                                            float conf, int num_classes, float* __restrict__ sel, int sel_ld) {
     __shared__ float sv[16];
     __shared__ int si[16];
     const int n = blockIdx.x;
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(1024) void yolo_select_kernel(const float* __restri
     if (threadIdx.x == 0) {
         for (int k = 1; k < (int)(blockDim.x >> 6); ++k)
             if (sv[k] > best || (sv[k] == best && si[k] < bi)) { best = sv[k]; bi = si[k]; }
-        float* o = sel + (long long)n * 8;
+        float* o = sel + (long long)n * sel_ld;
         if (best < 0.f) {
             o[0] = __int_as_float(-1);
             for (int k = 1; k < 8; ++k) o[k] = 0.f;
@@ -348,13 +348,13 @@ __global__ __launch_bounds__(1024) void yolo_select_kernel(const float* __restri
     }
 }
 void launch_yolo_select(const float* pred, int N, int rows, int attrs, float conf, int num_classes, float* sel,
-                        hipStream_t s) {
-    hipLaunchKernelGGL(yolo_select_kernel, dim3(N), dim3(1024), 0, s, pred, rows, attrs, conf, num_classes, sel);
+                        hipStream_t s, int sel_ld) {
+    hipLaunchKernelGGL(yolo_select_kernel, dim3(N), dim3(1024), 0, s, pred, rows, attrs, conf, num_classes, sel, sel_ld);
 }
 
 // ---------------------------------------------------------------- heat-map arg-max (+4 neighbours), eval.py:113-147
 __global__ __launch_bounds__(256) void heatmap_argmax_kernel(const float* __restrict__ hm, int H, int W,
-                                                              float* __restrict__ out) {
+                                                              float* __restrict__ out, int C, int out_ld) {
     __shared__ float sv[4];
     __shared__ int si[4];
     const int HW = H * W;
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256) void heatmap_argmax_kernel(const float* __rest
         for (int k = 1; k < 4; ++k)
             if (sv[k] > best || (sv[k] == best && si[k] < bi)) { best = sv[k]; bi = si[k]; }
         if (bi < 0 || bi >= HW) { bi = 0; best = P[0]; }   // no element compared greater (all -inf / NaN): stay in bounds
-        float* o = out + (long long)blockIdx.x * 6;
+        float* o = out + (long long)(blockIdx.x / C) * out_ld + (blockIdx.x % C) * 6;
         const int x = bi % W, y = bi / W;
         o[0] = __int_as_float(bi);
         o[1] = best;
@@ -387,8 +387,8 @@ __global__ __launch_bounds__(256) void heatmap_argmax_kernel(const float* __rest
         o[5] = inner ? P[bi + W] : 0.f;
     }
 }
-void launch_heatmap_argmax(const float* hm, int N, int C, int H, int W, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(heatmap_argmax_kernel, dim3(N * C), dim3(256), 0, s, hm, H, W, out);
+void launch_heatmap_argmax(const float* hm, int N, int C, int H, int W, float* out, hipStream_t s, int out_ld) {
+    hipLaunchKernelGGL(heatmap_argmax_kernel, dim3(N * C), dim3(256), 0, s, hm, H, W, out, C, out_ld > 0 ? out_ld : C * 6);
 }
 
 // ---------------------------------------------------------------- crop (dataloader.py:794-835, img.py:242-262)
@@ -440,14 +440,15 @@ __device__ __forceinline__ float crop_tap(const uint8_t* __restrict__ frame, int
 __global__ __launch_bounds__(256) void crop_kernel(const uint8_t* __restrict__ frame, int H, int W,
                                                     const float* __restrict__ sel, int reso,
                                                     const float* __restrict__ box_override, float* __restrict__ out_nhwc,
-                                                    float* __restrict__ out_nchw, float* __restrict__ pts, int oh, int ow) {
+                                                    float* __restrict__ out_nchw, float* __restrict__ pts, int oh, int ow,
+                                                    int sel_ld, int pts_ld) {
     const int img = blockIdx.y;
     frame += (long long)img * H * W * 3;
-    if (sel) sel += img * 8;
+    if (sel) sel += (long long)img * sel_ld;
     if (box_override) box_override += img * 4;
     if (out_nhwc) out_nhwc += (long long)img * oh * ow * 3;
     if (out_nchw) out_nchw += (long long)img * oh * ow * 3;
-    if (pts) pts += img * 8;
+    if (pts) pts += (long long)img * pts_ld;
     float x1, y1, x2, y2;
     if (box_override) {
         x1 = box_override[0]; y1 = box_override[1]; x2 = box_override[2]; y2 = box_override[3];
@@ -482,26 +483,9 @@ __global__ __launch_bounds__(256) void crop_kernel(const uint8_t* __restrict__ f
     }
 }
 void launch_crop(const uint8_t* frames, int batch, int H, int W, const float* sel, int reso, const float* boxes,
-                 float* out_nhwc, float* out_nchw, float* pts, int oh, int ow, hipStream_t s) {
+                 float* out_nhwc, float* out_nchw, float* pts, int oh, int ow, hipStream_t s, int sel_ld, int pts_ld) {
     hipLaunchKernelGGL(crop_kernel, dim3(grid_for((long long)oh * ow, 256, 1024), batch), dim3(256), 0, s, frames, H, W,
-                       sel, reso, boxes, out_nhwc, out_nchw, pts, oh, ow);
-}
-
-// ---------------------------------------------------------------- per-frame result record (one launch instead of 3 copies)
-__global__ void pack_records_kernel(const float* __restrict__ sel, const float* __restrict__ pts,
-                                    const float* __restrict__ kp, float* __restrict__ out, int kp_floats, int rec_floats) {
-    const int b = blockIdx.x;
-    for (int i = threadIdx.x; i < rec_floats; i += blockDim.x) {
-        float v;
-        if (i < 8) v = sel[b * 8 + i];
-        else if (i < 16) v = pts[b * 8 + i - 8];
-        else v = kp[(long long)b * kp_floats + i - 16];
-        out[(long long)b * rec_floats + i] = v;
-    }
-}
-void launch_pack_records(const float* sel, const float* pts, const float* kp, float* out, int batch, int kp_floats,
-                         int rec_floats, hipStream_t s) {
-    hipLaunchKernelGGL(pack_records_kernel, dim3(batch), dim3(128), 0, s, sel, pts, kp, out, kp_floats, rec_floats);
+                       sel, reso, boxes, out_nhwc, out_nchw, pts, oh, ow, sel_ld, pts_ld);
 }
 
 // ---------------------------------------------------------------- Pillow-exact bicubic resize (u8, two passes)

@@ -117,23 +117,22 @@ struct YoloHead {
 // (idx as int bits, x1,y1,x2,y2,obj,cls_conf,cls_idx); idx = -1 when nothing > conf
 void launch_yolo_decode(const YoloHead* heads, int nheads, int N, int reso, int attrs, int rows,
                         float* pred, hipStream_t s);
+// sel_ld: floats between consecutive images' records (8 dense; the fused pipeline writes straight into its result rows)
 void launch_yolo_select(const float* pred, int N, int rows, int attrs, float conf, int num_classes,
-                        float* sel, hipStream_t s);
+                        float* sel, hipStream_t s, int sel_ld = 8);
 // hm NCHW [N][C][H*W] -> out [N][C][6] = (idx as int bits, max, left, right, up, down)
-void launch_heatmap_argmax(const float* hm, int N, int C, int H, int W, float* out, hipStream_t s);
+// out_ld: floats between consecutive images' [C][6] blocks (0 = dense C*6)
+void launch_heatmap_argmax(const float* hm, int N, int C, int H, int W, float* out, hipStream_t s, int out_ld = 0);
 
-// [batch][rec_floats] rows = sel[8] | pts[8] | kp[kp_floats]
 void launch_f32_to_f16(const float* in, unsigned short* out, long long n, hipStream_t s);
 void launch_f32_to_bf16x3(const float* in, unsigned short* out_planes, long long n, hipStream_t s);
 void launch_probe_placement(int* d_out, int blocks, hipStream_t s);
-void launch_pack_records(const float* sel, const float* pts, const float* kp, float* out, int batch, int kp_floats,
-                         int rec_floats, hipStream_t s);
 
 // crop stage (dataloader.py:794-835 + img.py:242-262) on device.
 //  frames: BGR u8 [batch][H][W][3]; sel: [batch][8] select records (box in YOLO-input pixels) or boxes [batch][4];
 //  out_nhwc [oh][ow][3] (engine input) and/or out_nchw [3][oh][ow]; pts: (ul.x, ul.y, br.x, br.y)
 void launch_crop(const uint8_t* frames, int batch, int H, int W, const float* sel, int reso, const float* boxes,
-                 float* out_nhwc, float* out_nchw, float* pts, int oh, int ow, hipStream_t s);
+                 float* out_nhwc, float* out_nchw, float* pts, int oh, int ow, hipStream_t s, int sel_ld = 8, int pts_ld = 8);
 
 // Pillow-exact antialiased bicubic resize of a u8 HWC frame (two passes, 22-bit fixed point);
 // coefficient tables are built on the host (engine.cpp).

@@ -53,10 +53,7 @@ struct bp_pipeline {
     bp::Arena arena;
     uint8_t* frames = nullptr;
     uint8_t* tmp = nullptr;
-    float* results = nullptr;    // [batch][316]
-    float* sel = nullptr;        // [batch][8]
-    float* pts = nullptr;        // [batch][8]
-    float* kp = nullptr;         // [batch][50][6]
+    float* results = nullptr;    // [batch][316] = sel[8] | pts[8] | kp[50][6], each written by its producer
     float* hm = nullptr;
     float* fixed_box = nullptr;  // [batch][4] or null
     bool use_fixed = false;
@@ -538,14 +535,14 @@ static void pipeline_enqueue(bp_pipeline* p, hipStream_t s) {
     // a1: Pillow-exact bicubic stretch to reso x reso, BGR -> RGB, /255, straight into the detector's NHWC input
     bp::launch_resize_bicubic(p->frames, p->batch, p->H, p->W, p->tmp, yn.input_nhwc(), nullptr, reso, reso, t, 1, s);
     // a3-a5: detector + decode + arg-max objectness
-    yn.forward(yn.input_nhwc(), true, p->batch, nullptr, p->conf, p->num_classes, p->sel, s);
+    // every stage writes its part of the frame's result row directly (sel[8] | pts[8] | kp[50][6]): no gather launch
+    const int R = BP_RESULT_FLOATS;
+    yn.forward(yn.input_nhwc(), true, p->batch, nullptr, p->conf, p->num_classes, p->results, s, R);
     // a6-a7: box rescale + crop window + bilinear crop into the KPD's NHWC input
-    bp::launch_crop(p->frames, p->batch, p->H, p->W, p->use_fixed ? nullptr : p->sel, reso,
-                    p->use_fixed ? p->fixed_box : nullptr, kn.input_nhwc(), nullptr, p->pts, kn.in_h(), kn.in_w(), s);
+    bp::launch_crop(p->frames, p->batch, p->H, p->W, p->use_fixed ? nullptr : p->results, reso,
+                    p->use_fixed ? p->fixed_box : nullptr, kn.input_nhwc(), nullptr, p->results + 8, kn.in_h(), kn.in_w(), s, R, R);
     // a8-a9: KPD + heat-map arg-max
-    kn.forward(kn.input_nhwc(), true, p->batch, p->hm, p->kp, s);
-    // gather the three small records into one result row per frame
-    bp::launch_pack_records(p->sel, p->pts, p->kp, p->results, p->batch, 300, BP_RESULT_FLOATS, s);
+    kn.forward(kn.input_nhwc(), true, p->batch, p->hm, p->results + 16, s, R);
     BP_HIP(hipGetLastError());
 }
 
@@ -562,9 +559,6 @@ int bp_pipeline_create(bp_yolo* y, bp_kpd* k, int frame_h, int frame_w, int batc
     p->frames = d_frames ? d_frames : (uint8_t*)p->arena.alloc_bytes((size_t)batch * frame_h * frame_w * 3);
     p->tmp = (uint8_t*)p->arena.alloc_bytes((size_t)batch * frame_h * reso * 3);
     p->results = d_results ? d_results : p->arena.alloc((size_t)batch * BP_RESULT_FLOATS);
-    p->sel = p->arena.alloc((size_t)batch * 8);
-    p->pts = p->arena.alloc((size_t)batch * 8);
-    p->kp = p->arena.alloc((size_t)batch * 300);
     p->hm = d_hm ? d_hm : p->arena.alloc((size_t)batch * 50 * k->net->out_h() * k->net->out_w());
     p->fixed_box = p->arena.alloc((size_t)batch * 4);
     const bp::ResizePlan ph = bp::make_bicubic_plan(frame_w, reso), pv = bp::make_bicubic_plan(frame_h, reso);

@@ -706,7 +706,7 @@ YoloNet::YoloNet(const std::string& cfg_text, const float* stream, size_t n_floa
 }
 
 void YoloNet::forward(const float* d_img, bool nhwc_input, int batch, float* d_pred, float conf, int num_classes,
-                      float* d_sel, hipStream_t s) {
+                      float* d_sel, hipStream_t s, int sel_ld) {
     BP_CHECK(batch >= 1 && batch <= max_batch_, "batch out of range");
     if (nhwc_input) {
         if (d_img != in_nhwc_)
@@ -719,7 +719,7 @@ void YoloNet::forward(const float* d_img, bool nhwc_input, int batch, float* d_p
     // heads hold per-image strides for max_batch_ == layout of batch b (contiguous by image), so decode as is
     float* pred = d_pred ? d_pred : pred_;
     launch_yolo_decode(heads_.data(), (int)heads_.size(), batch, reso_, attrs_, rows_, pred, s);
-    if (d_sel) launch_yolo_select(pred, batch, rows_, attrs_, conf, num_classes, d_sel, s);
+    if (d_sel) launch_yolo_select(pred, batch, rows_, attrs_, conf, num_classes, d_sel, s, sel_ld);
     BP_HIP(hipGetLastError());
 }
 
@@ -841,7 +841,7 @@ KpdNet::KpdNet(const float* stream, size_t n_floats, int n_classes, int max_batc
     finalize();
 }
 
-void KpdNet::forward(const float* d_inps, bool nhwc_input, int batch, float* d_hm, float* d_kp, hipStream_t s) {
+void KpdNet::forward(const float* d_inps, bool nhwc_input, int batch, float* d_hm, float* d_kp, hipStream_t s, int kp_ld) {
     BP_CHECK(batch >= 1 && batch <= max_batch_, "batch out of range");
     if (nhwc_input) {
         if (d_inps != in_nhwc_)
@@ -852,7 +852,7 @@ void KpdNet::forward(const float* d_inps, bool nhwc_input, int batch, float* d_h
     }
     ops_[hm_op_].conv.out = d_hm ? d_hm : hm_;
     run_ops(batch, s);
-    if (d_kp) launch_heatmap_argmax(d_hm ? d_hm : hm_, batch, outC_, out_h(), out_w(), d_kp, s);
+    if (d_kp) launch_heatmap_argmax(d_hm ? d_hm : hm_, batch, outC_, out_h(), out_w(), d_kp, s, kp_ld);
     BP_HIP(hipGetLastError());
 }
 

@@ -131,7 +131,7 @@ public:
     int reso() const { return reso_; }
     // img: NCHW f32 [B,3,reso,reso] RGB 0..1 (or NHWC when nhwc_input); pred [B,rows,attrs] (may be null when sel given)
     void forward(const float* d_img, bool nhwc_input, int batch, float* d_pred, float conf, int num_classes,
-                 float* d_sel, hipStream_t s);
+                 float* d_sel, hipStream_t s, int sel_ld = 8);
     float* input_nhwc() { return in_nhwc_; }
     float* pred_buffer() { return pred_; }
 private:
@@ -154,7 +154,7 @@ public:
     int in_h() const { return inH_; }
     int in_w() const { return inW_; }
     // inps: NCHW f32 [B,3,320,256] (or NHWC); hm NCHW [B,50,80,64] (null -> internal); kp [B,50,6] (nullable)
-    void forward(const float* d_inps, bool nhwc_input, int batch, float* d_hm, float* d_kp, hipStream_t s);
+    void forward(const float* d_inps, bool nhwc_input, int batch, float* d_hm, float* d_kp, hipStream_t s, int kp_ld = 0);
     float* input_nhwc() { return in_nhwc_; }
 private:
     size_t n_floats_ = 0;
