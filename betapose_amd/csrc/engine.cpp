@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <sstream>
 
@@ -223,6 +224,10 @@ static void choose_launch(const Op& op, int batch, int force_tile, int sk_target
         if (t == TILE_64x64 && sk_target == 512 && sk_min_chunks == 4 && sk_max == 8)   // default policy: measured table
             for (const SplitEntry& e : kSplitTable)
                 if (e.M == (int)M && e.CoutPad == c.CoutPad && e.nchunks == c.nchunks) { s = e.splits; break; }
+    }
+    {   // experiment hook (tools only): BP_SPLIT_PCT scales the slice count, e.g. 50 halves it
+        static const int pct = std::getenv("BP_SPLIT_PCT") ? std::atoi(std::getenv("BP_SPLIT_PCT")) : 100;
+        if (pct != 100 && s > 1) s = std::max(1, (s * pct + 50) / 100);
     }
     int per = (c.nchunks + s - 1) / s;
     s = (c.nchunks + per - 1) / per;

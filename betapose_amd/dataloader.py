@@ -202,10 +202,12 @@ class DataWriter:
 
     def __init__(self, cam_K, left_number, kp_model_vertices, save_video=False, savepath='examples/res/1.avi',
                  fourcc=0, fps=25, frameSize=(640, 480), queueSize=1024):
-        # same positional signature as the reference (dataloader.py:650-653); the video-writer arguments are accepted
-        # and unused
-        if save_video:
-            raise NotImplementedError("video output is outside the hot path")
+        # same positional signature as the reference (dataloader.py:650-653).  save_video: the annotated frames go to a
+        # Motion-JPEG .avi (video.MJPEGWriter stands in for cv2.VideoWriter; `fourcc` is accepted and ignored)
+        self.save_video = bool(save_video)
+        if self.save_video:
+            from .video import MJPEGWriter
+            self.stream = MJPEGWriter(savepath, fps, frameSize)
         self.stopped = False
         self.final_result = []
         self.Q = Queue(maxsize=queueSize)
@@ -245,6 +247,11 @@ class DataWriter:
                 else:
                     result.update({'cam_R': [], 'cam_t': []})
                 self.final_result.append(result)
+                if self.save_video:
+                    from .video import vis_frame
+                    self.stream.write(vis_frame(orig_img, result))
+            elif self.save_video and orig_img is not None:
+                self.stream.write(np.asarray(orig_img))
             self._busy = False
 
     def running(self):
@@ -259,6 +266,8 @@ class DataWriter:
     def stop(self):
         self.stopped = True
         time.sleep(0.01)
+        if self.save_video:
+            self.stream.release()
 
     def results(self):
         return self.final_result
