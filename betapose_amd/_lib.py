@@ -81,6 +81,8 @@ PROTOTYPES = {
     "bp_darknet_classes": (C.c_int, [vp]),
     "bp_darknet_detect_rgb": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, C.c_float, vp, C.c_int]),
     "bp_darknet_detect_png": (C.c_int, [vp, vp, C.c_size_t, C.c_float, C.c_float, vp, C.c_int]),
+    "bp_darknet_detect_image": (C.c_int, [vp, vp, C.c_size_t, C.c_float, C.c_float, vp, C.c_int]),
+    "bp_image_decode_rgb": (C.c_int, [vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "bp_darknet_detect_file": (C.c_int, [vp, C.c_char_p, C.c_float, C.c_float, vp, C.c_int]),
     "bp_yolo_create_darknet": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
     "bp_stream_create_masked": (C.c_int, [vp, C.c_int, C.POINTER(vp)]),

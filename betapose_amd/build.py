@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbetapose_hip.so")
-SOURCES = ["conv_igemm.hip", "conv_w64.hip", "aux_kernels.hip", "engine.cpp", "host_post.cpp", "frame_io.cpp", "c_api.cpp", "darknet_compat.cpp"]
+SOURCES = ["conv_igemm.hip", "conv_w64.hip", "aux_kernels.hip", "engine.cpp", "host_post.cpp", "frame_io.cpp", "jpeg_bmp.cpp", "c_api.cpp", "darknet_compat.cpp"]
 HEADERS = ["bp_common.h", "engine.h", "frame_io.h", "conv_tail.inc", "conv_dev.h", os.path.join("..", "..", "include", "betapose_hip.h"),
            os.path.join("..", "..", "include", "yolo_v2_class_compat.h")]
 ARCH = "gfx950"

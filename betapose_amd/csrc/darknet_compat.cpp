@@ -8,7 +8,8 @@
 // layer, cell-major / anchor-minor candidates with objectness > thresh, prob = objectness*class (0 when <= thresh),
 // boxes relative to the image (yolo_layer.c:84-92,365-392) -> per-class sort + IoU suppression, nms 0.4
 // (box.c:331-363) -> bbox_t in image pixels.
-// Image decoding: PNG only (csrc/frame_io.cpp); the reference decodes JPEG/PNG/BMP through stb / OpenCV.
+// Image decoding: PNG (csrc/frame_io.cpp), baseline JPEG and uncompressed BMP (csrc/jpeg_bmp.cpp, stb_image's pixel
+// arithmetic restated and pinned against the reference's compiled load_image_color).
 #include "../../include/betapose_hip.h"
 #include "../../include/yolo_v2_class_compat.h"
 
@@ -252,18 +253,53 @@ int bp_darknet_detect_rgb(bp_darknet* d, const float* planar_rgb, int w, int h, 
     DK_CATCH
 }
 
-int bp_darknet_detect_png(bp_darknet* d, const unsigned char* png, size_t n, float thresh, float nms, bp_bbox* out, int cap) {
+// encoded image (PNG, baseline JPEG, uncompressed BMP: sniffed from the first bytes) -> interleaved RGB u8
+static void decode_image_rgb(const unsigned char* data, size_t n, std::vector<uint8_t>& rgb, int* h, int* w) {
+    if (n >= 8 && std::memcmp(data, "\x89PNG\r\n\x1a\n", 8) == 0) {
+        bp::png_info(data, n, h, w, nullptr);
+        std::vector<uint8_t> bgr((size_t)*h * *w * 3), scratch;
+        bp::png_decode_bgr(data, n, bgr.data(), bgr.size(), h, w, scratch);
+        rgb.resize(bgr.size());
+        for (size_t i = 0; i + 2 < bgr.size(); i += 3) { rgb[i] = bgr[i + 2]; rgb[i + 1] = bgr[i + 1]; rgb[i + 2] = bgr[i]; }
+    } else if (n >= 3 && data[0] == 0xFF && data[1] == 0xD8) {
+        bp::jpeg_decode_rgb(data, n, rgb, h, w);
+    } else if (n >= 2 && data[0] == 'B' && data[1] == 'M') {
+        bp::bmp_decode_rgb(data, n, rgb, h, w);
+    } else {
+        throw std::runtime_error("unsupported image format (PNG, baseline JPEG and uncompressed BMP are decoded)");
+    }
+}
+
+int bp_darknet_detect_image(bp_darknet* d, const unsigned char* data, size_t n, float thresh, float nms, bp_bbox* out, int cap) {
     DK_TRY
-    if (!d || !png) throw std::runtime_error("null argument");
+    if (!d || !data) throw std::runtime_error("null argument");
     int h = 0, w = 0;
-    bp::png_info(png, n, &h, &w, nullptr);
-    std::vector<uint8_t> bgr((size_t)h * w * 3), scratch;
-    bp::png_decode_bgr(png, n, bgr.data(), bgr.size(), &h, &w, scratch);
+    std::vector<uint8_t> rgb;
+    decode_image_rgb(data, n, rgb, &h, &w);
     std::vector<float> im((size_t)3 * h * w);                      // image.c load_image_stb: planar R,G,B / 255
     for (int y = 0; y < h; ++y)
         for (int x = 0; x < w; ++x)
-            for (int k = 0; k < 3; ++k) im[((size_t)k * h + y) * w + x] = (float)(bgr[((size_t)y * w + x) * 3 + (2 - k)] / 255.);
+            for (int k = 0; k < 3; ++k) im[((size_t)k * h + y) * w + x] = (float)(rgb[((size_t)y * w + x) * 3 + k] / 255.);
     return bp_darknet_detect_rgb(d, im.data(), w, h, thresh, nms, out, cap);
+    DK_CATCH
+}
+
+int bp_darknet_detect_png(bp_darknet* d, const unsigned char* png, size_t n, float thresh, float nms, bp_bbox* out, int cap) {
+    return bp_darknet_detect_image(d, png, n, thresh, nms, out, cap);      // kept name: any supported format
+}
+
+// decoded pixels of an encoded image, interleaved RGB u8 (test / tool hook for the decoders above): *h, *w receive the
+// size; out may be null to query it
+int bp_image_decode_rgb(const unsigned char* data, size_t n, unsigned char* out, size_t cap, int* h, int* w) {
+    DK_TRY
+    if (!data || !h || !w) throw std::runtime_error("null argument");
+    std::vector<uint8_t> rgb;
+    decode_image_rgb(data, n, rgb, h, w);
+    if (out) {
+        if (cap < rgb.size()) throw std::runtime_error("output buffer too small");
+        std::memcpy(out, rgb.data(), rgb.size());
+    }
+    return 0;
     DK_CATCH
 }
 
@@ -271,7 +307,7 @@ int bp_darknet_detect_file(bp_darknet* d, const char* path, float thresh, float 
     DK_TRY
     if (!path) throw std::runtime_error("null argument");
     const std::vector<uint8_t> file = bp::read_file(path);
-    return bp_darknet_detect_png(d, file.data(), file.size(), thresh, nms, out, cap);
+    return bp_darknet_detect_image(d, file.data(), file.size(), thresh, nms, out, cap);
     DK_CATCH
 }
 
@@ -311,7 +347,7 @@ extern "C" int detect_mat(const uint8_t* data, const size_t data_length, bbox_t_
     std::lock_guard<std::mutex> lk(g_detector_mutex);
     if (!g_detector) { g_cerr = "init() has not been called"; return -1; }
     std::vector<bp_bbox> v(C_SHARP_MAX_OBJECTS);
-    const int n = bp_darknet_detect_png(g_detector.get(), data, data_length, kThresh, kNms, v.data(), (int)v.size());
+    const int n = bp_darknet_detect_image(g_detector.get(), data, data_length, kThresh, kNms, v.data(), (int)v.size());
     return n < 0 ? n : to_container(n, v, container);
 }
 

@@ -53,4 +53,8 @@ private:
     bool stop_ = false;
 };
 
+// csrc/jpeg_bmp.cpp: baseline JPEG / uncompressed BMP -> interleaved RGB u8 (throws std::runtime_error)
+void jpeg_decode_rgb(const uint8_t* data, size_t n, std::vector<uint8_t>& rgb, int* h, int* w);
+void bmp_decode_rgb(const uint8_t* data, size_t n, std::vector<uint8_t>& rgb, int* h, int* w);
+
 }  // namespace bp

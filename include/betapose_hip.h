@@ -199,6 +199,11 @@ int bp_darknet_classes(const bp_darknet* d);
  * written to out), < 0 on error. */
 int bp_darknet_detect_rgb(bp_darknet* d, const float* planar_rgb, int w, int h, float thresh, float nms, bp_bbox* out,
                           int cap);
+/* encoded image in memory: PNG, baseline JPEG or uncompressed BMP (what load_image / stb_image hands the reference's
+ * Detector, image.c:1820-1875); bp_darknet_detect_png is the older name of the same entry point */
+int bp_darknet_detect_image(bp_darknet* d, const unsigned char* data, size_t n, float thresh, float nms, bp_bbox* out,
+                            int cap);
+int bp_image_decode_rgb(const unsigned char* data, size_t n, unsigned char* out_rgb, size_t cap, int* h, int* w);
 int bp_darknet_detect_png(bp_darknet* d, const unsigned char* png, size_t n, float thresh, float nms, bp_bbox* out,
                           int cap);
 int bp_darknet_detect_file(bp_darknet* d, const char* png_path, float thresh, float nms, bp_bbox* out, int cap);

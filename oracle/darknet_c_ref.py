@@ -39,6 +39,19 @@ def available() -> bool:
     return os.path.exists(LIB)
 
 
+def load_image_color(path: str) -> np.ndarray:
+    """The reference's image loader on its own: ``load_image_color`` (image.c:1877 -> load_image_stb :1820 -> the
+    vendored stb_image v2.16): planar RGB float32 [3,h,w] / 255.  Needs no network."""
+    L = C.CDLL(LIB)
+    L.load_image_color.restype = _Image
+    L.load_image_color.argtypes = [C.c_char_p, C.c_int, C.c_int]
+    L.free_image.argtypes = [_Image]
+    im = L.load_image_color(path.encode(), 0, 0)
+    arr = np.ctypeslib.as_array(im.data, shape=(im.c, im.h, im.w)).copy()
+    L.free_image(im)
+    return arr
+
+
 class DarknetC:
     def __init__(self, cfg_text_without_net: str, weights_path: str, reso: int = 416):
         self.lib = C.CDLL(LIB)

@@ -72,6 +72,14 @@ def test_detect_matches_reference_darknet_c(cuda, files):
             got_file = det.detect_file(path, thresh, nms, cap=20000)       # own PNG decode + /255
             _match(got_file, want, ordered=nms > 0)
         assert len(ref.detect(im, 0.02, 0.0)) > len(ref.detect(im, 0.02, 0.4)) > 0   # the NMS actually prunes here
+    # JPEG and BMP files: the detector's own decoders (csrc/jpeg_bmp.cpp) against the reference's stb loader + Darknet-C
+    from PIL import Image
+    import os
+    for ext, kw in ((".jpg", {"quality": 85, "subsampling": 2}), (".jpg", {"quality": 92, "subsampling": 0}), (".bmp", {})):
+        path = os.path.splitext(pngs[0])[0] + "_x" + str(kw.get("subsampling", 9)) + ext
+        Image.open(pngs[0]).convert("RGB").save(path, **kw)
+        im = ref.load_image(path)
+        _match(det.detect_file(path, 0.05, 0.4, cap=20000), ref.detect(im, 0.05, 0.4))
     # network-sized input: no resize branch (yolo_v2_class.cpp:263-266)
     small = np.ascontiguousarray(ref.load_image(pngs[0])[:, :416, :416])
     _match(det.detect(small, 0.05, 0.4, cap=20000), ref.detect(small, 0.05, 0.4))
