@@ -1,45 +1,45 @@
 #!/bin/bash
 # Regenerates everything under profiles/ for one round on an MI355X box (writes into gpurun_out/, copy what you keep).
-#   tools/reproduce_profiles.sh [round tag, default r01]
+#   tools/reproduce_profiles.sh [round tag, default r02]
 # Each block is independent; PMC passes are separate rocprofv3 runs with --kernel-trace only.
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 REPO="$(cd "$(dirname "$0")/.." && pwd)"
 OUT=$REPO/gpurun_out
 mkdir -p "$OUT"
-cd /tmp && export TMPDIR=/tmp
-
-# 1. headline bench line (+ other_precisions, roofline, cpu_baseline) and the opt-in modes on their own
-python $REPO/bench.py                                   > $OUT/${TAG}_bench_default.json   2>/dev/null
-python $REPO/bench.py --precision f16    --no-cpu-baseline --other-modes "" > $OUT/${TAG}_bench_f16.json    2>/dev/null
-python $REPO/bench.py --precision bf16x3 --no-cpu-baseline --other-modes "" > $OUT/${TAG}_bench_bf16x3.json 2>/dev/null
-
-# 2. rocprofv3 kernel statistics of the same command (kernels are serialised under the profiler: compare AverageNs of
-#    the conv kernel with roofline.avg_launch_us, not the frames/s)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof32 -o p -- \
-    python $REPO/bench.py --steps 200 --warmup 20 --no-cpu-baseline --other-modes "" > $OUT/${TAG}_bench_under_rocprof.json 2>/dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof16 -o p -- \
-    python $REPO/bench.py --steps 200 --warmup 20 --no-cpu-baseline --other-modes "" --precision f16 > $OUT/${TAG}_bench_f16_under_rocprof.json 2>/dev/null
-cp $OUT/prof32/p_kernel_stats.csv $OUT/${TAG}_bench_kernel_stats.csv
-cp $OUT/prof32/p_domain_stats.csv $OUT/${TAG}_bench_domain_stats.csv
-cp $OUT/prof16/p_kernel_stats.csv $OUT/${TAG}_bench_f16_kernel_stats.csv
-
-# 3. HBM-side traffic of the conv kernels (FETCH_SIZE / WRITE_SIZE, two passes each)
 cd $REPO
-tools/pmc_traffic.sh                 && cp $OUT/pmc_traffic.json $OUT/${TAG}_pmc_traffic.json
-tools/pmc_traffic.sh --precision f16 && cp $OUT/pmc_traffic.json $OUT/${TAG}_pmc_traffic_f16.json
 
-# 4. per-shape split-K tuning tables (engine.cpp embeds the winners), per-op times, LDS micro-benchmark
-python tools/tune_conv.py        > $OUT/${TAG}_splitk_tuning.txt        2>&1
-python tools/tune_conv.py --f16  > $OUT/${TAG}_splitk_tuning_f16.txt    2>&1
-python tools/tune_conv.py --b3   > $OUT/${TAG}_splitk_tuning_bf16x3.txt 2>&1
-python tools/profile_ops.py      > $OUT/${TAG}_per_op_times.txt         2>/dev/null
-tools/micro/run_lds_bw.sh        > $OUT/${TAG}_lds_bandwidth.txt        2>/dev/null
+# 1. headline bench line (+ other_precisions, roofline, latency, h2d_inclusive, cpu_baseline) and the other modes alone
+python bench.py                                   > $OUT/${TAG}_bench_default.json 2>/dev/null
+python bench.py --precision f32 --no-cpu-baseline --other-modes "" > $OUT/${TAG}_bench_f32.json 2>/dev/null
+python bench.py --precision f16 --no-cpu-baseline --other-modes "" > $OUT/${TAG}_bench_f16.json 2>/dev/null
+for cfg in "bf16x3 28 2" "f16 28 3" "f32 28 2" "bf16x3 2 4" "bf16x3 4 3"; do set -- $cfg
+  python bench.py --precision $1 --batch $2 --streams $3 --steps 60 --warmup 6 --no-cpu-baseline --other-modes "" --no-roofline --no-side-runs 2>/dev/null
+done > $OUT/${TAG}_bench_batched.jsonl
+for st in 1 2 3 4 5 6 8; do
+  python bench.py --streams $st --steps 300 --warmup 20 --no-cpu-baseline --other-modes "" --no-roofline --no-side-runs 2>/dev/null
+done > $OUT/${TAG}_bench_streams.jsonl
 
-# 5. experiments recorded in DESIGN.md
-python tools/partition_probe.py  > $OUT/${TAG}_cu_partition_probe.txt   2>/dev/null
-tools/partition_sweep.sh         > $OUT/${TAG}_cu_partition_sweep.txt   2>/dev/null
-tools/f16_sweep.sh               > $OUT/${TAG}_f16_sweep.txt            2>/dev/null
-python tools/host_launch_cost.py > $OUT/${TAG}_host_launch_cost.txt     2>/dev/null
-for pr in f32 bf16x3 f16; do python tools/soak_determinism.py --iters 4000 --precision $pr; done > $OUT/${TAG}_soak.txt 2>/dev/null
-ls -la $OUT | tail -30
+# 2. rocprofv3 kernel statistics of the default command (kernels are serialised under the profiler: compare AverageNs
+#    of the dominant conv kernel with roofline.isolated.avg_launch_us, not the frames/s)
+tools/trace_headline.sh $TAG > /dev/null
+
+# 3. HBM-side traffic: the dominant kernel per launch, and one whole frame (FETCH_SIZE / WRITE_SIZE, two passes each)
+tools/pmc_traffic.sh && cp $OUT/pmc_traffic.json $OUT/${TAG}_pmc_traffic.json
+tools/pmc_traffic.sh --precision f32 && cp $OUT/pmc_traffic.json $OUT/${TAG}_pmc_traffic_f32.json
+tools/pmc_frame_traffic.sh 1 > $OUT/${TAG}_pmc_frame_traffic.json
+tools/pmc_mfma_busy.sh > /dev/null && cp $OUT/pmc_mfma_busy.json $OUT/${TAG}_pmc_mfma_busy.json
+
+# 4. per-shape kernel / slice tuning tables (engine.cpp embeds the winners), per-op times
+python tools/tune_conv.py            > $OUT/${TAG}_tune_b3.txt          2>&1
+python tools/tune_conv.py --f16      > $OUT/${TAG}_tune_f16.txt         2>&1
+python tools/tune_conv.py --fp32     > $OUT/${TAG}_tune_f32.txt         2>&1
+python tools/tune_conv.py --batch 4  > $OUT/${TAG}_tune_b3_batch4.txt   2>&1
+python tools/tune_conv.py --batch 28 > $OUT/${TAG}_tune_b3_batch28.txt  2>&1
+python tools/tune_conv.py --f16 --batch 28 > $OUT/${TAG}_tune_f16_batch28.txt 2>&1
+python tools/profile_ops.py                 > $OUT/${TAG}_per_op_times.txt     2>/dev/null
+python tools/profile_ops.py --precision f32 > $OUT/${TAG}_per_op_times_f32.txt 2>/dev/null
+
+# 5. determinism soak (bit-identical records over 4000 frames under 4-stream load, every precision)
+for pr in bf16x3 f32 f16; do python tools/soak_determinism.py --iters 4000 --precision $pr; done > $OUT/${TAG}_soak.txt 2>/dev/null
+ls -la $OUT | tail -40
