@@ -16,6 +16,9 @@ SOURCES = ["conv_igemm.hip", "conv_w64.hip", "aux_kernels.hip", "engine.cpp", "h
 HEADERS = ["bp_common.h", "engine.h", "frame_io.h", "conv_tail.inc", "conv_dev.h", os.path.join("..", "..", "include", "betapose_hip.h"),
            os.path.join("..", "..", "include", "yolo_v2_class_compat.h")]
 ARCH = "gfx950"
+# Host launch stubs every HIP object must export.  hipcc has been seen to drop a kernel's host stub SILENTLY (the object
+# links, the launch then fails at run time) -- DESIGN.md §3.1d -- so the build counts them.
+MIN_STUBS = {"conv_igemm.hip": 9, "conv_w64.hip": 8, "aux_kernels.hip": 18}
 
 
 def hipcc() -> str:
@@ -55,6 +58,13 @@ def build(force: bool = False, verbose: bool = True) -> str:
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out))
         if verbose and out.strip():
             print(out)
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    for src, want in MIN_STUBS.items():
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        syms = subprocess.run([nm, obj], stdout=subprocess.PIPE, text=True).stdout
+        have = syms.count("__device_stub__")
+        if have < want:
+            raise RuntimeError("%s: %d kernel host stubs in the object, expected >= %d (hipcc dropped a kernel)" % (src, have, want))
     cmd = [cc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-lz", "-lpthread"]
     if verbose:
         print(" ".join(cmd), flush=True)
