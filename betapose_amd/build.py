@@ -12,13 +12,13 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbetapose_hip.so")
-SOURCES = ["conv_igemm.hip", "conv_w64.hip", "aux_kernels.hip", "engine.cpp", "host_post.cpp", "frame_io.cpp", "jpeg_bmp.cpp", "c_api.cpp", "darknet_compat.cpp"]
+SOURCES = ["conv_igemm.hip", "conv_w64.hip", "conv_kg.hip", "conv_rd.hip", "aux_kernels.hip", "engine.cpp", "host_post.cpp", "frame_io.cpp", "jpeg_bmp.cpp", "c_api.cpp", "darknet_compat.cpp"]
 HEADERS = ["bp_common.h", "engine.h", "frame_io.h", "conv_tail.inc", "conv_dev.h", os.path.join("..", "..", "include", "betapose_hip.h"),
            os.path.join("..", "..", "include", "yolo_v2_class_compat.h")]
 ARCH = "gfx950"
 # Host launch stubs every HIP object must export.  hipcc has been seen to drop a kernel's host stub SILENTLY (the object
 # links, the launch then fails at run time) -- DESIGN.md §3.1d -- so the build counts them.
-MIN_STUBS = {"conv_igemm.hip": 9, "conv_w64.hip": 8, "aux_kernels.hip": 18}
+MIN_STUBS = {"conv_igemm.hip": 10, "conv_w64.hip": 8, "conv_kg.hip": 3, "conv_rd.hip": 2, "aux_kernels.hip": 18}
 
 
 def hipcc() -> str:
@@ -47,7 +47,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for src in SOURCES:
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         cmd = [cc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c",
-               os.path.join(CSRC, src), "-o", obj]
+               os.path.join(CSRC, src), "-o", obj] + os.environ.get("BP_CFLAGS", "").split()
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

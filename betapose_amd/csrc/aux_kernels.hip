@@ -573,6 +573,32 @@ void launch_f32_to_bf16x3(const float* in, unsigned short* out, long long n, hip
                        reinterpret_cast<__bf16*>(out), n);
 }
 
+// ---- the same three planes, STAGE-PACKED for conv_kg.hip: per 64-row filter tile and 16-k stage one contiguous block
+// [plane][row 0..63][32 B] that already is the kernel's LDS image (granule g of row r at slot g ^ ((r >> 3) & 1)), so a
+// stage arrives by six 1 KB lane-linear DMA instructions from 6 KB of consecutive addresses
+__global__ void f32_to_bf16x3_staged_kernel(const float* __restrict__ in, __bf16* __restrict__ out, int CoutPad, int Kpad) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)CoutPad * Kpad) return;
+    const int n = (int)(i / Kpad), k = (int)(i - (long long)n * Kpad);
+    const float x = in[i];
+    const __bf16 h1 = (__bf16)x;
+    const float r1 = x - (float)h1;
+    const __bf16 h2 = (__bf16)r1;
+    const float r2 = r1 - (float)h2;
+    const int tile = n >> 6, r = n & 63, stage = k >> 4, kk = k & 15;
+    const int slot = (kk >> 3) ^ ((r >> 3) & 1);
+    const long long base = ((long long)tile * (Kpad >> 4) + stage) * (3 * 64 * 16) + r * 16 + slot * 8 + (kk & 7);
+    out[base] = h1;
+    out[base + 64 * 16] = h2;
+    out[base + 2 * 64 * 16] = (__bf16)r2;
+}
+
+void launch_f32_to_bf16x3_staged(const float* in, unsigned short* out, int CoutPad, int Kpad, hipStream_t s) {
+    const long long n = (long long)CoutPad * Kpad;
+    hipLaunchKernelGGL(f32_to_bf16x3_staged_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in,
+                       reinterpret_cast<__bf16*>(out), CoutPad, Kpad);
+}
+
 // ---- placement probe: which XCD / CU every workgroup of a grid landed on (CU-mask experiments, tests)
 __global__ void probe_placement_kernel(int* out) {
     if (threadIdx.x == 0) {

@@ -66,6 +66,7 @@ struct ConvParams {
     int CoutPad;
     int cin_pack;          // channels per filter tap in the packed K order (= Cin, or 4 for Cin <= 4 stems)
     const unsigned short* w16;   // 16-bit copy of w for mfma_mode: fp16 [CoutPad][Kpad], or three bf16 planes [3][CoutPad][Kpad]
+    const unsigned short* w16s;  // PREC_BF16X3 only: the same planes stage-packed for conv_kg.hip (aux_kernels.hip)
     int mfma_mode;         // Precision the launch uses (PREC_F16 / PREC_BF16X3 need w16 and an eligible layer)
     unsigned long long* stamps;   // debug (tools/bench_conv.py --stamps): per-block s_memtime marks, null in production
 };
@@ -75,7 +76,13 @@ struct ConvParams {
 enum Precision : int { PREC_F32 = 0, PREC_F16 = 1, PREC_BF16X3 = 2 };
 
 // TILE_W64_<WM>x<WN>: conv_w64.hip, WM x WN waves of 64x64 each (16-bit precision modes only)
-enum ConvTile : int { TILE_64x64 = 0, TILE_128x64 = 1, TILE_W64_1x1 = 2, TILE_W64_1x2 = 3, TILE_W64_2x1 = 5, TILE_W64_2x2 = 6 };
+// TILE_KG<G>: conv_kg.hip, 64x64 block tile, G groups of 4 waves each on its own K range (bf16x3 mode only)
+enum ConvTile : int { TILE_64x64 = 0, TILE_128x64 = 1, TILE_W64_1x1 = 2, TILE_W64_1x2 = 3, TILE_W64_2x1 = 5, TILE_W64_2x2 = 6,
+                      TILE_KG1 = 7, TILE_KG2 = 8, TILE_KG4 = 9,
+                      // TILE_RD<W>: conv_rd.hip, one wave per 64x64 tile and K range, W K ranges per block, no LDS stage (bf16x3)
+                      TILE_RD4 = 10, TILE_RD8 = 11,
+                      // conv_igemm.hip's 64x64-block bf16x3 kernel with the filter fragments fetched straight into registers
+                      TILE_64x64_BD = 12, TILE_LAST = 12 };
 
 // when non-null, launch_conv brackets the implicit-GEMM kernel itself (not the split-K reduce) with these events
 struct ConvProfHook { hipEvent_t e0, e1; };
@@ -86,6 +93,10 @@ int conv_vec_mode(const ConvParams& p);   // 0 scalar gather, 1 Cin % 32 == 0, 2
 void launch_conv(const ConvParams& p, int tile, hipStream_t s);
 void launch_conv_w64(const ConvParams& p, int tile, hipStream_t s);   // conv_w64.hip
 bool conv_tile_is_w64(int tile);
+void launch_conv_kg(const ConvParams& p, int tile, hipStream_t s);    // conv_kg.hip
+bool conv_tile_is_kg(int tile);
+void launch_conv_rd(const ConvParams& p, int tile, hipStream_t s);    // conv_rd.hip
+bool conv_tile_is_rd(int tile);
 int conv_tiles(const ConvParams& p, int tile);   // blocks per K-slice
 int conv_tile_bm(int tile);
 int conv_tile_bn(int tile);
@@ -126,6 +137,7 @@ void launch_heatmap_argmax(const float* hm, int N, int C, int H, int W, float* o
 
 void launch_f32_to_f16(const float* in, unsigned short* out, long long n, hipStream_t s);
 void launch_f32_to_bf16x3(const float* in, unsigned short* out_planes, long long n, hipStream_t s);
+void launch_f32_to_bf16x3_staged(const float* in, unsigned short* out, int CoutPad, int Kpad, hipStream_t s);   // conv_kg.hip's layout
 void launch_probe_placement(int* d_out, int blocks, hipStream_t s);
 
 // crop stage (dataloader.py:794-835 + img.py:242-262) on device.

@@ -322,7 +322,7 @@ int bp_kpd_tap_copy(bp_kpd* k, int i, int batch, float* d_out, void* stream) {
 int bp_yolo_set_policy(bp_yolo* y, int t, int mc, int ms, int ft) {
     BP_TRY
     BP_CHECK(y, "null argument");
-    BP_CHECK(t >= 1 && mc >= 1 && ms >= 1 && ft >= -1 && ft <= bp::TILE_W64_2x2, "policy values out of range");
+    BP_CHECK(t >= 1 && mc >= 1 && ms >= 1 && ft >= -1 && ft <= bp::TILE_LAST, "policy values out of range");
     y->net->set_splitk_policy(t, mc);
     y->net->set_max_splits(ms);
     y->net->set_force_tile(ft);
@@ -348,7 +348,7 @@ int bp_kpd_set_precision(bp_kpd* k, int prec) {
 int bp_kpd_set_policy(bp_kpd* k, int t, int mc, int ms, int ft) {
     BP_TRY
     BP_CHECK(k, "null argument");
-    BP_CHECK(t >= 1 && mc >= 1 && ms >= 1 && ft >= -1 && ft <= bp::TILE_W64_2x2, "policy values out of range");
+    BP_CHECK(t >= 1 && mc >= 1 && ms >= 1 && ft >= -1 && ft <= bp::TILE_LAST, "policy values out of range");
     k->net->set_splitk_policy(t, mc);
     k->net->set_max_splits(ms);
     k->net->set_force_tile(ft);
@@ -452,7 +452,7 @@ int bp_conv2d(const float* d_in, int N, int H, int W, int Cin, const float* h_w,
         net.set_precision(prec);
         BP_CHECK(net.ops_[0].conv.mfma_mode == prec, "layer is not eligible for the 16-bit MFMA paths (needs Cin % 32 == 0)");
     } else {
-        BP_CHECK(!bp::conv_tile_is_w64(t), "w64 tiles need a 16-bit precision mode (tile + 16 / + 32)");
+        BP_CHECK(!bp::conv_tile_is_w64(t) && !bp::conv_tile_is_kg(t) && !bp::conv_tile_is_rd(t) && t != bp::TILE_64x64_BD, "w64 / K-group / register-direct tiles need a 16-bit precision mode (tile + 16 / + 32)");
     }
     bp::ConvParams p = net.ops_[0].conv;
     p.N = N; p.M = N * OH * OW;
@@ -504,8 +504,8 @@ int bp_conv2d(const float* d_in, int N, int H, int W, int Cin, const float* h_w,
                          sum[0] / stages, sum[1] / stages, sum[2] / stages, sum[3] / stages);
         }
         std::fprintf(stderr, "[stamps] blocks=%d  mean cycles since the block's entry: index math done %.0f | chunk 0 in LDS %.0f | "
-                     "K loop done %.0f | slab parked + ticket %.0f (%d blocks) | slices combined %.0f (%d) | stores done %.0f (%d) | "
-                     "last mark of the grid %.0f after the first entry\n", nb, mean(1), mean(2), mean(3), mean(5), cnt[5], mean(6),
+                     "K loop done %.0f | in-block sums %.0f | slab parked + ticket %.0f (%d blocks) | slices combined %.0f (%d) | stores done %.0f (%d) | "
+                     "last mark of the grid %.0f after the first entry\n", nb, mean(1), mean(2), mean(3), mean(7), mean(5), cnt[5], mean(6),
                      cnt[6], mean(4), cnt[4], last);
     }
     if (iters > 0 && ms_per_iter) {

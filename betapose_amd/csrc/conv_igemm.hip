@@ -306,13 +306,32 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 //           relative to an fp64 conv) -- at 6/16 of the fp32-MFMA cycles.  LDS carries three planes per operand.
 // Fragment layout of the 32x32x16 forms: lane l supplies row (l & 31), k = 8*(l>>5) .. 8*(l>>5)+7 (one 16-B LDS read).
 // =====================================================================================================================
-template <int TM, int TN, int NP>
+// timing experiments only (tools/ablate_pipeline.sh, wrong results): -DBP_ABLATE_SPLIT parks raw bits instead of the
+// three-way split (same LDS traffic, no conversions), -DBP_ABLATE_MFMA reads the fragments but multiplies nothing
+#ifdef BP_ABLATE_SPLIT
+static constexpr bool BP_ABL_SPLIT = true;
+#else
+static constexpr bool BP_ABL_SPLIT = false;
+#endif
+#ifdef BP_ABLATE_MFMA
+static constexpr bool BP_ABL_MFMA = true;
+#else
+static constexpr bool BP_ABL_MFMA = false;
+#endif
+// BD ("filters direct", NP = 3, 64x64 tile): the filter fragments skip LDS -- every wave fetches the six 1 KB fragments
+// of its 32 columns straight from the stage-packed copy ConvParams::w16s (fully coalesced, one chunk ahead) -- so LDS
+// carries the activations only: 36 KB per chunk instead of 72 KB.  In the pipeline LDS bandwidth is what the K loops
+// run into (profiles/r02_ablate_pipeline.txt: with the MFMAs AND the operand split compiled out the frame gets 10 %
+// faster, with the K loops cut to one chunk 84 %); the price is that a fragment is fetched by the two waves that share
+// its columns (32 KB instead of 20 KB per chunk through the vector-memory path, which has the room).
+template <int TM, int TN, int NP, bool BD = false>
 __global__ __launch_bounds__(256) void conv_igemm_h_kernel(const ConvParams p) {
+    static_assert(!BD || (NP == 3 && TM == 1 && TN == 1), "filters-direct variant: bf16x3, 64x64 tile");
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int RA = BM / 64;          // fp32 A rows per thread (8 consecutive floats each: two 16-B loads, one 16-B LDS store per plane)
     constexpr int RBH = BN / 64;         // 16-bit B rows per thread and plane (8 elements each)
     constexpr int LDT = BN + 4;
-    constexpr int STAGE_HALFS = NP * (BM + BN) * LDH;
+    constexpr int STAGE_HALFS = NP * (BM + (BD ? 0 : BN)) * LDH;
     constexpr int SMEM_FLOATS = (2 * STAGE_HALFS / 2 > BM * LDT) ? 2 * STAGE_HALFS / 2 : BM * LDT;
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
     unsigned short* const sh = reinterpret_cast<unsigned short*>(smem);
@@ -332,7 +351,11 @@ __global__ __launch_bounds__(256) void conv_igemm_h_kernel(const ConvParams p) {
     const int tile_m = tile_id / n_tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int c_begin = split * p.chunks_per_split;
+#ifdef BP_ABLATE_KLOOP   // timing experiment only (wrong results): one chunk per block, i.e. the fixed cost of the launch chain
+    const int c_end = min(p.nchunks, c_begin + 1);
+#else
     const int c_end = min(p.nchunks, c_begin + p.chunks_per_split);
+#endif
 
     const int lr = tid >> 2, a8 = (tid & 3) * 8; // A: row lr (+64i), floats a8..a8+7
     const int br = tid >> 2, b8 = (tid & 3) * 8; // B: row br (+64i), elements b8..+7
@@ -342,7 +365,11 @@ __global__ __launch_bounds__(256) void conv_igemm_h_kernel(const ConvParams p) {
     const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.in), 0, (int)min((long long)p.N * p.H * p.W * p.in_ld * 4, (long long)OOB), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<unsigned short*>(p.w16), 0, NP * plane_bytes, 0x00020000);
+        const_cast<unsigned short*>(BD ? p.w16s : p.w16), 0, NP * plane_bytes, 0x00020000);
+    // BD: fragment (plane, k-step) of chunk c for this wave's 32 columns = 1 KB at bd_tile + (2 c + k-step) * 6 KB +
+    // plane * 2 KB; lane -> row 32 wn + (lane & 31), granule (lane >> 5) at slot granule ^ ((row >> 3) & 1)
+    const int bd_tile = tile_n * (p.Kpad >> 4) * (NP * 64 * 32);
+    const unsigned bd_voff = (unsigned)((32 * wn + (lane & 31)) * 32 + (((lane >> 5) ^ ((lane >> 3) & 1)) << 4));
 
     unsigned a_base[RA];
     unsigned long long a_mask[RA];
@@ -404,9 +431,22 @@ __global__ __launch_bounds__(256) void conv_igemm_h_kernel(const ConvParams p) {
             ra_[2 * i] = buf_load4(rsrcA, va[i], 0);                                                   \
             ra_[2 * i + 1] = buf_load4(rsrcA, va[i], 16);                                              \
         }                                                                                              \
+        if constexpr (!BD) {                                                                           \
+            _Pragma("unroll") for (int pl = 0; pl < NP; ++pl)                                          \
+                _Pragma("unroll") for (int i = 0; i < RBH; ++i)                                        \
+                    rb_[pl][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrcB, (int)b_base[i] + pl * plane_bytes, sb, 0); \
+        }                                                                                              \
+    }
+    // BD: the six filter fragments (k-step ks in rb_[pl][ks]) of the next chunk of the block's range; past the range the
+    // offset is out of range (zeros, no memory traffic)
+    int bd_c = c_begin;
+#define BH_LOAD_BD(rb_)                                                                                \
+    {                                                                                                  \
+        const int so_ = bd_c < c_end ? bd_tile + bd_c * (2 * NP * 64 * 32) : (int)OOB;                 \
+        ++bd_c;                                                                                        \
         _Pragma("unroll") for (int pl = 0; pl < NP; ++pl)                                              \
-            _Pragma("unroll") for (int i = 0; i < RBH; ++i)                                            \
-                rb_[pl][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrcB, (int)b_base[i] + pl * plane_bytes, sb, 0); \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                           \
+                rb_[pl][ks] = __builtin_amdgcn_raw_buffer_load_b128(rsrcB, (int)bd_voff, so_ + ks * (NP * 64 * 32) + pl * 2048, 0); \
     }
 #define BH_STORE(s_, ra_, rb_)                                                                         \
     {                                                                                                  \
@@ -416,6 +456,10 @@ __global__ __launch_bounds__(256) void conv_igemm_h_kernel(const ConvParams p) {
             if constexpr (NP == 1) {                                                                   \
                 const f16x4 l = __builtin_convertvector(lo, f16x4), h = __builtin_convertvector(hi, f16x4); \
                 *reinterpret_cast<f16x8*>(dst) = __builtin_shufflevector(l, h, 0, 1, 2, 3, 4, 5, 6, 7); \
+            } else if constexpr (BP_ABL_SPLIT) {   /* timing experiment: same LDS traffic, no conversions */ \
+                *reinterpret_cast<f32x4*>(dst) = lo;                                                   \
+                *reinterpret_cast<f32x4*>(dst + BM * LDH) = hi;                                        \
+                *reinterpret_cast<f32x4*>(dst + 2 * BM * LDH) = lo;                                    \
             } else {                                                                                   \
                 const bf16x4 l1 = __builtin_convertvector(lo, bf16x4), h1 = __builtin_convertvector(hi, bf16x4); \
                 const f32x4 rl1 = lo - __builtin_convertvector(l1, f32x4), rh1 = hi - __builtin_convertvector(h1, f32x4); \
@@ -427,9 +471,11 @@ __global__ __launch_bounds__(256) void conv_igemm_h_kernel(const ConvParams p) {
                 *reinterpret_cast<bf16x8*>(dst + 2 * BM * LDH) = __builtin_shufflevector(l3, h3, 0, 1, 2, 3, 4, 5, 6, 7); \
             }                                                                                          \
         }                                                                                              \
-        _Pragma("unroll") for (int pl = 0; pl < NP; ++pl)                                              \
-            _Pragma("unroll") for (int i = 0; i < RBH; ++i)                                            \
-                *reinterpret_cast<u32x4*>(BH_BS(s_, pl) + (br + 64 * i) * LDH + b_st_off) = rb_[pl][i]; \
+        if constexpr (!BD) {                                                                           \
+            _Pragma("unroll") for (int pl = 0; pl < NP; ++pl)                                          \
+                _Pragma("unroll") for (int i = 0; i < RBH; ++i)                                        \
+                    *reinterpret_cast<u32x4*>(BH_BS(s_, pl) + (br + 64 * i) * LDH + b_st_off) = rb_[pl][i]; \
+        }                                                                                              \
     }
 
     f32x16 acc[TM][TN];
@@ -451,27 +497,33 @@ __global__ __launch_bounds__(256) void conv_igemm_h_kernel(const ConvParams p) {
     const int b_row0 = wn * (BN / 2) * LDH;
 
     f32x4 ra0[2 * RA], ra1[2 * RA];
-    u32x4 rb0[NP][RBH], rb1[NP][RBH];
+    constexpr int RBN = BD ? 2 : RBH;
+    u32x4 rb0[NP][RBN], rb1[NP][RBN];
     // partial products (A plane, B plane), smallest first
     constexpr int NPROD = NP == 1 ? 1 : 6;
     constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
     constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
     // One chunk: LDS[cur_] holds chunk c; (rna_, rnb_) hold chunk c+1 (in flight since the previous phase);
     // (rfa_, rfb_) receive chunk c+2, whose addresses were computed in the previous phase.
+    // BD: rnb_ holds the filter fragments of chunk c (requested in the previous phase), rfb_ receives those of c+1.
 #define BH_PHASE(cur_, rna_, rnb_, rfa_, rfb_)                                                         \
     {                                                                                                  \
         BH_LOAD(rfa_, rfb_);                                                                           \
+        if constexpr (BD) BH_LOAD_BD(rfb_);                                                            \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                             \
             frag_t fa[NP][TM], fb[NP][TN];                                                             \
             _Pragma("unroll") for (int pl = 0; pl < NP; ++pl) {                                        \
                 _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[pl][i] =                             \
                     *reinterpret_cast<const frag_t*>(BH_AS(cur_, pl) + a_row0 + i * 32 * LDH + (ks ? frag_ks1 : frag_ks0)); \
-                _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[pl][j] =                             \
-                    *reinterpret_cast<const frag_t*>(BH_BS(cur_, pl) + b_row0 + j * 32 * LDH + (ks ? frag_ks1 : frag_ks0)); \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                       \
+                    if constexpr (BD) fb[pl][j] = __builtin_bit_cast(frag_t, rnb_[pl][ks]);            \
+                    else fb[pl][j] = *reinterpret_cast<const frag_t*>(BH_BS(cur_, pl) + b_row0 + j * 32 * LDH + (ks ? frag_ks1 : frag_ks0)); \
+                }                                                                                      \
             }                                                                                          \
             _Pragma("unroll") for (int q = 0; q < NPROD; ++q)                                          \
                 _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) \
-                    acc[i][j] = HalfOps<NP>::mfma(fa[NP == 1 ? 0 : PA[q]][i], fb[NP == 1 ? 0 : PB[q]][j], acc[i][j]); \
+                    if constexpr (BP_ABL_MFMA) asm volatile("" :: "v"(fa[NP == 1 ? 0 : PA[q]][i]), "v"(fb[NP == 1 ? 0 : PB[q]][j])); \
+                    else acc[i][j] = HalfOps<NP>::mfma(fa[NP == 1 ? 0 : PA[q]][i], fb[NP == 1 ? 0 : PB[q]][j], acc[i][j]); \
         }                                                                                              \
         BH_STORE((cur_) ^ 1, rna_, rnb_);                                                              \
         BH_ADDR();                                                                                     \
@@ -480,6 +532,7 @@ __global__ __launch_bounds__(256) void conv_igemm_h_kernel(const ConvParams p) {
 
     if (c_begin < c_end) {
         BH_ADDR(); BH_LOAD(ra0, rb0);
+        if constexpr (BD) BH_LOAD_BD(rb1);        // the first phase multiplies with rb1
         BH_ADDR(); BH_LOAD(ra1, rb1);
         BH_ADDR();
         BH_STORE(0, ra0, rb0);
@@ -506,6 +559,7 @@ __global__ __launch_bounds__(256) void conv_igemm_h_kernel(const ConvParams p) {
 #undef BH_BS
 #undef BH_ADDR
 #undef BH_LOAD
+#undef BH_LOAD_BD
 #undef BH_STORE
 #undef BH_PHASE
 }
@@ -544,14 +598,14 @@ static void launch_t(const ConvParams& p, hipStream_t s) {
     }
 }
 
-template <int TM, int TN, int NP>
+template <int TM, int TN, int NP, bool BD = false>
 static void launch_h_t(const ConvParams& p, hipStream_t s) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     dim3 grid(((p.M + BM - 1) / BM) * (p.CoutPad / BN) * p.splits);
     if (g_conv_prof)
-        hipExtLaunchKernelGGL((conv_igemm_h_kernel<TM, TN, NP>), grid, dim3(256), 0, s, g_conv_prof->e0, g_conv_prof->e1, 0, p);
+        hipExtLaunchKernelGGL((conv_igemm_h_kernel<TM, TN, NP, BD>), grid, dim3(256), 0, s, g_conv_prof->e0, g_conv_prof->e1, 0, p);
     else
-        hipLaunchKernelGGL((conv_igemm_h_kernel<TM, TN, NP>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((conv_igemm_h_kernel<TM, TN, NP, BD>), grid, dim3(256), 0, s, p);
 }
 
 int conv_vec_mode(const ConvParams& p) {
@@ -576,14 +630,23 @@ void launch_conv(const ConvParams& p, int tile, hipStream_t s) {
     BP_CHECK((long long)p.N * p.H * p.W * p.in_ld * 4 < (long long)OOB, "activation tensor too large for 32-bit offsets");
     if (conv_tile_is_w64(tile)) {
         launch_conv_w64(p, tile, s);
+    } else if (conv_tile_is_kg(tile)) {
+        launch_conv_kg(p, tile, s);
+    } else if (conv_tile_is_rd(tile)) {
+        launch_conv_rd(p, tile, s);
     } else if (p.mfma_mode == PREC_F16 && conv_h16_eligible(p)) {
         switch (tile) {
             case TILE_128x64: launch_h_t<2, 1, 1>(p, s); break;
             default: launch_h_t<1, 1, 1>(p, s); break;
         }
     } else if (p.mfma_mode == PREC_BF16X3 && conv_h16_eligible(p)) {
-        BP_CHECK(tile == TILE_64x64, "the bf16x3 kernel is built for the 64x64 tile");
-        launch_h_t<1, 1, 3>(p, s);
+        BP_CHECK(tile == TILE_64x64 || tile == TILE_64x64_BD, "the bf16x3 kernel is built for the 64x64 tile");
+        if (tile == TILE_64x64_BD) {
+            BP_CHECK(p.w16s != nullptr, "filters-direct tile needs the stage-packed filter copy");
+            launch_h_t<1, 1, 3, true>(p, s);
+        } else {
+            launch_h_t<1, 1, 3>(p, s);
+        }
     } else {
         switch (tile) {
             case TILE_128x64: launch_t<2, 1>(p, s); break;

@@ -97,46 +97,46 @@ static const SplitEntry kSplitTable[] = {
 // conv_igemm.hip win every shape of the two networks); other shapes use the heuristic in choose_h16.
 struct PlanEntry { int M, CoutPad, nchunks, tile, splits; };
 static const PlanEntry kPlanB3[] = {
-    {    80,   512,   64, 0,  6},
-    {    80,   512,  144, 0, 10},
-    {    80,  2048,   16, 0,  3},
-    {    80,  2048,   32, 0,  3},
-    {   169,    64,   32, 0, 10},
-    {   169,   256,   16, 0,  5},
-    {   169,   512,   32, 0,  5},
-    {   169,  1024,  144, 0,  5},
-    {   320,   256,   32, 0,  5},
-    {   320,   256,   72, 0,  8},
-    {   320,   512,   32, 0,  5},
-    {   320,  1024,    8, 0,  1},
-    {   320,  1024,   16, 0,  3},
-    {   320,  1024,  144, 0,  6},
-    {   676,    64,   16, 0,  5},
-    {   676,   128,    8, 0,  1},
-    {   676,   256,   16, 0,  3},
-    {   676,   256,   24, 0,  5},
-    {   676,   512,   72, 0,  5},
-    {  1280,   128,   16, 0,  3},
-    {  1280,   128,   36, 0,  5},
-    {  1280,   256,   16, 0,  3},
-    {  1280,   512,    4, 0,  1},
-    {  1280,   512,    8, 0,  1},
-    {  1280,   512,   72, 0,  3},
-    {  2704,    64,    8, 0,  1},
-    {  2704,   128,    8, 0,  1},
-    {  2704,   128,   12, 0,  1},
-    {  2704,   256,   36, 0,  4},
-    {  5120,    64,    2, 0,  1},
-    {  5120,    64,    8, 0,  1},
-    {  5120,    64,   18, 0,  3},
-    {  5120,    64,   36, 0,  3},
-    {  5120,   128,    8, 0,  1},
-    {  5120,   256,    2, 0,  1},
-    { 10816,    64,    4, 0,  1},
-    { 10816,   128,   18, 0,  2},
-    { 43264,    64,    2, 0,  1},
-    { 43264,    64,    9, 0,  1},
-    {0, 0, 0, 0, 0},
+    {    80,   512,   64, TILE_64x64_BD,  6},
+    {    80,   512,  144, TILE_64x64_BD, 10},
+    {    80,  2048,   16, TILE_64x64_BD,  3},
+    {    80,  2048,   32, TILE_64x64_BD,  3},
+    {   169,    64,   32, TILE_64x64_BD, 10},
+    {   169,   256,   16, TILE_64x64_BD,  5},
+    {   169,   512,   32, TILE_64x64_BD,  5},
+    {   169,  1024,  144, TILE_64x64_BD,  5},
+    {   320,   256,   32, TILE_64x64_BD,  5},
+    {   320,   256,   72, TILE_64x64_BD,  8},
+    {   320,   512,   32, TILE_64x64_BD,  5},
+    {   320,  1024,    8, TILE_64x64_BD,  1},
+    {   320,  1024,   16, TILE_64x64_BD,  3},
+    {   320,  1024,  144, TILE_64x64_BD,  6},
+    {   676,    64,   16, TILE_64x64_BD,  5},
+    {   676,   128,    8, TILE_64x64_BD,  1},
+    {   676,   256,   16, TILE_64x64_BD,  3},
+    {   676,   256,   24, TILE_64x64_BD,  5},
+    {   676,   512,   72, TILE_64x64_BD,  5},
+    {  1280,   128,   16, TILE_64x64_BD,  3},
+    {  1280,   128,   36, TILE_64x64_BD,  5},
+    {  1280,   256,   16, TILE_64x64_BD,  3},
+    {  1280,   512,    4, TILE_64x64_BD,  1},
+    {  1280,   512,    8, TILE_64x64_BD,  1},
+    {  1280,   512,   72, TILE_64x64_BD,  3},
+    {  2704,    64,    8, TILE_64x64_BD,  1},
+    {  2704,   128,    8, TILE_64x64_BD,  1},
+    {  2704,   128,   12, TILE_64x64_BD,  1},
+    {  2704,   256,   36, TILE_64x64_BD,  4},
+    {  5120,    64,    2, TILE_64x64_BD,  1},
+    {  5120,    64,    8, TILE_64x64_BD,  1},
+    {  5120,    64,   18, TILE_64x64_BD,  3},
+    {  5120,    64,   36, TILE_64x64_BD,  3},
+    {  5120,   128,    8, TILE_64x64_BD,  1},
+    {  5120,   256,    2, TILE_64x64_BD,  1},
+    { 10816,    64,    4, TILE_64x64_BD,  1},
+    { 10816,   128,   18, TILE_64x64_BD,  2},
+    { 43264,    64,    2, TILE_64x64_BD,  1},
+    { 43264,    64,    9, TILE_64x64_BD,  1},
+    {     0,     0,    0, TILE_64x64_BD,  0},
 };
 static const PlanEntry kPlanF16[] = {
     {    80,   512,   64, 0,  5},
@@ -181,7 +181,27 @@ static const PlanEntry kPlanF16[] = {
     {0, 0, 0, 0, 0},
 };
 
+// experiment hook (tools only): BP_PLAN_FILE names a text file of "M CoutPad nchunks tile splits" lines that take
+// precedence over the built-in bf16x3 table, so a tuning sweep can be tried in the whole pipeline without a rebuild
+static const std::vector<PlanEntry>& plan_file_entries() {
+    static const std::vector<PlanEntry> entries = [] {
+        std::vector<PlanEntry> v;
+        if (const char* path = std::getenv("BP_PLAN_FILE")) {
+            if (FILE* f = std::fopen(path, "r")) {
+                PlanEntry e;
+                while (std::fscanf(f, "%d %d %d %d %d", &e.M, &e.CoutPad, &e.nchunks, &e.tile, &e.splits) == 5) v.push_back(e);
+                std::fclose(f);
+            }
+        }
+        return v;
+    }();
+    return entries;
+}
+
 static void choose_h16(const ConvParams& c, long long M, int mode, int sk_max, int* tile, int* splits) {
+    if (mode == PREC_BF16X3)
+        for (const PlanEntry& e : plan_file_entries())
+            if (e.M == (int)M && e.CoutPad == c.CoutPad && e.nchunks == c.nchunks) { *tile = e.tile; *splits = e.splits; return; }
     for (const PlanEntry& e : (mode == PREC_F16 ? kPlanF16 : kPlanB3)) {
         if (e.M == 0) break;
         if (e.M == (int)M && e.CoutPad == c.CoutPad && e.nchunks == c.nchunks) { *tile = e.tile; *splits = e.splits; return; }
@@ -190,7 +210,7 @@ static void choose_h16(const ConvParams& c, long long M, int mode, int sk_max, i
     // conv_w64.hip (64x64 per wave, half the filter re-reads) wins once its tile grid covers about half the CUs;
     // below that the 64x64-block kernels, which reach the same block count with fewer K slices
     const long long tiles128 = ((M + 127) / 128) * ((c.CoutPad + 127) / 128);
-    int t = (c.CoutPad >= 128 && tiles128 >= 128) ? TILE_W64_2x2 : TILE_64x64;
+    int t = (c.CoutPad >= 128 && tiles128 >= 128) ? TILE_W64_2x2 : (mode == PREC_BF16X3 && c.w16s ? TILE_64x64_BD : TILE_64x64);
     const int bm = conv_tile_bm(t), bn = conv_tile_bn(t);
     const long long blocks = ((M + bm - 1) / bm) * ((c.CoutPad + bn - 1) / bn);
     const int target = t == TILE_W64_2x2 ? 256 : (mode == PREC_F16 ? 128 : 512);
@@ -217,7 +237,7 @@ static void choose_launch(const Op& op, int batch, int force_tile, int sk_target
             while (blocks * s < sk_target && c.nchunks / (s + 1) >= sk_min_chunks && s < sk_max) ++s;
         }
     } else {
-        if (force_tile >= 0 && !conv_tile_is_w64(force_tile)) t = force_tile;
+        if (force_tile >= 0 && !conv_tile_is_w64(force_tile) && !conv_tile_is_kg(force_tile) && !conv_tile_is_rd(force_tile) && force_tile != TILE_64x64_BD) t = force_tile;
         const int bm = conv_tile_bm(t);
         const long long blocks = ((M + bm - 1) / bm) * (c.CoutPad / 64);
         while (blocks * s < sk_target && c.nchunks / (s + 1) >= sk_min_chunks && s < sk_max) ++s;
@@ -284,6 +304,7 @@ int Net::add_conv(const std::string& name, const Tensor& in, const Tensor& out_v
     c.M = OH * OW; c.nchunks = Kpad / 32; c.splits = 1; c.chunks_per_split = c.nchunks; c.partial = nullptr;
     c.tickets = nullptr;
     c.stamps = nullptr;
+    c.w16 = nullptr; c.w16s = nullptr;
     c.CoutPad = CoutPad;
     const double Kalg = (double)k * k * Cin;   // algorithmic K (the packing pad is not work)
     op.flops = 2.0 * OH * OW * (double)Cout * Kalg;
@@ -329,6 +350,7 @@ void Net::set_precision(int prec) {
             if (op.type != OP_CONV) continue;
             ConvParams& c = op.conv;
             c.w16 = nullptr;
+            c.w16s = nullptr;
             if (!((c.Cin % 32 == 0) && (c.in_ld % 4 == 0) && c.ksize <= 8)) continue;   // the RGB stems stay on the fp32 kernel
             auto it = copies.find(c.w);
             if (it == copies.end()) {
@@ -341,6 +363,17 @@ void Net::set_precision(int prec) {
                 made = true;
             }
             c.w16 = it->second;
+            c.w16s = nullptr;
+            if (prec == PREC_BF16X3) {
+                auto is = store_->bf16x3s.find(c.w);
+                if (is == store_->bf16x3s.end()) {
+                    unsigned short* d = (unsigned short*)store_->arena.alloc_bytes((size_t)3 * c.CoutPad * c.Kpad * sizeof(unsigned short));
+                    launch_f32_to_bf16x3_staged(c.w, d, c.CoutPad, c.Kpad, nullptr);
+                    is = store_->bf16x3s.emplace(c.w, d).first;
+                    made = true;
+                }
+                c.w16s = is->second;
+            }
         }
         if (made) {
             BP_HIP(hipGetLastError());

@@ -60,6 +60,7 @@ struct WeightStore {
     std::vector<float*> ptrs;
     std::map<const float*, unsigned short*> f16;      // fp16 copies of packed filters, made on first use
     std::map<const float*, unsigned short*> bf16x3;   // three bf16 planes per filter (PREC_BF16X3)
+    std::map<const float*, unsigned short*> bf16x3s;  // ... and their stage-packed copy (conv_kg.hip)
     std::mutex f16_mutex;
 };
 

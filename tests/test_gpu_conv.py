@@ -258,3 +258,79 @@ def test_conv_w64_full_size_layers(cuda):
         assert float((y3 - (2.0 * y1 + y2)).abs().max()) < 5e-5
         ref = F.conv2d(x1.double().permute(0, 3, 1, 2), w.double(), padding=k // 2).float()
         _check(y1.cpu().permute(0, 3, 1, 2), ref)
+
+
+# ---- conv_kg.hip: 64x64 tile, K split over G groups of four waves INSIDE the block (partial sums meet in LDS), with and
+# without cross-block slices on top.  Same bars: fp32-accurate, every epilogue / store mode, bit-reproducible.
+KG_TILES = ["kg1", "kg2", "kg4", "rd4", "rd8", "bd"]   # rd<W>: conv_rd.hip, operands global -> registers -> MFMA, W K ranges per block; bd: conv_igemm.hip's 64x64 kernel with the filter fragments straight into registers
+
+
+@pytest.mark.parametrize("case", F16_CASES)
+@pytest.mark.parametrize("tile", KG_TILES)
+@pytest.mark.parametrize("splits", [1, 3])
+def test_conv_kg_bf16x3_is_fp32_accurate(cuda, case, tile, splits):
+    N, H, W, Cin, Cout, k, st, pad, act = case
+    g = torch.Generator().manual_seed(1100 + CASES.index(case))
+    x = torch.randn(N, H, W, Cin, generator=g) * torch.exp(2 * torch.randn(N, H, W, 1, generator=g))   # wide dynamic range
+    w = torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g)
+    if splits > 1 and Cin * k * k // 32 < 2 * splits:
+        pytest.skip("too few K-chunks to split")
+    OH, OW = (H + 2 * pad - k) // st + 1, (W + 2 * pad - k) // st + 1
+    res = torch.randn(N, OH, OW, Cout, generator=g)
+    for after in (False, True):
+        ref64 = _ref(x.double(), w.double(), b.double(), st, pad, act, res.double(), after)
+        out3 = ops.conv2d_nhwc(x.to(cuda), w, b, stride=st, pad=pad, act=act, res=res.to(cuda), res_after_act=after,
+                               tile=tile + "_b3", splits=splits)
+        out32 = ops.conv2d_nhwc(x.to(cuda), w, b, stride=st, pad=pad, act=act, res=res.to(cuda), res_after_act=after,
+                                tile="64x64", splits=splits)
+        again = ops.conv2d_nhwc(x.to(cuda), w, b, stride=st, pad=pad, act=act, res=res.to(cuda), res_after_act=after,
+                                tile=tile + "_b3", splits=splits)
+        assert torch.equal(out3, again)                         # fixed summation order: bit-reproducible
+        out3, out32 = out3.cpu().permute(0, 3, 1, 2), out32.cpu().permute(0, 3, 1, 2)
+        scale = float(ref64.abs().mean())
+        e3 = float((out3.double() - ref64).abs().max()) / scale
+        e32 = float((out32.double() - ref64).abs().max()) / scale
+        assert e3 <= max(1.5 * e32, 2e-6), (e3, e32)
+        _check(out3, ref64.float(), tol=2e-5 * max(1.0, scale))
+
+
+@pytest.mark.parametrize("tile", KG_TILES)
+def test_conv_kg_store_modes(cuda, tile):
+    g = torch.Generator().manual_seed(16)
+    x = torch.randn(2, 10, 8, 64, generator=g)
+    w = torch.randn(128, 64, 3, 3, generator=g) / 24
+    b = torch.randn(128, generator=g)
+    ref = _ref(x, w, b, 1, 1, "relu", None, False)
+    xd = x.to(cuda)
+    t = tile + "_b3"
+    up = ops.conv2d_nhwc(xd, w, b, pad=1, act="relu", store="up2", tile=t).cpu().permute(0, 3, 1, 2)
+    _check(up, F.interpolate(ref, scale_factor=2, mode="nearest"))
+    ps = ops.conv2d_nhwc(xd, w, b, pad=1, act="relu", store="pixshuf", tile=t).cpu().permute(0, 3, 1, 2)
+    _check(ps, F.pixel_shuffle(ref, 2))
+    nc = ops.conv2d_nhwc(xd, w, b, pad=1, act="relu", store="nchw", tile=t, splits=2).cpu()
+    _check(nc, ref)
+    # Cout below the tile (detection head class): columns past Cout are never stored
+    w18 = torch.randn(18, 64, 1, 1, generator=g) / 8
+    b18 = torch.randn(18, generator=g)
+    hd = ops.conv2d_nhwc(xd, w18, b18, tile=t).cpu().permute(0, 3, 1, 2)
+    _check(hd, _ref(x, w18, b18, 1, 0, "linear", None, False))
+
+
+def test_conv_kg_full_size_layers(cuda):
+    """Full-size layers of both networks: against the definition (fp64) and the size-independent linearity property;
+    K ranges that do not divide over the groups (odd stage counts, groups left without work)."""
+    g = torch.Generator().manual_seed(22)
+    for (H, W, Cin, Cout, k, tile, splits) in [(52, 52, 128, 256, 3, "kg4", 1), (13, 13, 512, 1024, 3, "kg4", 3),
+                                               (104, 104, 64, 128, 3, "kg2", 1), (20, 16, 1024, 256, 1, "kg4", 1),
+                                               (208, 208, 64, 32, 1, "kg4", 1), (26, 26, 32, 64, 1, "kg4", 1),
+                                               (13, 13, 96, 64, 3, "kg4", 2), (40, 32, 160, 64, 1, "kg2", 1)]:
+        x1 = torch.randn(1, H, W, Cin, generator=g)
+        x2 = torch.randn(1, H, W, Cin, generator=g)
+        w = torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k)
+        y1 = ops.conv2d_nhwc(x1.to(cuda), w, None, pad=k // 2, tile=tile + "_b3", splits=splits)
+        y2 = ops.conv2d_nhwc(x2.to(cuda), w, None, pad=k // 2, tile=tile + "_b3", splits=splits)
+        y3 = ops.conv2d_nhwc((2.0 * x1 + x2).to(cuda), w, None, pad=k // 2, tile=tile + "_b3", splits=splits)
+        assert float((y3 - (2.0 * y1 + y2)).abs().max()) < 5e-5
+        ref = F.conv2d(x1.double().permute(0, 3, 1, 2), w.double(), padding=k // 2).float()
+        _check(y1.cpu().permute(0, 3, 1, 2), ref)
