@@ -370,6 +370,23 @@ __global__ __launch_bounds__(256) void conv_igemm_h_kernel(const ConvParams p) {
     // plane * 2 KB; lane -> row 32 wn + (lane & 31), granule (lane >> 5) at slot granule ^ ((row >> 3) & 1)
     const int bd_tile = tile_n * (p.Kpad >> 4) * (NP * 64 * 32);
     const unsigned bd_voff = (unsigned)((32 * wn + (lane & 31)) * 32 + (((lane >> 5) ^ ((lane >> 3) & 1)) << 4));
+    // BD: the six filter fragments (k-step ks in rb_[pl][ks]) of the next chunk of the block's range; past the range the
+    // offset is out of range (zeros, no memory traffic)
+    int bd_c = c_begin;
+#define BH_LOAD_BD(rb_)                                                                                \
+    {                                                                                                  \
+        const int so_ = bd_c < c_end ? bd_tile + bd_c * (2 * NP * 64 * 32) : (int)OOB;                 \
+        ++bd_c;                                                                                        \
+        _Pragma("unroll") for (int pl = 0; pl < NP; ++pl)                                              \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                           \
+                rb_[pl][ks] = __builtin_amdgcn_raw_buffer_load_b128(rsrcB, (int)bd_voff, so_ + ks * (NP * 64 * 32) + pl * 2048, 0); \
+    }
+    constexpr int RBN = BD ? 2 : RBH;
+    u32x4 rb0[NP][RBN], rb1[NP][RBN];
+    if constexpr (BD) {   // the first chunk's filters need no index math: requested before it (a cold kernel waits > 1 us for its first operands)
+        BH_LOAD_BD(rb1);  // the first phase multiplies with rb1
+        __builtin_amdgcn_sched_barrier(0);
+    }
 
     unsigned a_base[RA];
     unsigned long long a_mask[RA];
@@ -437,17 +454,7 @@ __global__ __launch_bounds__(256) void conv_igemm_h_kernel(const ConvParams p) {
                     rb_[pl][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrcB, (int)b_base[i] + pl * plane_bytes, sb, 0); \
         }                                                                                              \
     }
-    // BD: the six filter fragments (k-step ks in rb_[pl][ks]) of the next chunk of the block's range; past the range the
-    // offset is out of range (zeros, no memory traffic)
-    int bd_c = c_begin;
-#define BH_LOAD_BD(rb_)                                                                                \
-    {                                                                                                  \
-        const int so_ = bd_c < c_end ? bd_tile + bd_c * (2 * NP * 64 * 32) : (int)OOB;                 \
-        ++bd_c;                                                                                        \
-        _Pragma("unroll") for (int pl = 0; pl < NP; ++pl)                                              \
-            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                           \
-                rb_[pl][ks] = __builtin_amdgcn_raw_buffer_load_b128(rsrcB, (int)bd_voff, so_ + ks * (NP * 64 * 32) + pl * 2048, 0); \
-    }
+
 #define BH_STORE(s_, ra_, rb_)                                                                         \
     {                                                                                                  \
         _Pragma("unroll") for (int i = 0; i < RA; ++i) {                                               \
@@ -497,8 +504,6 @@ __global__ __launch_bounds__(256) void conv_igemm_h_kernel(const ConvParams p) {
     const int b_row0 = wn * (BN / 2) * LDH;
 
     f32x4 ra0[2 * RA], ra1[2 * RA];
-    constexpr int RBN = BD ? 2 : RBH;
-    u32x4 rb0[NP][RBN], rb1[NP][RBN];
     // partial products (A plane, B plane), smallest first
     constexpr int NPROD = NP == 1 ? 1 : 6;
     constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
@@ -532,7 +537,6 @@ __global__ __launch_bounds__(256) void conv_igemm_h_kernel(const ConvParams p) {
 
     if (c_begin < c_end) {
         BH_ADDR(); BH_LOAD(ra0, rb0);
-        if constexpr (BD) BH_LOAD_BD(rb1);        // the first phase multiplies with rb1
         BH_ADDR(); BH_LOAD(ra1, rb1);
         BH_ADDR();
         BH_STORE(0, ra0, rb0);
