@@ -29,9 +29,11 @@ tools/pmc_traffic.sh && cp $OUT/pmc_traffic.json $OUT/${TAG}_pmc_traffic.json
 tools/pmc_traffic.sh --precision f32 && cp $OUT/pmc_traffic.json $OUT/${TAG}_pmc_traffic_f32.json
 tools/pmc_frame_traffic.sh 1 > $OUT/${TAG}_pmc_frame_traffic.json
 tools/pmc_mfma_busy.sh > /dev/null && cp $OUT/pmc_mfma_busy.json $OUT/${TAG}_pmc_mfma_busy.json
+tools/pmc_wave_stalls.sh > /dev/null && cp $OUT/pmc_wave_stalls.json $OUT/${TAG}_pmc_wave_stalls.json
 
 # 4. per-shape kernel / slice tuning tables (engine.cpp embeds the winners), per-op times
 python tools/tune_conv.py            > $OUT/${TAG}_tune_b3.txt          2>&1
+python tools/tune_conv.py --kg       > $OUT/${TAG}_tune_b3_kernels.txt  2>&1   # 64x64 / filters-direct / K-group / register-direct
 python tools/tune_conv.py --f16      > $OUT/${TAG}_tune_f16.txt         2>&1
 python tools/tune_conv.py --fp32     > $OUT/${TAG}_tune_f32.txt         2>&1
 python tools/tune_conv.py --batch 4  > $OUT/${TAG}_tune_b3_batch4.txt   2>&1
@@ -42,4 +44,10 @@ python tools/profile_ops.py --precision f32 > $OUT/${TAG}_per_op_times_f32.txt 2
 
 # 5. determinism soak (bit-identical records over 4000 frames under 4-stream load, every precision)
 for pr in bf16x3 f32 f16; do python tools/soak_determinism.py --iters 4000 --precision $pr; done > $OUT/${TAG}_soak.txt 2>/dev/null
+
+# 6. what bounds the batch-1 pipeline: parts of the conv kernels compiled out (timing only), the launch-chain floor,
+#    BASELINE configs[4] (eight resident objects, (frame, object) units) against eight single-object runs
+bash tools/ablate_pipeline.sh > /dev/null && cp $OUT/ablate_pipeline.txt $OUT/${TAG}_ablate_pipeline.txt
+python tools/launch_floor.py 202 > $OUT/${TAG}_launch_floor.txt 2>/dev/null
+python tools/occlusion_scale.py --frames 384 > $OUT/${TAG}_occlusion_8obj.txt 2>&1
 ls -la $OUT | tail -40
