@@ -208,9 +208,21 @@ def roofline(det, pose, batch):
     # rocprofv3 PMC passes (profiles/*_pmc_traffic.json, collected with tools/pmc_traffic.sh, corrections inside)
     traffic, traffic_src = None, None
     mode = {2: "f16", 3: "bf16x3"}.get(key[1], "f32")
-    family = "conv_w64_kernel" if key[0] >= 2 else "conv_igemm_h_kernel"
-    want = "bp::conv_igemm_kernel<%s" % TILE_NAMES.get(key[0], "?") if mode == "f32" else \
-        "bp::%s<%s, %d" % (family, TILE_NAMES.get(key[0], "?"), 1 if mode == "f16" else 3)
+    def kernel_name(tile, mode):
+        if mode == "f32":
+            return "bp::conv_igemm_kernel<%s, %d>" % (TILE_NAMES.get(tile, "?"), key[1])
+        np_ = 1 if mode == "f16" else 3
+        if tile == 12:
+            return "bp::conv_igemm_h_kernel<1, 1, 3, true>"        # filters direct
+        if tile in (7, 8, 9):
+            return "bp::conv_kg_kernel<%d, 3>" % {7: 1, 8: 2, 9: 4}[tile]
+        if tile in (10, 11):
+            return "bp::conv_rd_kernel<%d>" % {10: 4, 11: 8}[tile]
+        if tile >= 2:
+            return "bp::conv_w64_kernel<%s, %d>" % (TILE_NAMES.get(tile, "?"), np_)
+        return "bp::conv_igemm_h_kernel<%s, %d, false>" % (TILE_NAMES.get(tile, "?"), np_)
+    name = kernel_name(key[0], mode)
+    want = name.split(">")[0]
     try:
         import glob
         for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic*.json")))[::-1]:
@@ -221,10 +233,6 @@ def roofline(det, pose, batch):
     except Exception:
         pass
     peak = {"f32": PEAK_FP32_MFMA_TFLOPS, "f16": PEAK_F16_MFMA_TFLOPS, "bf16x3": PEAK_BF16X3_TFLOPS}[mode]
-    if mode == "f32":
-        name = "bp::conv_igemm_kernel<%s, %d>" % (TILE_NAMES.get(key[0], "?"), key[1])
-    else:
-        name = "bp::%s<%s, %d>" % (family, TILE_NAMES.get(key[0], "?"), 1 if mode == "f16" else 3)
     extra = {}
     if mode == "bf16x3":
         # six bf16 partial products per algorithmic multiply: the matrix cores execute 6x the algorithmic FLOPs;
