@@ -530,14 +530,21 @@ __global__ __launch_bounds__(256) void conv_igemm_h_kernel(const ConvParams p) {
                     if constexpr (BP_ABL_MFMA) asm volatile("" :: "v"(fa[NP == 1 ? 0 : PA[q]][i]), "v"(fb[NP == 1 ? 0 : PB[q]][j])); \
                     else acc[i][j] = HalfOps<NP>::mfma(fa[NP == 1 ? 0 : PA[q]][i], fb[NP == 1 ? 0 : PB[q]][j], acc[i][j]); \
         }                                                                                              \
-        BH_STORE((cur_) ^ 1, rna_, rnb_);                                                              \
+        BH_STORE((cur_) ^ 1, BH_PARKED(rna_, rfa_), rnb_);                                             \
         BH_ADDR();                                                                                     \
         __syncthreads();                                                                               \
     }
+#ifdef BP_ABLATE_PREFETCH   // timing experiment (BD variant only, results stay right): activations ONE chunk ahead instead of two
+#define BH_PARKED(rn_, rf_) rf_
+#else
+#define BH_PARKED(rn_, rf_) rn_
+#endif
 
     if (c_begin < c_end) {
         BH_ADDR(); BH_LOAD(ra0, rb0);
+#ifndef BP_ABLATE_PREFETCH
         BH_ADDR(); BH_LOAD(ra1, rb1);
+#endif
         BH_ADDR();
         BH_STORE(0, ra0, rb0);
         __syncthreads();
@@ -563,6 +570,7 @@ __global__ __launch_bounds__(256) void conv_igemm_h_kernel(const ConvParams p) {
 #undef BH_BS
 #undef BH_ADDR
 #undef BH_LOAD
+#undef BH_PARKED
 #undef BH_LOAD_BD
 #undef BH_STORE
 #undef BH_PHASE
