@@ -93,8 +93,10 @@ static const SplitEntry kSplitTable[] = {
 };
 
 // 16-bit precision modes: {M, CoutPad, K-chunks} -> {tile, slices}, measured one kernel at a time over both kernel
-// families (tools/tune_conv.py [--f16], profiles/r02_tune_{b3,f16}.txt: at batch 1 the 64x64-block kernels of
-// conv_igemm.hip win every shape of the two networks); other shapes use the heuristic in choose_h16.
+// families (tools/tune_conv.py [--f16 | --kg], profiles/r02_tune_{b3,f16,b3_kernels}.txt: at batch 1 the 64x64-block
+// kernels of conv_igemm.hip win every shape of the two networks, in the bf16x3 mode its filters-direct variant; the
+// slice counts are those the whole pipeline runs fastest with, which are higher than a kernel timed alone prefers);
+// other shapes use the heuristic in choose_h16.
 struct PlanEntry { int M, CoutPad, nchunks, tile, splits; };
 static const PlanEntry kPlanB3[] = {
     {    80,   512,   64, TILE_64x64_BD,  6},
