@@ -655,6 +655,7 @@ void launch_conv(const ConvParams& p, int tile, hipStream_t s) {
         BP_CHECK(tile == TILE_64x64 || tile == TILE_64x64_BD, "the bf16x3 kernel is built for the 64x64 tile");
         if (tile == TILE_64x64_BD) {
             BP_CHECK(p.w16s != nullptr, "filters-direct tile needs the stage-packed filter copy");
+            BP_CHECK((long long)3 * p.CoutPad * p.Kpad * 2 < (long long)OOB, "filter planes too large for 32-bit offsets");
             launch_h_t<1, 1, 3, true>(p, s);
         } else {
             launch_h_t<1, 1, 3>(p, s);
