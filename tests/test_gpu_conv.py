@@ -334,3 +334,20 @@ def test_conv_kg_full_size_layers(cuda):
         assert float((y3 - (2.0 * y1 + y2)).abs().max()) < 5e-5
         ref = F.conv2d(x1.double().permute(0, 3, 1, 2), w.double(), padding=k // 2).float()
         _check(y1.cpu().permute(0, 3, 1, 2), ref)
+
+
+@pytest.mark.parametrize("case", F16_CASES)
+@pytest.mark.parametrize("splits", [1, 3])
+def test_conv_filters_direct_is_bit_identical_to_the_staged_kernel(cuda, case, splits):
+    """The filters-direct variant (filter fragments global -> registers from the stage-packed copy) feeds the MFMAs the
+    same operands in the same order as the LDS-staged bf16x3 kernel: the two data paths must agree bit for bit."""
+    N, H, W, Cin, Cout, k, st, pad, act = case
+    if splits > 1 and Cin * k * k // 32 < 2 * splits:
+        pytest.skip("too few K-chunks to split")
+    g = torch.Generator().manual_seed(1300 + CASES.index(case))
+    x = (torch.randn(N, H, W, Cin, generator=g) * torch.exp(2 * torch.randn(N, H, W, 1, generator=g))).to(cuda)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g)
+    a1 = ops.conv2d_nhwc(x, w, b, stride=st, pad=pad, act=act, tile="bd_b3", splits=splits)
+    a2 = ops.conv2d_nhwc(x, w, b, stride=st, pad=pad, act=act, tile="64x64_b3", splits=splits)
+    assert torch.equal(a1, a2)
