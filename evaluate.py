@@ -117,7 +117,8 @@ def main():
     ys, ks = bpd.broadcast_stream(ys), bpd.broadcast_stream(ks)
     det = Darknet("yolo/cfg/yolov3-single.cfg", reso=int(args.inp_dim), max_batch=max(1, args.detbatch), device=local)
     det.load_stream(ys).cuda()
-    pose_model = FastPoseHIP.from_stream(ks, n_classes=args.nClasses, max_batch=1, device=local).cuda()
+    pose_model = FastPoseHIP.from_stream(ks, n_classes=args.nClasses, max_batch=max(1, args.detbatch) if args.fused else 1,
+                                        device=local).cuda()
     det.set_precision(args.precision)
     pose_model.set_precision(args.precision)
 
@@ -135,14 +136,14 @@ def main():
             # decode threads are a per-GPU budget: ranks of one node share the host cores
             threads = max(1, min(args.load_threads, (os.cpu_count() or 8) // max(1, world)))
             loader = FrameLoader([os.path.join(args.inputpath, im_names[i]) for i in mine], threads=threads,
-                                 depth=max(16, 2 * args.streams + threads))
+                                 depth=max(16, 2 * args.streams * max(1, args.detbatch) + threads))
             runner = StreamedRunner(det, pose_model, loader.height, loader.width, streams=args.streams,
-                                    confidence=args.confidence, num_classes=args.num_classes)
+                                    confidence=args.confidence, num_classes=args.num_classes, batch=args.detbatch)
             runner.run(loader, keep)
             loader.close()
         t_dev = time.time() - t_dev
-        print("rank %d: %d frames, files -> records %.1f frames/sec (%d frames in flight, %d decode threads)" % (
-            rank, len(mine), len(mine) / max(t_dev, 1e-9), args.streams, args.load_threads))
+        print("rank %d: %d frames, files -> records %.1f frames/sec (%d launches of %d frame(s) in flight, %d decode threads)" % (
+            rank, len(mine), len(mine) / max(t_dev, 1e-9), args.streams, max(1, args.detbatch), args.load_threads))
         allrec = bpd.gather_records(recs, mine, len(im_names))
         final_result = []
         if rank == 0:

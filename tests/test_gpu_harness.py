@@ -183,3 +183,23 @@ def test_video_detection_loader_flow(tmp_path, cuda):
             assert 0 <= b[0] < b[2] <= 640 and 0 <= b[1] < b[3] <= 480
     finally:
         opt.inp_dim, opt.confidence = old
+
+
+def test_fused_frames_per_launch_matches_one_frame_per_launch(tmp_path):
+    """``--fused --detbatch 3`` (three frames per launch and stream, ragged last launch) against ``--detbatch 1``: same
+    frames in the JSON, same arg-max pixels (key points within the float tolerance of a different summation order)."""
+    import json
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    outs = {}
+    for b in (1, 3):
+        od = tmp_path / ("b%d" % b)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "evaluate.py"), "--synthetic", "7", "--outdir", str(od), "--fused",
+                            "--detbatch", str(b), "--streams", "2"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs[b] = json.load(open(od / "Betapose-results.json"))
+    assert [e["image_id"] for e in outs[1]] == [e["image_id"] for e in outs[3]] and len(outs[1]) == 7
+    for e1, e3 in zip(outs[1], outs[3]):
+        k1, k3 = np.asarray(e1["keypoints"]).reshape(-1, 3), np.asarray(e3["keypoints"]).reshape(-1, 3)
+        assert np.abs(k1[:, :2] - k3[:, :2]).max() <= 5e-3 and np.abs(k1[:, 2] - k3[:, 2]).max() <= 2e-4

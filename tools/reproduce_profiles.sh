@@ -50,5 +50,5 @@ for pr in bf16x3 f32 f16; do python tools/soak_determinism.py --iters 4000 --pre
 bash tools/ablate_pipeline.sh > /dev/null && cp $OUT/ablate_pipeline.txt $OUT/${TAG}_ablate_pipeline.txt
 python tools/launch_floor.py 202 > $OUT/${TAG}_launch_floor.txt 2>/dev/null
 python tools/occlusion_scale.py --frames 384 > $OUT/${TAG}_occlusion_8obj.txt 2>&1
-python evaluate.py --synthetic 768 --outdir /tmp/ev --fused --streams 4 2>&1 | grep frames/sec > $OUT/${TAG}_evaluate_fused.txt
+for b in 1 2 4; do python evaluate.py --synthetic 768 --outdir /tmp/ev --fused --streams 4 --detbatch $b 2>&1 | grep frames/sec; done > $OUT/${TAG}_evaluate_fused.txt
 ls -la $OUT | tail -40
