@@ -180,6 +180,46 @@ static const PlanEntry kPlanF16[] = {
     { 10816,   128,   18, 0,  1},
     { 43264,    64,    2, 0,  1},
     { 43264,    64,    9, 0,  1},
+    // batch 28 (BASELINE configs[2]; profiles/r02_tune_f16_batch28.txt, with the 128x64 block among the candidates)
+    {  2240,   512,   64, 1,  1},
+    {  2240,   512,  144, 1,  1},
+    {  2240,  2048,   16, 0,  1},
+    {  2240,  2048,   32, 0,  1},
+    {  4732,    64,   32, 0,  1},
+    {  4732,   256,   16, 0,  1},
+    {  4732,   512,   32, 6,  1},
+    {  4732,  1024,  144, 1,  1},
+    {  8960,   256,   32, 6,  1},
+    {  8960,   256,   72, 6,  1},
+    {  8960,   512,   32, 0,  1},
+    {  8960,  1024,    8, 0,  1},
+    {  8960,  1024,   16, 0,  1},
+    {  8960,  1024,  144, 1,  1},
+    { 18928,    64,   16, 0,  1},
+    { 18928,   128,    8, 6,  1},
+    { 18928,   256,   16, 0,  1},
+    { 18928,   256,   24, 0,  1},
+    { 18928,   512,   72, 6,  1},
+    { 35840,   128,   16, 0,  1},
+    { 35840,   128,   36, 0,  1},
+    { 35840,   256,   16, 6,  1},
+    { 35840,   512,    4, 0,  1},
+    { 35840,   512,    8, 0,  1},
+    { 35840,   512,   72, 6,  1},
+    { 75712,    64,    8, 0,  1},
+    { 75712,   128,    8, 0,  1},
+    { 75712,   128,   12, 6,  1},
+    { 75712,   256,   36, 6,  1},
+    {143360,    64,    2, 0,  1},
+    {143360,    64,    8, 0,  1},
+    {143360,    64,   18, 0,  1},
+    {143360,    64,   36, 0,  1},
+    {143360,   128,    8, 6,  1},
+    {143360,   256,    2, 0,  1},
+    {302848,    64,    4, 0,  1},
+    {302848,   128,   18, 6,  1},
+    {1211392,    64,    2, 0,  1},
+    {1211392,    64,    9, 1,  1},
     {0, 0, 0, 0, 0},
 };
 
@@ -204,15 +244,15 @@ static void choose_h16(const ConvParams& c, long long M, int mode, int sk_max, i
     if (mode == PREC_BF16X3)
         for (const PlanEntry& e : plan_file_entries())
             if (e.M == (int)M && e.CoutPad == c.CoutPad && e.nchunks == c.nchunks) { *tile = e.tile; *splits = e.splits; return; }
-    for (const PlanEntry& e : (mode == PREC_F16 ? kPlanF16 : kPlanB3)) {
-        if (e.M == 0) break;
-        if (e.M == (int)M && e.CoutPad == c.CoutPad && e.nchunks == c.nchunks) { *tile = e.tile; *splits = e.splits; return; }
-    }
+    for (const PlanEntry* e = (mode == PREC_F16 ? kPlanF16 : kPlanB3); e->M != 0; ++e)   // tables end with a zero row
+        if (e->M == (int)M && e->CoutPad == c.CoutPad && e->nchunks == c.nchunks) { *tile = e->tile; *splits = e->splits; return; }
     // heuristic from the batch-4 / batch-28 sweeps (profiles/r02_tune_b3_batch{4,28}.txt): the 128x128 block of
     // conv_w64.hip (64x64 per wave, half the filter re-reads) wins once its tile grid covers about half the CUs;
     // below that the 64x64-block kernels, which reach the same block count with fewer K slices
     const long long tiles128 = ((M + 127) / 128) * ((c.CoutPad + 127) / 128);
-    int t = (c.CoutPad >= 128 && tiles128 >= 128) ? TILE_W64_2x2 : (mode == PREC_BF16X3 && c.w16s ? TILE_64x64_BD : TILE_64x64);
+    // ... in the fp16 mode.  In the bf16x3 mode the filters-direct 64x64 kernel beats every w64 shape at every batch
+    // size tried (profiles/r02_tune_b3_batch28.txt: 46 of 47 shapes at batch 28, by 11 % in the sum)
+    int t = (mode == PREC_BF16X3 && c.w16s) ? TILE_64x64_BD : ((c.CoutPad >= 128 && tiles128 >= 128) ? TILE_W64_2x2 : TILE_64x64);
     const int bm = conv_tile_bm(t), bn = conv_tile_bn(t);
     const long long blocks = ((M + bm - 1) / bm) * ((c.CoutPad + bn - 1) / bn);
     const int target = t == TILE_W64_2x2 ? 256 : (mode == PREC_F16 ? 128 : 512);
