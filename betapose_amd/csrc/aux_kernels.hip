@@ -599,6 +599,22 @@ void launch_f32_to_bf16x3_staged(const float* in, unsigned short* out, int CoutP
                        reinterpret_cast<__bf16*>(out), CoutPad, Kpad);
 }
 
+// fp16 operands, stage-packed the same way (one plane: 2 KB per 64-row tile and 16-k stage)
+__global__ void f32_to_f16_staged_kernel(const float* __restrict__ in, _Float16* __restrict__ out, int CoutPad, int Kpad) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)CoutPad * Kpad) return;
+    const int n = (int)(i / Kpad), k = (int)(i - (long long)n * Kpad);
+    const int tile = n >> 6, r = n & 63, stage = k >> 4, kk = k & 15;
+    const int slot = (kk >> 3) ^ ((r >> 3) & 1);
+    out[((long long)tile * (Kpad >> 4) + stage) * (64 * 16) + r * 16 + slot * 8 + (kk & 7)] = (_Float16)in[i];
+}
+
+void launch_f32_to_f16_staged(const float* in, unsigned short* out, int CoutPad, int Kpad, hipStream_t s) {
+    const long long n = (long long)CoutPad * Kpad;
+    hipLaunchKernelGGL(f32_to_f16_staged_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in,
+                       reinterpret_cast<_Float16*>(out), CoutPad, Kpad);
+}
+
 // ---- placement probe: which XCD / CU every workgroup of a grid landed on (CU-mask experiments, tests)
 __global__ void probe_placement_kernel(int* out) {
     if (threadIdx.x == 0) {

@@ -66,7 +66,7 @@ struct ConvParams {
     int CoutPad;
     int cin_pack;          // channels per filter tap in the packed K order (= Cin, or 4 for Cin <= 4 stems)
     const unsigned short* w16;   // 16-bit copy of w for mfma_mode: fp16 [CoutPad][Kpad], or three bf16 planes [3][CoutPad][Kpad]
-    const unsigned short* w16s;  // PREC_BF16X3 only: the same planes stage-packed for conv_kg.hip (aux_kernels.hip)
+    const unsigned short* w16s;  // the same operands stage-packed (aux_kernels.hip): filters-direct kernels, conv_kg.hip, conv_rd.hip
     int mfma_mode;         // Precision the launch uses (PREC_F16 / PREC_BF16X3 need w16 and an eligible layer)
     unsigned long long* stamps;   // debug (tools/bench_conv.py --stamps): per-block s_memtime marks, null in production
 };
@@ -137,6 +137,7 @@ void launch_heatmap_argmax(const float* hm, int N, int C, int H, int W, float* o
 
 void launch_f32_to_f16(const float* in, unsigned short* out, long long n, hipStream_t s);
 void launch_f32_to_bf16x3(const float* in, unsigned short* out_planes, long long n, hipStream_t s);
+void launch_f32_to_f16_staged(const float* in, unsigned short* out, int CoutPad, int Kpad, hipStream_t s);      // ... fp16 mode
 void launch_f32_to_bf16x3_staged(const float* in, unsigned short* out, int CoutPad, int Kpad, hipStream_t s);   // conv_kg.hip's layout
 void launch_probe_placement(int* d_out, int blocks, hipStream_t s);
 

@@ -326,7 +326,7 @@ static constexpr bool BP_ABL_MFMA = false;
 // its columns (32 KB instead of 20 KB per chunk through the vector-memory path, which has the room).
 template <int TM, int TN, int NP, bool BD = false>
 __global__ __launch_bounds__(256) void conv_igemm_h_kernel(const ConvParams p) {
-    static_assert(!BD || (NP == 3 && TM == 1 && TN == 1), "filters-direct variant: bf16x3, 64x64 tile");
+    static_assert(!BD || (TM == 1 && TN == 1), "filters-direct variant: 64x64 tile");
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int RA = BM / 64;          // fp32 A rows per thread (8 consecutive floats each: two 16-B loads, one 16-B LDS store per plane)
     constexpr int RBH = BN / 64;         // 16-bit B rows per thread and plane (8 elements each)
@@ -648,6 +648,10 @@ void launch_conv(const ConvParams& p, int tile, hipStream_t s) {
         launch_conv_rd(p, tile, s);
     } else if (p.mfma_mode == PREC_F16 && conv_h16_eligible(p)) {
         switch (tile) {
+            case TILE_64x64_BD:
+                BP_CHECK(p.w16s != nullptr, "filters-direct tile needs the stage-packed filter copy");
+                launch_h_t<1, 1, 1, true>(p, s);
+                break;
             case TILE_128x64: launch_h_t<2, 1, 1>(p, s); break;
             default: launch_h_t<1, 1, 1>(p, s); break;
         }

@@ -140,6 +140,8 @@ static const PlanEntry kPlanB3[] = {
     { 43264,    64,    9, TILE_64x64_BD,  1},
     {     0,     0,    0, TILE_64x64_BD,  0},
 };
+// (fp16, batch 1: the filters-direct variant wins 40 of 47 shapes alone by 4.5 % in the sum, profiles/r02_tune_f16.txt, and
+// LOSES in the pipeline -- 1 329 against 1 381 frames/s, A/B on one box -- so the batch-1 rows stay on the staged kernel)
 static const PlanEntry kPlanF16[] = {
     {    80,   512,   64, 0,  5},
     {    80,   512,  144, 0,  6},
@@ -180,14 +182,14 @@ static const PlanEntry kPlanF16[] = {
     { 10816,   128,   18, 0,  1},
     { 43264,    64,    2, 0,  1},
     { 43264,    64,    9, 0,  1},
-    // batch 28 (BASELINE configs[2]; profiles/r02_tune_f16_batch28.txt, with the 128x64 block among the candidates)
+    // batch 28 (BASELINE configs[2]; profiles/r02_tune_f16_batch28.txt, with the 128x64 block and the filters-direct kernel among the candidates)
     {  2240,   512,   64, 1,  1},
     {  2240,   512,  144, 1,  1},
     {  2240,  2048,   16, 0,  1},
     {  2240,  2048,   32, 0,  1},
-    {  4732,    64,   32, 0,  1},
-    {  4732,   256,   16, 0,  1},
-    {  4732,   512,   32, 6,  1},
+    {  4732,    64,   32, 12,  1},
+    {  4732,   256,   16, 1,  1},
+    {  4732,   512,   32, 12,  1},
     {  4732,  1024,  144, 1,  1},
     {  8960,   256,   32, 6,  1},
     {  8960,   256,   72, 6,  1},
@@ -212,13 +214,13 @@ static const PlanEntry kPlanF16[] = {
     { 75712,   256,   36, 6,  1},
     {143360,    64,    2, 0,  1},
     {143360,    64,    8, 0,  1},
-    {143360,    64,   18, 0,  1},
-    {143360,    64,   36, 0,  1},
+    {143360,    64,   18, 12,  1},
+    {143360,    64,   36, 12,  1},
     {143360,   128,    8, 6,  1},
     {143360,   256,    2, 0,  1},
     {302848,    64,    4, 0,  1},
     {302848,   128,   18, 6,  1},
-    {1211392,    64,    2, 0,  1},
+    {1211392,    64,    2, 12,  1},
     {1211392,    64,    9, 1,  1},
     {0, 0, 0, 0, 0},
 };
@@ -406,12 +408,15 @@ void Net::set_precision(int prec) {
             }
             c.w16 = it->second;
             c.w16s = nullptr;
-            if (prec == PREC_BF16X3) {
-                auto is = store_->bf16x3s.find(c.w);
-                if (is == store_->bf16x3s.end()) {
-                    unsigned short* d = (unsigned short*)store_->arena.alloc_bytes((size_t)3 * c.CoutPad * c.Kpad * sizeof(unsigned short));
-                    launch_f32_to_bf16x3_staged(c.w, d, c.CoutPad, c.Kpad, nullptr);
-                    is = store_->bf16x3s.emplace(c.w, d).first;
+            {
+                auto& staged = prec == PREC_F16 ? store_->f16s : store_->bf16x3s;
+                auto is = staged.find(c.w);
+                if (is == staged.end()) {
+                    const size_t planes = prec == PREC_F16 ? 1 : 3;
+                    unsigned short* d = (unsigned short*)store_->arena.alloc_bytes(planes * c.CoutPad * c.Kpad * sizeof(unsigned short));
+                    if (prec == PREC_F16) launch_f32_to_f16_staged(c.w, d, c.CoutPad, c.Kpad, nullptr);
+                    else launch_f32_to_bf16x3_staged(c.w, d, c.CoutPad, c.Kpad, nullptr);
+                    is = staged.emplace(c.w, d).first;
                     made = true;
                 }
                 c.w16s = is->second;

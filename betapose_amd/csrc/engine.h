@@ -60,7 +60,8 @@ struct WeightStore {
     std::vector<float*> ptrs;
     std::map<const float*, unsigned short*> f16;      // fp16 copies of packed filters, made on first use
     std::map<const float*, unsigned short*> bf16x3;   // three bf16 planes per filter (PREC_BF16X3)
-    std::map<const float*, unsigned short*> bf16x3s;  // ... and their stage-packed copy (conv_kg.hip)
+    std::map<const float*, unsigned short*> bf16x3s;  // ... and their stage-packed copy (filters-direct kernels, conv_kg/rd.hip)
+    std::map<const float*, unsigned short*> f16s;     // stage-packed fp16 copy
     std::mutex f16_mutex;
 };
 

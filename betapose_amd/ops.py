@@ -13,7 +13,7 @@ from . import _lib
 ACT = {"linear": 0, "leaky": 1, "relu": 2}
 STORE = {"nhwc": 0, "up2": 1, "pixshuf": 2, "nchw": 3}
 # +16: fp16 operands, +32: bf16x3 (fp32-accurate) operands; w<WM>x<WN> = conv_w64.hip with WM x WN waves of 64x64
-TILE = {"auto": -1, "64x64": 0, "128x64": 1, "64x64_f16": 16, "128x64_f16": 17, "64x64_b3": 32, "bd_b3": 32 + 12}
+TILE = {"auto": -1, "64x64": 0, "128x64": 1, "64x64_f16": 16, "128x64_f16": 17, "64x64_b3": 32, "bd_b3": 32 + 12, "bd_f16": 16 + 12}
 for _n, _i in (("w1x1", 2), ("w1x2", 3), ("w2x1", 5), ("w2x2", 6)):
     TILE[_n + "_f16"] = 16 + _i
     TILE[_n + "_b3"] = 32 + _i

@@ -338,7 +338,8 @@ def test_conv_kg_full_size_layers(cuda):
 
 @pytest.mark.parametrize("case", F16_CASES)
 @pytest.mark.parametrize("splits", [1, 3])
-def test_conv_filters_direct_is_bit_identical_to_the_staged_kernel(cuda, case, splits):
+@pytest.mark.parametrize("mode", ["b3", "f16"])
+def test_conv_filters_direct_is_bit_identical_to_the_staged_kernel(cuda, case, splits, mode):
     """The filters-direct variant (filter fragments global -> registers from the stage-packed copy) feeds the MFMAs the
     same operands in the same order as the LDS-staged bf16x3 kernel: the two data paths must agree bit for bit."""
     N, H, W, Cin, Cout, k, st, pad, act = case
@@ -348,6 +349,6 @@ def test_conv_filters_direct_is_bit_identical_to_the_staged_kernel(cuda, case, s
     x = (torch.randn(N, H, W, Cin, generator=g) * torch.exp(2 * torch.randn(N, H, W, 1, generator=g))).to(cuda)
     w = torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k)
     b = torch.randn(Cout, generator=g)
-    a1 = ops.conv2d_nhwc(x, w, b, stride=st, pad=pad, act=act, tile="bd_b3", splits=splits)
-    a2 = ops.conv2d_nhwc(x, w, b, stride=st, pad=pad, act=act, tile="64x64_b3", splits=splits)
+    a1 = ops.conv2d_nhwc(x, w, b, stride=st, pad=pad, act=act, tile="bd_" + mode, splits=splits)
+    a2 = ops.conv2d_nhwc(x, w, b, stride=st, pad=pad, act=act, tile="64x64_" + mode, splits=splits)
     assert torch.equal(a1, a2)

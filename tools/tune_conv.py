@@ -48,7 +48,7 @@ add(20, 16, 512, 1024, 3, 1); add(40, 32, 256, 512, 3, 1); add(80, 64, 128, 50, 
 F16 = "--f16" in sys.argv          # tune the fp16-operand kernels instead of the bf16x3 (fp32-accurate) ones
 FP32 = "--fp32" in sys.argv        # ... or the fp32-MFMA kernel (64x64 tile, slices only)
 SUF = "_f16" if F16 else "_b3"
-TILES = ["64x64"] if FP32 else ["64x64" + SUF, "w1x1" + SUF, "w1x2" + SUF, "w2x1" + SUF, "w2x2" + SUF] + (["128x64_f16"] if F16 else ["bd_b3"])
+TILES = ["64x64"] if FP32 else ["64x64" + SUF, "w1x1" + SUF, "w1x2" + SUF, "w2x1" + SUF, "w2x2" + SUF] + (["128x64_f16", "bd_f16"] if F16 else ["bd_b3"])
 if "--kg" in sys.argv:             # batch-1 candidates only: the 64x64-block kernel against the K-group kernels
     TILES = ["64x64_b3", "bd_b3", "kg2_b3", "rd4_b3"]
 TILE_ID = {"64x64": 0, "128x64": 1, "w1x1": 2, "w1x2": 3, "w2x1": 5, "w2x2": 6, "kg1": 7, "kg2": 8, "kg4": 9, "rd4": 10, "rd8": 11, "bd": 12}
