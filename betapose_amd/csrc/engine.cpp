@@ -127,7 +127,7 @@ static const PlanEntry kPlanB3[] = {
     {  2704,    64,    8, TILE_64x64_BD,  1},
     {  2704,   128,    8, TILE_64x64_BD,  1},
     {  2704,   128,   12, TILE_64x64_BD,  1},
-    {  2704,   256,   36, TILE_64x64_BD,  4},
+    {  2704,   256,   36, TILE_64x64_BD,  2},   // in the pipeline: 2 slices 933, 3: 929, 4: 921, 5+: 910 frames/s (tools/tune_splits_insitu.py)
     {  5120,    64,    2, TILE_64x64_BD,  1},
     {  5120,    64,    8, TILE_64x64_BD,  1},
     {  5120,    64,   18, TILE_64x64_BD,  3},

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Greedy in-situ tuning of the K-slice counts: for the conv shapes that occur most often, try neighbouring slice counts
+in the WHOLE 4-frames-in-flight pipeline (BP_PLAN_FILE, no rebuild) and keep a change only when frames/s improve by more
+than the run-to-run noise.  A kernel timed alone prefers fewer slices than the pipeline does.
+    python tools/tune_splits_insitu.py            # prints the accepted changes and the final plan lines"""
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = open(os.path.join(ROOT, "betapose_amd", "csrc", "engine.cpp")).read()
+a = src.index("static const PlanEntry kPlanB3[] = {")
+rows = re.findall(r"\{\s*(\d+),\s*(\d+),\s*(\d+),\s*TILE_64x64_BD,\s*(\d+)\}", src[a:src.index("};", a)])
+plan = {(int(M), int(cp), int(n)): int(s) for M, cp, n, s in rows if int(M)}
+CLASSES = [(320, 256, 72), (320, 256, 32), (320, 1024, 8), (2704, 256, 36), (2704, 128, 8), (676, 512, 72), (676, 256, 16),
+           (169, 1024, 144), (169, 512, 32), (1280, 128, 36), (1280, 128, 16), (5120, 64, 18)]
+
+
+def fps(p, steps=400):
+    with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as f:
+        for (M, cp, n), s in p.items():
+            f.write("%d %d %d 12 %d\n" % (M, cp, n, s))
+    env = dict(os.environ, BP_PLAN_FILE=f.name)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "40", "--no-side-runs",
+                          "--no-cpu-baseline", "--no-roofline", "--other-modes", ""], capture_output=True, text=True, env=env).stdout
+    os.unlink(f.name)
+    return json.loads(out.strip().splitlines()[-1])["value"]
+
+
+base = max(fps(plan), fps(plan))
+print("baseline %.1f frames/s" % base, flush=True)
+for key in CLASSES:
+    if key not in plan:
+        continue
+    s0 = plan[key]
+    nch = key[2]
+    cands = sorted({max(1, s0 - 2), max(1, s0 - 1), s0 + 1, s0 + 2, min(16, s0 * 2)} - {s0})
+    best_s, best = s0, base
+    for s in cands:
+        if s > 1 and nch // s < 2:
+            continue
+        trial = dict(plan); trial[key] = s
+        v = fps(trial)
+        print("  %s: %d -> %d slices: %.1f" % (key, s0, s, v), flush=True)
+        if v > best * 1.008:
+            v2 = fps(trial)                       # confirm
+            if v2 > best * 1.005:
+                best_s, best = s, min(v, v2)
+    if best_s != s0:
+        plan[key] = best_s
+        base = best
+        print("ACCEPT %s: %d -> %d slices, now %.1f frames/s" % (key, s0, best_s, base), flush=True)
+print("final %.1f frames/s" % base)
+for (M, cp, n), s in sorted(plan.items()):
+    print("    {%6d, %5d, %4d, TILE_64x64_BD, %2d}," % (M, cp, n, s))
