@@ -5,8 +5,9 @@
 // CUDA backend, train_YOLO/src/convolutional_kernels.cu:121-383, and the torch Conv2d/BatchNorm2d/ReLU modules of
 // yolo/darknet.py:240-259 and KPD/src/models/layers/SE_Resnet.py:25-42).  What it is for: at batch 1 a layer has 24-172
 // output tiles of 64x64 for 256 CUs, so K has to be cut to fill the chip -- and cutting it ACROSS blocks costs more
-// than the K loop saves (measured, profiles/r02_ablate_pipeline.txt: slab write-through + ticket + read-back + the
-// epilogue are 7.5 us against 12 us of K loop, and the slabs are a third of the frame's HBM traffic).  Here a block is
+// than the K loop saves (measured, profiles/r02_w64_stage_ablation.txt: slab write-through + ticket + read-back + the
+// epilogue are 7.5 us against 12 us of K loop; profiles/r02_ablate_pipeline.txt: 16 % of the frame; and the slabs are a
+// third of the frame's HBM traffic).  Here a block is
 // G groups of 4 waves; every group runs the 64x64 tile over its own K range with its own LDS stages, and the partial
 // sums meet in LDS: no slab, no ticket, one epilogue per tile.  Cross-block slices (p.splits) stay available for the
 // layers with too few tiles even so and go through the shared tail (conv_tail.inc) from group 0.

@@ -138,7 +138,7 @@ static const PlanEntry kPlanB3[] = {
     { 10816,   128,   18, TILE_64x64_BD,  2},
     { 43264,    64,    2, TILE_64x64_BD,  1},
     { 43264,    64,    9, TILE_64x64_BD,  1},
-    {     0,     0,    0, TILE_64x64_BD,  0},
+    {0, 0, 0, 0, 0},
 };
 // (fp16, batch 1: the filters-direct variant wins 40 of 47 shapes alone by 4.5 % in the sum, profiles/r02_tune_f16.txt, and
 // LOSES in the pipeline -- 1 329 against 1 381 frames/s, A/B on one box -- so the batch-1 rows stay on the staged kernel)
