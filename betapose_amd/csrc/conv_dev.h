@@ -125,15 +125,20 @@ __device__ __forceinline__ int fast_div(int m, int d, float rcp) {
 // switches once per block): RES 0 none, 1 add before the activation (ResNet), 2 add after it (YOLO shortcut).
 // Output and residual go through raw buffer descriptors whose range ends at row M, so rows past the tensor are dropped
 // by the hardware -- no per-pass branch.
-template <int ACT, int RES>
-__device__ __forceinline__ void epilogue_rows(const float* srow, int s_step, int passes, f32x4 bias4,
+template <int ACT, int RES, int PASSES, int PF>
+__device__ __forceinline__ void epilogue_rows(const float* srow, int s_step, f32x4 bias4,
                                               __amdgpu_buffer_rsrc_t rsrcO, unsigned off_o, unsigned step_o,
-                                              __amdgpu_buffer_rsrc_t rsrcR, unsigned off_r, unsigned step_r) {
-#pragma unroll 4
-    for (int pass = 0; pass < passes; ++pass) {
+                                              __amdgpu_buffer_rsrc_t rsrcR, unsigned off_r, unsigned step_r, const f32x4* rpre) {
+    // PF: the residual rows were requested before the tile was staged (rpre[pass], registers): a cold 16-B load costs the
+    // block > 1 us at the very end of the kernel otherwise
+#pragma unroll
+    for (int pass = 0; pass < PASSES; ++pass) {
         f32x4 v = *reinterpret_cast<const f32x4*>(srow);
         f32x4 r4 = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (RES != 0) r4 = buf_load4(rsrcR, off_r, 0);
+        if constexpr (RES != 0) {
+            if constexpr (PF) r4 = rpre[pass];
+            else r4 = buf_load4(rsrcR, off_r, 0);
+        }
         v += bias4;
         if constexpr (RES == 1) v += r4;
         if constexpr (ACT == ACT_LEAKY) {

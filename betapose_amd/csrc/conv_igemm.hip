@@ -485,6 +485,9 @@ __global__ __launch_bounds__(256) void conv_igemm_h_kernel(const ConvParams p) {
         }                                                                                              \
     }
 
+    // the epilogue's bias (4 consecutive channels per thread, conv_tail.inc) is requested before the K loop: at the
+    // block's end it would be a cold load of > 1 us on the critical path (the array is padded to CoutPad)
+    const f32x4 bias_early = *reinterpret_cast<const f32x4*>(p.bias + min(n0 + (tid % (BN / 4)) * 4, p.CoutPad - 4));
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -561,8 +564,10 @@ __global__ __launch_bounds__(256) void conv_igemm_h_kernel(const ConvParams p) {
     __shared__ int s_last;
 #define BP_NT 256
 #define BP_SLAST s_last
+#define BP_EARLY_BIAS bias_early
 #define BP_TAIL_STAMP(k_)
 #include "conv_tail.inc"
+#undef BP_EARLY_BIAS
 #undef BP_TAIL_STAMP
 #undef BP_NT
 #undef BP_SLAST
