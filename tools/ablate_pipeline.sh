@@ -5,7 +5,7 @@
 mkdir -p gpurun_out
 out=gpurun_out/ablate_pipeline.txt
 : > $out
-variants=("" "-DBP_ABLATE_TAIL" "-DBP_ABLATE_KLOOP" "-DBP_ABLATE_TAIL -DBP_ABLATE_KLOOP" "-DBP_ABLATE_SPLIT" "-DBP_ABLATE_MFMA" "-DBP_ABLATE_SPLIT -DBP_ABLATE_MFMA" "-DBP_ABLATE_PREFETCH" "-DBP_ABLATE_EPILOGUE" "-DBP_ABLATE_ACKWAIT")
+variants=("" "-DBP_ABLATE_TAIL" "-DBP_ABLATE_KLOOP" "-DBP_ABLATE_TAIL -DBP_ABLATE_KLOOP" "-DBP_ABLATE_SPLIT" "-DBP_ABLATE_MFMA" "-DBP_ABLATE_SPLIT -DBP_ABLATE_MFMA" "-DBP_ABLATE_PREFETCH" "-DBP_ABLATE_EPILOGUE" "-DBP_ABLATE_ACKWAIT" "-DBP_ABLATE_SLABSTORE" "-DBP_ABLATE_REDUCE")
 for v in "${variants[@]}"; do
   BP_CFLAGS="$v" python -m betapose_amd.build --force > /dev/null 2>&1 || { echo "build failed: $v" >> $out; continue; }
   for st in 4 1; do
