@@ -11,7 +11,9 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbetapose_hip.so")
+# BP_LIB: an alternative build of the same library (tools only: `python -m betapose_amd.build --experimental` makes
+# libbetapose_hip_exp.so with the measured-and-rejected kernels and the timing ablations compiled in)
+LIB_PATH = os.environ.get("BP_LIB") or os.path.join(_HERE, "libbetapose_hip.so")
 _lock = threading.Lock()
 _lib = None
 
@@ -58,6 +60,8 @@ PROTOTYPES = {
     "bp_resize_bicubic": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "bp_conv2d": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
                             C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, c_float_p, vp]),
+    "bp_conv2d_planes": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, c_float_p, vp]),
     "bp_pipeline_create": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, vp, vp, vp, C.POINTER(vp)]),
     "bp_pipeline_kernel_count": (C.c_int, [vp]),
     "bp_yolo_profile": (C.c_int, [vp, C.c_int, C.c_int, c_float_p, c_int_p, C.c_int, vp]),

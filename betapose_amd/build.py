@@ -12,13 +12,13 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbetapose_hip.so")
-SOURCES = ["conv_igemm.hip", "conv_w64.hip", "conv_kg.hip", "conv_rd.hip", "aux_kernels.hip", "engine.cpp", "host_post.cpp", "frame_io.cpp", "jpeg_bmp.cpp", "c_api.cpp", "darknet_compat.cpp"]
+SOURCES = ["conv_igemm.hip", "conv_pl.hip", "conv_w64.hip", "conv_kg.hip", "conv_rd.hip", "aux_kernels.hip", "engine.cpp", "host_post.cpp", "frame_io.cpp", "jpeg_bmp.cpp", "c_api.cpp", "darknet_compat.cpp"]
 HEADERS = ["bp_common.h", "engine.h", "frame_io.h", "conv_tail.inc", "conv_dev.h", os.path.join("..", "..", "include", "betapose_hip.h"),
            os.path.join("..", "..", "include", "yolo_v2_class_compat.h")]
 ARCH = "gfx950"
 # Host launch stubs every HIP object must export.  hipcc has been seen to drop a kernel's host stub SILENTLY (the object
 # links, the launch then fails at run time) -- DESIGN.md §3.1d -- so the build counts them.
-MIN_STUBS = {"conv_igemm.hip": 11, "conv_w64.hip": 8, "conv_kg.hip": 3, "conv_rd.hip": 2, "aux_kernels.hip": 19}
+MIN_STUBS = {"conv_igemm.hip": 11, "conv_pl.hip": 11, "conv_w64.hip": 8, "conv_kg.hip": 3, "conv_rd.hip": 2, "aux_kernels.hip": 19}
 
 
 def hipcc() -> str:
@@ -36,18 +36,25 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, experimental: bool = False) -> str:
+    """experimental: -DBP_EXPERIMENTAL into libbetapose_hip_exp.so (never loaded by the product: _lib.py BP_LIB)."""
+    if experimental:
+        return _build(True, verbose, os.path.join(HERE, "libbetapose_hip_exp.so"), os.path.join(HERE, "build_exp"),
+                      ["-DBP_EXPERIMENTAL"])
     if not force and not _stale():
         return LIB
+    return _build(force, verbose, LIB, os.path.join(HERE, "build"), [])
+
+
+def _build(force: bool, verbose: bool, LIB: str, objdir: str, extra) -> str:
     cc = hipcc()
     objs = []
-    objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     procs = []
     for src in SOURCES:
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         cmd = [cc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c",
-               os.path.join(CSRC, src), "-o", obj] + os.environ.get("BP_CFLAGS", "").split()
+               os.path.join(CSRC, src), "-o", obj] + list(extra) + os.environ.get("BP_CFLAGS", "").split()
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -73,4 +80,4 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, experimental="--experimental" in sys.argv))

@@ -69,6 +69,17 @@ struct ConvParams {
     const unsigned short* w16s;  // the same operands stage-packed (aux_kernels.hip): filters-direct kernels, conv_kg.hip, conv_rd.hip
     int mfma_mode;         // Precision the launch uses (PREC_F16 / PREC_BF16X3 need w16 and an eligible layer)
     unsigned long long* stamps;   // debug (tools/bench_conv.py --stamps): per-block s_memtime marks, null in production
+    // ---- operand planes (conv_pl.hip).  A tensor's planes MIRROR its fp32 view: element (pixel, c) of plane pl lives at
+    // planes + pl * plane_elems + pixel * ld + c (same ld as the fp32 view, 2 bytes per element): three bf16 planes with
+    // x == p0 + p1 + p2 exactly (PREC_BF16X3) or one fp16 plane (PREC_F16).  They are written by the PRODUCER's epilogue
+    // (every conv kernel through conv_tail.inc, the pooling / shuffle kernels) and fetched by LDS-DMA in the consumer.
+    const unsigned short* in16;   // planes of `in` (null: the layer runs on a kernel that reads fp32 activations)
+    long long in16_plane;         // elements between planes
+    unsigned short* out16;        // planes of `out` (null: not emitted)
+    long long out16_plane;
+    int out_np;                   // planes the epilogue emits: 0 none, 1 fp16, 3 bf16x3
+    int abl;                      // timing ablations, experimental builds only (-DBP_EXPERIMENTAL; tools/abl_pl.sh): 0 in the product
+    const unsigned short* wpl;    // filters as conv_pl.hip's LDS image: [CoutPad/64][nchunks][plane][64 rows][64 B swizzled]
 };
 
 // tile configuration ids for launch_conv
@@ -82,7 +93,13 @@ enum ConvTile : int { TILE_64x64 = 0, TILE_128x64 = 1, TILE_W64_1x1 = 2, TILE_W6
                       // TILE_RD<W>: conv_rd.hip, one wave per 64x64 tile and K range, W K ranges per block, no LDS stage (bf16x3)
                       TILE_RD4 = 10, TILE_RD8 = 11,
                       // conv_igemm.hip's 64x64-block bf16x3 kernel with the filter fragments fetched straight into registers
-                      TILE_64x64_BD = 12, TILE_LAST = 12 };
+                      TILE_64x64_BD = 12,
+                      // conv_pl.hip: both operands by LDS-DMA from 16-bit planes, <block tile>, waves x wave tile
+                      TILE_PL64 = 13,       // 64x64, 2x2 waves of 32x32
+                      TILE_PL128 = 14,      // 128x128, 2x2 waves of 64x64
+                      TILE_PL128x64 = 15,   // 128x64, 2x2 waves of 64x32
+                      TILE_PL256x128 = 16,  // 256x128, 4x2 waves of 64x64
+                      TILE_LAST = 16 };
 
 // when non-null, launch_conv brackets the implicit-GEMM kernel itself (not the split-K reduce) with these events
 struct ConvProfHook { hipEvent_t e0, e1; };
@@ -97,6 +114,14 @@ void launch_conv_kg(const ConvParams& p, int tile, hipStream_t s);    // conv_kg
 bool conv_tile_is_kg(int tile);
 void launch_conv_rd(const ConvParams& p, int tile, hipStream_t s);    // conv_rd.hip
 bool conv_tile_is_rd(int tile);
+void launch_conv_pl(const ConvParams& p, int tile, hipStream_t s);    // conv_pl.hip
+bool conv_tile_is_pl(int tile);
+bool conv_pl_eligible(const ConvParams& p);   // planes + wpl present, Cin % 32 == 0, taps fit the 32-bit mask
+// filters [CoutPad][Kpad] fp32 -> conv_pl.hip's LDS image, np = 1 (fp16) or 3 (exact bf16 split)
+void launch_pack_wpl(const float* in, unsigned short* out, int CoutPad, int Kpad, int np, hipStream_t s);
+// fp32 NHWC view -> its operand planes (producers that are not convolutions; tests)
+void launch_f32_to_planes(const float* in, int ld, long long pixels, int C, unsigned short* planes, long long plane_elems,
+                          int np, hipStream_t s);
 int conv_tiles(const ConvParams& p, int tile);   // blocks per K-slice
 int conv_tile_bm(int tile);
 int conv_tile_bn(int tile);

@@ -425,6 +425,13 @@ int bp_heatmap_argmax(const float* d_hm, int batch, int C, int H, int W, float* 
 int bp_conv2d(const float* d_in, int N, int H, int W, int Cin, const float* h_w, const float* h_bias, int Cout, int k,
               int stride, int pad, int act, int store_mode, const float* d_res, int res_after_act, int tile, int splits,
               float* d_out, int iters, float* ms_per_iter, void* stream) {
+    return bp_conv2d_planes(d_in, N, H, W, Cin, h_w, h_bias, Cout, k, stride, pad, act, store_mode, d_res, res_after_act, tile,
+                            splits, d_out, nullptr, iters, ms_per_iter, stream);
+}
+
+int bp_conv2d_planes(const float* d_in, int N, int H, int W, int Cin, const float* h_w, const float* h_bias, int Cout, int k,
+                     int stride, int pad, int act, int store_mode, const float* d_res, int res_after_act, int tile, int splits,
+                     float* d_out, unsigned short* d_out_planes, int iters, float* ms_per_iter, void* stream) {
     BP_TRY
     BP_CHECK(d_in && h_w && d_out, "null argument");
     hipStream_t s = (hipStream_t)stream;
@@ -446,17 +453,42 @@ int bp_conv2d(const float* d_in, int N, int H, int W, int Cin, const float* h_w,
     net.add_conv("conv", in, out, cw, Cout, k, stride, pad, act, store_mode, d_res ? &res : nullptr, nullptr,
                  res_after_act, 1e-5f, OH, OW);
     int t = tile;
-    if (t >= 16) {   // +16: fp16-MFMA operands, +32: bf16x3 split operands
-        const int prec = t >= 32 ? bp::PREC_BF16X3 : bp::PREC_F16;
-        t -= t >= 32 ? 32 : 16;
+    int prec = bp::PREC_F32;
+    if (t >= 256) {   // + 256: fp16-MFMA operands, + 512: bf16x3 split operands
+        prec = t >= 512 ? bp::PREC_BF16X3 : bp::PREC_F16;
+        t -= t >= 512 ? 512 : 256;
         net.set_precision(prec);
         BP_CHECK(net.ops_[0].conv.mfma_mode == prec, "layer is not eligible for the 16-bit MFMA paths (needs Cin % 32 == 0)");
     } else {
-        BP_CHECK(!bp::conv_tile_is_w64(t) && !bp::conv_tile_is_kg(t) && !bp::conv_tile_is_rd(t) && t != bp::TILE_64x64_BD, "w64 / K-group / register-direct tiles need a 16-bit precision mode (tile + 16 / + 32)");
+        BP_CHECK(t <= bp::TILE_128x64, "this tile needs a 16-bit precision mode (tile + 256 / + 512)");
     }
     bp::ConvParams p = net.ops_[0].conv;
     p.N = N; p.M = N * OH * OW;
     if (t < 0) t = bp::TILE_64x64;
+    const int np = prec == bp::PREC_F16 ? 1 : 3;
+    if (bp::conv_tile_is_pl(t)) {
+        // the caller's activations are fp32: their operand planes are made here, as the layer's producer would have
+        const long long in_elems = (long long)N * H * W * Cin;
+        BP_CHECK(Cin % 32 == 0 && k * k <= 32, "layer is not eligible for the operand-plane kernels (needs Cin % 32 == 0, k*k <= 32)");
+        unsigned short* d_in16 = (unsigned short*)net.arena_.alloc_bytes((size_t)np * in_elems * 2);
+        bp::launch_f32_to_planes(d_in, Cin, (long long)N * H * W, Cin, d_in16, in_elems, np, s);
+        p.in16 = d_in16; p.in16_plane = in_elems;
+        auto& packed = np == 1 ? net.weight_store()->wpl1 : net.weight_store()->wpl3;
+        auto it = packed.find(p.w);
+        if (it == packed.end()) {
+            unsigned short* d = (unsigned short*)net.weight_store()->arena.alloc_bytes((size_t)np * p.CoutPad * p.Kpad * 2);
+            bp::launch_pack_wpl(p.w, d, p.CoutPad, p.Kpad, np, s);
+            it = packed.emplace(p.w, d).first;
+        }
+        p.wpl = it->second;
+    }
+    if (const char* e = std::getenv("BP_PL_ABL")) p.abl = std::atoi(e);   // (read by experimental builds only)
+    if (d_out_planes) {   // the epilogue's operand planes of the output (any kernel): [np][the output tensor's elements]
+        BP_CHECK(prec != bp::PREC_F32, "output planes need a 16-bit precision mode");
+        long long out_elems = (long long)N * OH * OW * Cout;
+        if (store_mode == bp::ST_UP2) out_elems *= 4;
+        p.out16 = d_out_planes; p.out16_plane = out_elems; p.out_np = np;
+    }
     int sp = splits;
     if (sp <= 0) {
         const long long blocks = bp::conv_tiles(p, t);
@@ -504,7 +536,7 @@ int bp_conv2d(const float* d_in, int N, int H, int W, int Cin, const float* h_w,
                          sum[0] / stages, sum[1] / stages, sum[2] / stages, sum[3] / stages);
         }
         std::fprintf(stderr, "[stamps] blocks=%d  mean cycles since the block's entry: index math done %.0f | chunk 0 in LDS %.0f | "
-                     "K loop done %.0f | in-block sums %.0f | slab parked + ticket %.0f (%d blocks) | slices combined %.0f (%d) | stores done %.0f (%d) | "
+                     "K loop done %.0f | in-block sums (conv_kg) or cycles parked at the stage waits (conv_pl) %.0f | slab parked + ticket %.0f (%d blocks) | slices combined %.0f (%d) | stores done %.0f (%d) | "
                      "last mark of the grid %.0f after the first entry\n", nb, mean(1), mean(2), mean(3), mean(7), mean(5), cnt[5], mean(6),
                      cnt[6], mean(4), cnt[4], last);
     }

@@ -27,9 +27,70 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // native vector types: they stay in VGPRs (HIP's float4 struct made hipcc park the prefetch registers in scratch)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
 static constexpr int BK = 32;
 static constexpr int LDS_LD = 36;
 static constexpr unsigned OOB = 0x7fffff00u;   // byte offset beyond any descriptor's num_records -> load returns 0
+
+// ---- operand planes of an output (ConvParams::out16): what the NEXT convolution's matrix cores consume, written by
+// the producer so that no consumer converts or splits anything (the reference's half path converts the activations
+// too: train_YOLO/src/convolutional_kernels.cu:87,98,268-280 cuda_f32_to_f16 -> fp16 conv -> cuda_f16_to_f32).
+//   np == 1: one fp16 plane (RNE);  np == 3: three bf16 planes with x == p0 + p1 + p2 exactly (8 + 8 + 8 significand bits)
+struct PlaneDesc {
+    __amdgpu_buffer_rsrc_t r0, r1, r2;   // one descriptor per plane, each ending at row M: rows past the tensor are dropped
+    int np;
+};
+__device__ __forceinline__ PlaneDesc make_plane_desc(const ConvParams& p) {
+    PlaneDesc d;
+    unsigned short* base = p.out16 ? p.out16 : reinterpret_cast<unsigned short*>(p.out);
+    const int bytes = (int)min((long long)p.M * p.out_ld * 2, (long long)0x7fffff00);
+    d.np = p.out16 ? p.out_np : 0;
+    d.r0 = __builtin_amdgcn_make_buffer_rsrc(base, 0, bytes, 0x00020000);
+    d.r1 = __builtin_amdgcn_make_buffer_rsrc(base + (d.np == 3 ? p.out16_plane : 0), 0, bytes, 0x00020000);
+    d.r2 = __builtin_amdgcn_make_buffer_rsrc(base + (d.np == 3 ? 2 * p.out16_plane : 0), 0, bytes, 0x00020000);
+    return d;
+}
+// four consecutive channels of one pixel -> 8 B per plane at byte offset `off` (= element index * 2)
+__device__ __forceinline__ void emit_planes4(const PlaneDesc& d, f32x4 v, unsigned off) {
+    if (d.np == 1) {
+        const f16x4 h = __builtin_convertvector(v, f16x4);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h), d.r0, (int)off, 0, 0);
+    } else if (d.np == 3) {
+        const bf16x4 h1 = __builtin_convertvector(v, bf16x4);
+        const f32x4 r1 = v - __builtin_convertvector(h1, f32x4);
+        const bf16x4 h2 = __builtin_convertvector(r1, bf16x4);
+        const f32x4 r2 = r1 - __builtin_convertvector(h2, f32x4);
+        const bf16x4 h3 = __builtin_convertvector(r2, bf16x4);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h1), d.r0, (int)off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h2), d.r1, (int)off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h3), d.r2, (int)off, 0, 0);
+    }
+}
+// one element (store modes / alignments the 16-B path does not cover); idx = element index inside the output view
+__device__ __forceinline__ void emit_plane1(const ConvParams& p, long long idx, float v) {
+    if (!p.out16) return;
+    if (p.out_np == 1) {
+        const _Float16 h = (_Float16)v;
+        p.out16[idx] = __builtin_bit_cast(unsigned short, h);
+    } else if (p.out_np == 3) {
+        const __bf16 h1 = (__bf16)v;
+        const float r1 = v - (float)h1;
+        const __bf16 h2 = (__bf16)r1;
+        const float r2 = r1 - (float)h2;
+        const __bf16 h3 = (__bf16)r2;
+        p.out16[idx] = __builtin_bit_cast(unsigned short, h1);
+        p.out16[idx + p.out16_plane] = __builtin_bit_cast(unsigned short, h2);
+        p.out16[idx + 2 * p.out16_plane] = __builtin_bit_cast(unsigned short, h3);
+    }
+}
 
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == ACT_LEAKY) return v > 0.f ? v : 0.1f * v;
@@ -60,22 +121,30 @@ __device__ __forceinline__ void epilogue_store(const ConvParams& p, int m, int n
     switch (p.store_mode) {
         case ST_NHWC:
             p.out[(long long)m * p.out_ld + n] = v;
+            emit_plane1(p, (long long)m * p.out_ld + n, v);
             break;
         case ST_UP2: {
             const int oy = pix / p.OW, ox = pix - oy * p.OW;
             const int W2 = 2 * p.OW;
-            float* o = p.out + ((long long)(b * 2 * p.OH + 2 * oy) * W2 + 2 * ox) * p.out_ld + n;
+            const long long i0 = ((long long)(b * 2 * p.OH + 2 * oy) * W2 + 2 * ox) * p.out_ld + n;
+            float* o = p.out + i0;
             o[0] = v;
             o[p.out_ld] = v;
             o[(long long)W2 * p.out_ld] = v;
             o[(long long)(W2 + 1) * p.out_ld] = v;
+            emit_plane1(p, i0, v);
+            emit_plane1(p, i0 + p.out_ld, v);
+            emit_plane1(p, i0 + (long long)W2 * p.out_ld, v);
+            emit_plane1(p, i0 + (long long)(W2 + 1) * p.out_ld, v);
         } break;
         case ST_PIXSHUF: {
             const int oy = pix / p.OW, ox = pix - oy * p.OW;
             const int cq = p.Cout >> 2;
             const int ij = n / cq, c = n - ij * cq;
             const int y = 2 * oy + (ij >> 1), x = 2 * ox + (ij & 1);
-            p.out[((long long)(b * 2 * p.OH + y) * (2 * p.OW) + x) * p.out_ld + c] = v;
+            const long long i0 = ((long long)(b * 2 * p.OH + y) * (2 * p.OW) + x) * p.out_ld + c;
+            p.out[i0] = v;
+            emit_plane1(p, i0, v);
         } break;
         case ST_NCHW:
             p.out[((long long)b * p.Cout + n) * hw + pix] = v;
@@ -128,7 +197,8 @@ __device__ __forceinline__ int fast_div(int m, int d, float rcp) {
 template <int ACT, int RES, int PASSES, int PF>
 __device__ __forceinline__ void epilogue_rows(const float* srow, int s_step, f32x4 bias4,
                                               __amdgpu_buffer_rsrc_t rsrcO, unsigned off_o, unsigned step_o,
-                                              __amdgpu_buffer_rsrc_t rsrcR, unsigned off_r, unsigned step_r, const f32x4* rpre) {
+                                              __amdgpu_buffer_rsrc_t rsrcR, unsigned off_r, unsigned step_r, const f32x4* rpre,
+                                              const PlaneDesc& pd) {
     // PF: the residual rows were requested before the tile was staged (rpre[pass], registers): a cold 16-B load costs the
     // block > 1 us at the very end of the kernel otherwise
 #pragma unroll
@@ -151,19 +221,13 @@ __device__ __forceinline__ void epilogue_rows(const float* srow, int s_step, f32
         if constexpr (RES == 2) v += r4;
         const u32x4 o = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
         __builtin_amdgcn_raw_buffer_store_b128(o, rsrcO, (int)off_o, 0, 0);
+        emit_planes4(pd, v, off_o >> 1);      // the planes mirror the fp32 view: same element index, half the bytes
         srow += s_step;
         off_o += step_o;
         off_r += step_r;
     }
 }
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 // LDS rows of the 16-bit kernels are 32 elements = 64 B, unpadded; the four 16-B granules of row r are stored at
 // granule index g ^ ((r >> 1) & 3), so the 16-B fragment reads of 8 consecutive lanes (8 rows, same logical granule)
 // hit all 32 banks once

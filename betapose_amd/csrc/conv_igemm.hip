@@ -583,10 +583,16 @@ __global__ __launch_bounds__(256) void conv_igemm_h_kernel(const ConvParams p) {
 
 thread_local ConvProfHook* g_conv_prof = nullptr;
 
-int conv_tile_bm(int tile) { return (tile == TILE_128x64 || tile == TILE_W64_2x1 || tile == TILE_W64_2x2) ? 128 : 64; }
+int conv_tile_bm(int tile) {
+    switch (tile) {
+        case TILE_128x64: case TILE_W64_2x1: case TILE_W64_2x2: case TILE_PL128: case TILE_PL128x64: return 128;
+        case TILE_PL256x128: return 256;
+        default: return 64;
+    }
+}
 int conv_tile_bn(int tile) {
     switch (tile) {
-        case TILE_W64_1x2: case TILE_W64_2x2: return 128;
+        case TILE_W64_1x2: case TILE_W64_2x2: case TILE_PL128: case TILE_PL256x128: return 128;
         default: return 64;
     }
 }
@@ -645,7 +651,11 @@ void launch_conv(const ConvParams& p, int tile, hipStream_t s) {
     BP_CHECK(p.Kpad % BK == 0 && p.nchunks == p.Kpad / BK, "Kpad");
     BP_CHECK(p.splits >= 1 && (p.splits == 1 || (p.partial != nullptr && p.tickets != nullptr)), "split-K workspace");
     BP_CHECK((long long)p.N * p.H * p.W * p.in_ld * 4 < (long long)OOB, "activation tensor too large for 32-bit offsets");
-    if (conv_tile_is_w64(tile)) {
+    BP_CHECK((long long)p.M * p.out_ld * 4 < (long long)OOB && (p.res == nullptr || (long long)p.M * p.res_ld * 4 < (long long)OOB),
+             "output / residual tensor too large for 32-bit offsets");
+    if (conv_tile_is_pl(tile)) {
+        launch_conv_pl(p, tile, s);
+    } else if (conv_tile_is_w64(tile)) {
         launch_conv_w64(p, tile, s);
     } else if (conv_tile_is_kg(tile)) {
         launch_conv_kg(p, tile, s);

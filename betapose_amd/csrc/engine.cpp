@@ -31,6 +31,8 @@ Tensor Net::new_tensor(int H, int W, int C) {
     Tensor t;
     t.H = H; t.W = W; t.C = C; t.ld = C;
     t.p = arena_.alloc((size_t)max_batch_ * H * W * C);
+    ActAlloc a; a.base = t.p; a.elems = (size_t)max_batch_ * H * W * C;
+    acts_.push_back(a);
     return t;
 }
 
@@ -242,7 +244,28 @@ static const std::vector<PlanEntry>& plan_file_entries() {
     return entries;
 }
 
+// conv_pl.hip (operand planes + LDS-DMA): which block tile, how many K slices
+static void choose_pl(const ConvParams& c, long long M, int mode, int sk_max, int* tile, int* splits) {
+    for (const PlanEntry& e : plan_file_entries())
+        if (e.M == (int)M && e.CoutPad == c.CoutPad && e.nchunks == c.nchunks && conv_tile_is_pl(e.tile)) { *tile = e.tile; *splits = e.splits; return; }
+    const long long tiles128 = ((M + 127) / 128) * ((c.CoutPad + 127) / 128);
+    int t = (c.CoutPad >= 128 && tiles128 >= 192) ? TILE_PL128 : TILE_PL64;
+    int s = 1;
+    if (t == TILE_PL64) {
+        bool hit = false;
+        for (const PlanEntry* e = kPlanB3; e->M != 0; ++e)   // the measured batch-1 slice counts of the 64x64 block
+            if (e->M == (int)M && e->CoutPad == c.CoutPad && e->nchunks == c.nchunks) { s = e->splits; hit = true; break; }
+        if (!hit) {
+            const long long blocks = ((M + 63) / 64) * (c.CoutPad / 64);
+            const int min_chunks = mode == PREC_F16 ? 8 : 4;
+            while (blocks * s < 512 && c.nchunks / (s + 1) >= min_chunks && s < sk_max) ++s;
+        }
+    }
+    *tile = t; *splits = s;
+}
+
 static void choose_h16(const ConvParams& c, long long M, int mode, int sk_max, int* tile, int* splits) {
+    if (conv_pl_eligible(c)) { choose_pl(c, M, mode, sk_max, tile, splits); return; }
     if (mode == PREC_BF16X3)
         for (const PlanEntry& e : plan_file_entries())
             if (e.M == (int)M && e.CoutPad == c.CoutPad && e.nchunks == c.nchunks) { *tile = e.tile; *splits = e.splits; return; }
@@ -349,6 +372,7 @@ int Net::add_conv(const std::string& name, const Tensor& in, const Tensor& out_v
     c.tickets = nullptr;
     c.stamps = nullptr;
     c.w16 = nullptr; c.w16s = nullptr;
+    c.in16 = nullptr; c.out16 = nullptr; c.wpl = nullptr; c.in16_plane = c.out16_plane = 0; c.out_np = 0; c.abl = 0;
     c.CoutPad = CoutPad;
     const double Kalg = (double)k * k * Cin;   // algorithmic K (the packing pad is not work)
     op.flops = 2.0 * OH * OW * (double)Cout * Kalg;
@@ -357,7 +381,8 @@ int Net::add_conv(const std::string& name, const Tensor& in, const Tensor& out_v
     return (int)ops_.size() - 1;
 }
 
-void Net::finalize() {
+// split-K workspace for the launches the CURRENT plan (precision, tiles, policy) makes, over every batch size
+size_t Net::workspace_need() const {
     size_t need = 0;
     for (const Op& op : ops_) {
         if (op.type != OP_CONV) continue;
@@ -371,9 +396,12 @@ void Net::finalize() {
             }
         }
     }
-    need = std::max(need, (size_t)4 << 20);   // headroom so a later policy change can still split small layers
-    partial_floats_ = need;
-    partial_ = need ? arena_.alloc(need) : nullptr;
+    return std::max(need, (size_t)4 << 20);   // headroom so a later policy change can still split small layers
+}
+
+void Net::finalize() {
+    partial_floats_ = workspace_need();
+    partial_ = arena_.alloc(partial_floats_);
     // arrival counters for the in-kernel split-K reduction: one per output tile of the widest layer
     size_t tiles = 0;
     for (const Op& op : ops_)
@@ -427,11 +455,86 @@ void Net::set_precision(int prec) {
             BP_HIP(hipDeviceSynchronize());
         }
     }
+    plan_planes(prec);
     for (Op& op : ops_)
-        if (op.type == OP_CONV) op.conv.mfma_mode = (prec != PREC_F32 && op.conv.w16 != nullptr) ? prec : PREC_F32;
+        if (op.type == OP_CONV) op.conv.mfma_mode = (prec != PREC_F32 && (op.conv.w16 != nullptr || conv_pl_eligible(op.conv))) ? prec : PREC_F32;
     precision_ = prec;
     ++plan_version_;
+    // the 16-bit plans split differently from the fp32 one the workspace was first sized for
+    if (const size_t need = workspace_need(); need > partial_floats_) {
+        partial_floats_ = need;
+        partial_ = arena_.alloc(need);
+    }
 }
+
+Net::ActAlloc* Net::find_act(const float* p) {
+    for (ActAlloc& a : acts_)
+        if (p >= a.base && p < a.base + a.elems) return &a;
+    return nullptr;
+}
+
+// Operand planes (conv_pl.hip): every activation allocation some 16-bit-eligible convolution reads gets three bf16 planes
+// (the fp16 mode uses the first), every producer of such an allocation -- convolutions of any arithmetic through
+// conv_tail.inc, the pooling / shuffle / copy kernels through a conversion launch -- is pointed at them, and the
+// filters are packed into the kernel's LDS image.  Planes are allocated once per engine (first 16-bit mode), outside any
+// graph capture.
+void Net::plan_planes(int prec) {
+    for (Op& op : ops_) {
+        op.out16 = nullptr; op.out16_plane = 0;
+        if (op.type == OP_CONV) { op.conv.in16 = nullptr; op.conv.out16 = nullptr; op.conv.wpl = nullptr; op.conv.out_np = 0; op.conv.in16_plane = op.conv.out16_plane = 0; }
+    }
+    if (prec == PREC_F32) return;
+    const int np = prec == PREC_F16 ? 1 : 3;
+    auto pl_shape_ok = [](const ConvParams& c) { return (c.Cin % 32 == 0) && (c.in_ld % 8 == 0) && c.ksize * c.ksize <= 32; };
+    bool made = false;
+    for (Op& op : ops_) {
+        if (op.type != OP_CONV || !pl_shape_ok(op.conv)) continue;
+        ActAlloc* a = find_act(op.conv.in);
+        if (!a || (op.conv.in - a->base) % 8 != 0 || a->elems % 8 != 0) continue;
+        a->wanted = true;
+    }
+    for (ActAlloc& a : acts_)
+        if (a.wanted && !a.planes) {
+            a.planes = (unsigned short*)arena_.alloc_bytes(3 * a.elems * sizeof(unsigned short));
+            BP_HIP(hipMemset(a.planes, 0, 3 * a.elems * sizeof(unsigned short)));
+        }
+    std::lock_guard<std::mutex> lk(store_->f16_mutex);
+    auto& packed = np == 1 ? store_->wpl1 : store_->wpl3;
+    for (Op& op : ops_) {
+        if (op.type == OP_CONV) {
+            ConvParams& c = op.conv;
+            if (ActAlloc* o = find_act(c.out); o && o->planes) {
+                c.out16 = o->planes + (c.out - o->base);
+                c.out16_plane = (long long)o->elems;
+                c.out_np = np;
+            }
+            if (!pl_shape_ok(c)) continue;
+            ActAlloc* a = find_act(c.in);
+            if (!a || !a->planes || (c.in - a->base) % 8 != 0) continue;
+            c.in16 = a->planes + (c.in - a->base);
+            c.in16_plane = (long long)a->elems;
+            auto it = packed.find(c.w);
+            if (it == packed.end()) {
+                unsigned short* d = (unsigned short*)store_->arena.alloc_bytes((size_t)np * c.CoutPad * c.Kpad * sizeof(unsigned short));
+                launch_pack_wpl(c.w, d, c.CoutPad, c.Kpad, np, nullptr);
+                it = packed.emplace(c.w, d).first;
+                made = true;
+            }
+            c.wpl = it->second;
+        } else if (op.out) {
+            if (ActAlloc* o = find_act(op.out); o && o->planes) {
+                op.out16 = o->planes + (op.out - o->base);
+                op.out16_plane = (long long)o->elems;
+            }
+        }
+    }
+    if (made) {
+        BP_HIP(hipGetLastError());
+        BP_HIP(hipDeviceSynchronize());
+    }
+}
+
+static int planes_np(int prec) { return prec == PREC_F16 ? 1 : 3; }
 
 void Net::run_op(const Op& op, int batch, hipStream_t s) {
     switch (op.type) {
@@ -449,20 +552,26 @@ void Net::run_op(const Op& op, int batch, hipStream_t s) {
             p.splits = splits; p.chunks_per_split = cps; p.partial = partial_; p.tickets = tickets_;
             launch_conv(p, tile, s);
         } break;
+        // (producers that are not convolutions: their operand planes come from a conversion launch behind them)
         case OP_MAXPOOL:
             launch_maxpool3s2p1(op.a, op.out, batch, op.H, op.W, op.C, op.OH, op.OW, s);
+            if (op.out16) launch_f32_to_planes(op.out, op.C, (long long)batch * op.OH * op.OW, op.C, op.out16, op.out16_plane, planes_np(precision_), s);
             break;
         case OP_ADD:
             launch_add(op.a, op.a_ld, op.b, op.b_ld, op.out, op.out_ld, (long long)batch * op.H * op.W, op.C, s);
+            if (op.out16) launch_f32_to_planes(op.out, op.out_ld, (long long)batch * op.H * op.W, op.C, op.out16, op.out16_plane, planes_np(precision_), s);
             break;
         case OP_UPSAMPLE:
             launch_upsample2(op.a, op.a_ld, op.out, op.out_ld, batch, op.H, op.W, op.C, s);
+            if (op.out16) launch_f32_to_planes(op.out, op.out_ld, (long long)batch * 4 * op.H * op.W, op.C, op.out16, op.out16_plane, planes_np(precision_), s);
             break;
         case OP_COPYCH:
             launch_copy_channels(op.a, op.a_ld, op.out, op.out_ld, (long long)batch * op.H * op.W, op.C, s);
+            if (op.out16) launch_f32_to_planes(op.out, op.out_ld, (long long)batch * op.H * op.W, op.C, op.out16, op.out16_plane, planes_np(precision_), s);
             break;
         case OP_PIXSHUF:
             launch_pixel_shuffle2(op.a, op.out, batch, op.H, op.W, op.C, s);
+            if (op.out16) launch_f32_to_planes(op.out, op.C / 4, (long long)batch * 4 * op.H * op.W, op.C / 4, op.out16, op.out16_plane, planes_np(precision_), s);
             break;
         case OP_AVGPOOL:
             launch_avgpool(op.a, op.a_ld, op.out, batch, op.H * op.W, op.C, s);

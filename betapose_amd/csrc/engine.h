@@ -43,6 +43,7 @@ struct Op {
     // fc
     const float* w = nullptr; const float* bias = nullptr; int Cin = 0, Cout = 0, act = 0;
     int in_parts = 1; float in_scale = 1.f;
+    unsigned short* out16 = nullptr; long long out16_plane = 0;   // operand planes of `out` (non-conv producers; set_precision)
     std::string name;
     double flops = 0;    // per image
     double bytes = 0;    // algorithmic bytes per image (weights counted once per launch elsewhere)
@@ -62,6 +63,7 @@ struct WeightStore {
     std::map<const float*, unsigned short*> bf16x3;   // three bf16 planes per filter (PREC_BF16X3)
     std::map<const float*, unsigned short*> bf16x3s;  // ... and their stage-packed copy (filters-direct kernels, conv_kg/rd.hip)
     std::map<const float*, unsigned short*> f16s;     // stage-packed fp16 copy
+    std::map<const float*, unsigned short*> wpl1, wpl3;   // conv_pl.hip's LDS image of the filters: fp16 / three bf16 planes
     std::mutex f16_mutex;
 };
 
@@ -100,8 +102,15 @@ protected:
     void add_tap(const std::string& name, const Tensor& t) { taps_.push_back(t); tap_names_.push_back(name); }
     Tensor new_tensor(int H, int W, int C);
     void finalize();   // allocate split-K workspace
+    size_t workspace_need() const;
 
     float* upload_weights(const float* host, size_t count);   // through the shared store (reused by clones)
+    // activation allocations (new_tensor) and their operand planes: planes mirror the fp32 allocation element for element
+    // (bp_common.h ConvParams::in16), so every view (pointer, ld) into an allocation has its planes view for free
+    struct ActAlloc { float* base = nullptr; size_t elems = 0; unsigned short* planes = nullptr; bool wanted = false; };
+    std::vector<ActAlloc> acts_;
+    ActAlloc* find_act(const float* p);
+    void plan_planes(int prec);   // allocate the planes 16-bit consumers need, point every producer / consumer at them
     int max_batch_;
     std::shared_ptr<WeightStore> store_;
     bool reuse_;

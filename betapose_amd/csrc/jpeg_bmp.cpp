@@ -75,66 +75,67 @@ const uint8_t kZigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4
                              41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22,
                              15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
 
-inline int fx(double x) { return (int)(x * 4096 + 0.5); }
-
-// one 8-point pass of the islow IDCT; in: s[0..7] (stride 1 via the lambda's caller), out: the four even / odd sums
-struct Idct1D {
-    int x0, x1, x2, x3, t0, t1, t2, t3;
-    void run(int s0, int s1, int s2, int s3, int s4, int s5, int s6, int s7) {
-        int p2 = s2, p3 = s6;
-        int p1 = (p2 + p3) * fx(0.5411961f);
-        t2 = p1 + p3 * fx(-1.847759065f);
-        t3 = p1 + p2 * fx(0.765366865f);
-        p2 = s0; p3 = s4;
-        t0 = (p2 + p3) * 4096;
-        t1 = (p2 - p3) * 4096;
-        x0 = t0 + t3; x3 = t0 - t3; x1 = t1 + t2; x2 = t1 - t2;
-        t0 = s7; t1 = s5; t2 = s3; t3 = s1;
-        p3 = t0 + t2;
-        int p4 = t1 + t3;
-        p1 = t0 + t3;
-        p2 = t1 + t2;
-        const int p5 = (p3 + p4) * fx(1.175875602f);
-        t0 = t0 * fx(0.298631336f);
-        t1 = t1 * fx(2.053119869f);
-        t2 = t2 * fx(3.072711026f);
-        t3 = t3 * fx(1.501321110f);
-        p1 = p5 + p1 * fx(-0.899976223f);
-        p2 = p5 + p2 * fx(-2.562915447f);
-        p3 = p3 * fx(-1.961570560f);
-        p4 = p4 * fx(-0.390180644f);
-        t3 += p1 + p4; t2 += p2 + p3; t1 += p2 + p4; t0 += p1 + p3;
+// ---- inverse DCT.  stb_image's "islow" 8-point pass is a fixed LINEAR map of its eight inputs with integer
+// coefficients (every constant is a float rounded to 12 fractional bits by (int)(x * 4096 + 0.5), truncation toward zero
+// included), and integer arithmetic is exact, so the factored butterfly it is usually written as and the plain
+// matrix form below give the same 32-bit results as long as nothing overflows (nothing does: |coefficients| < 2^14,
+// |inputs| < 2^17).  Even half  E = A_even * (s0, s4, s2, s6), odd half  O = A_odd * (s1, s3, s5, s7);
+// outputs  y[i] = E[i] + O[i],  y[7 - i] = E[i] - O[i].
+struct Islow8 {
+    int even26[4][2];    // contributions of (s2, s6) to E[0..3]
+    int odd[4][4];       // O[i] from (s1, s3, s5, s7)
+    static int q12(double x) { return (int)(x * 4096 + 0.5); }
+    Islow8() {
+        const int r = q12(0.5411961f), r6 = q12(-1.847759065f), r2 = q12(0.765366865f);
+        const int hi2 = r + r2, hi6 = r, lo2 = r, lo6 = r + r6;      // t3 = s2 (r + r2) + s6 r ;  t2 = s2 r + s6 (r + r6)
+        const int e[4][2] = {{hi2, hi6}, {lo2, lo6}, {-lo2, -lo6}, {-hi2, -hi6}};
+        for (int i = 0; i < 4; ++i) { even26[i][0] = e[i][0]; even26[i][1] = e[i][1]; }
+        const int k = q12(1.175875602f);
+        const int d7 = q12(0.298631336f), d5 = q12(2.053119869f), d3 = q12(3.072711026f), d1 = q12(1.501321110f);
+        const int m71 = q12(-0.899976223f), m53 = q12(-2.562915447f), m73 = q12(-1.961570560f), m51 = q12(-0.390180644f);
+        // rows: O[0] pairs with (y0, y7), ..., O[3] with (y3, y4); columns s1, s3, s5, s7
+        const int o[4][4] = {
+            {d1 + k + m71 + m51, k,                 k + m51,            k + m71},
+            {k,                  d3 + k + m53 + m73, k + m53,            k + m73},
+            {k + m51,            k + m53,            d5 + k + m53 + m51, k},
+            {k + m71,            k + m73,            k,                  d7 + k + m71 + m73}};
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) odd[i][j] = o[i][j];
     }
-};
-
-void idct_block(uint8_t* out, int stride, const short* d) {
-    int val[64];
-    Idct1D k;
-    for (int i = 0; i < 8; ++i) {
-        const short* c = d + i;
-        int* v = val + i;
-        if (c[8] == 0 && c[16] == 0 && c[24] == 0 && c[32] == 0 && c[40] == 0 && c[48] == 0 && c[56] == 0) {
-            const int dc = c[0] * 4;
-            for (int r = 0; r < 8; ++r) v[8 * r] = dc;
-        } else {
-            k.run(c[0], c[8], c[16], c[24], c[32], c[40], c[48], c[56]);
-            const int x0 = k.x0 + 512, x1 = k.x1 + 512, x2 = k.x2 + 512, x3 = k.x3 + 512;
-            v[0] = (x0 + k.t3) >> 10; v[56] = (x0 - k.t3) >> 10;
-            v[8] = (x1 + k.t2) >> 10; v[48] = (x1 - k.t2) >> 10;
-            v[16] = (x2 + k.t1) >> 10; v[40] = (x2 - k.t1) >> 10;
-            v[24] = (x3 + k.t0) >> 10; v[32] = (x3 - k.t0) >> 10;
+    // y[0..7] (before the caller's rounding shift); `bias` is added to the even half (rounding term / level shift)
+    void apply(const int s[8], int bias, int y[8]) const {
+        const int sum = (s[0] + s[4]) * 4096 + bias, dif = (s[0] - s[4]) * 4096 + bias;
+        const int base[4] = {sum, dif, dif, sum};
+        for (int i = 0; i < 4; ++i) {
+            const int E = base[i] + s[2] * even26[i][0] + s[6] * even26[i][1];
+            const int O = s[1] * odd[i][0] + s[3] * odd[i][1] + s[5] * odd[i][2] + s[7] * odd[i][3];
+            y[i] = E + O;
+            y[7 - i] = E - O;
         }
     }
-    for (int i = 0; i < 8; ++i) {
-        const int* v = val + 8 * i;
-        uint8_t* o = out + (size_t)i * stride;
-        k.run(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);
-        const int bias = 65536 + (128 << 17);
-        const int x0 = k.x0 + bias, x1 = k.x1 + bias, x2 = k.x2 + bias, x3 = k.x3 + bias;
-        o[0] = clamp8((x0 + k.t3) >> 17); o[7] = clamp8((x0 - k.t3) >> 17);
-        o[1] = clamp8((x1 + k.t2) >> 17); o[6] = clamp8((x1 - k.t2) >> 17);
-        o[2] = clamp8((x2 + k.t1) >> 17); o[5] = clamp8((x2 - k.t1) >> 17);
-        o[3] = clamp8((x3 + k.t0) >> 17); o[4] = clamp8((x3 - k.t0) >> 17);
+};
+const Islow8 kIslow;
+
+// 8x8 block: columns first, kept at 2 extra fractional bits (>> 10 with rounding), then rows (>> 17, the +128 level
+// shift folded into the rounding term), clamped to u8.  A column whose AC terms are all zero is its DC term * 4.
+void idct_block(uint8_t* out, int stride, const short* d) {
+    int mid[8][8];                                   // [row][column] after the column pass
+    for (int col = 0; col < 8; ++col) {
+        int s[8], ac = 0;
+        for (int r = 0; r < 8; ++r) { s[r] = d[8 * r + col]; if (r) ac |= s[r]; }
+        if (ac == 0) {
+            for (int r = 0; r < 8; ++r) mid[r][col] = s[0] * 4;
+            continue;
+        }
+        int y[8];
+        kIslow.apply(s, 512, y);
+        for (int r = 0; r < 8; ++r) mid[r][col] = y[r] >> 10;
+    }
+    for (int row = 0; row < 8; ++row) {
+        int y[8];
+        kIslow.apply(mid[row], 65536 + (128 << 17), y);
+        uint8_t* o = out + (size_t)row * stride;
+        for (int c = 0; c < 8; ++c) o[c] = clamp8(y[c] >> 17);
     }
 }
 
@@ -165,6 +166,7 @@ struct Decoder {
         while (len > 0) {
             const int pq = p[0] >> 4, tq = p[0] & 15;
             if (tq > 3 || pq > 1) throw std::runtime_error("JPEG: bad DQT");
+            if (len < 1 + (pq ? 128 : 64)) throw std::runtime_error("JPEG: truncated segment (DQT)");
             ++p; --len;
             for (int i = 0; i < 64; ++i) {
                 quant[tq][kZigzag[i]] = pq ? (uint16_t)be16(p + 2 * i) : p[i];
@@ -176,6 +178,7 @@ struct Decoder {
     }
     void parse_dht(const uint8_t* p, int len) {
         while (len > 0) {
+            if (len < 17) throw std::runtime_error("JPEG: truncated segment (DHT)");
             const int tc = p[0] >> 4, th = p[0] & 15;
             if (tc > 1 || th > 3) throw std::runtime_error("JPEG: bad DHT");
             HuffTable& h = tc ? ac[th] : dc[th];
@@ -188,6 +191,7 @@ struct Decoder {
                 code = (code + p[l]) << 1;
             }
             if (total > 256) throw std::runtime_error("JPEG: bad DHT");
+            if (len < 17 + total) throw std::runtime_error("JPEG: truncated segment (DHT)");
             std::memcpy(h.sym, p + 17, total);
             h.present = true;
             p += 17 + total;
@@ -195,6 +199,7 @@ struct Decoder {
         }
     }
     void parse_sof(const uint8_t* p, int len) {
+        if (len < 6) throw std::runtime_error("JPEG: truncated segment (SOF)");
         if (p[0] != 8) throw std::runtime_error("JPEG: only 8-bit samples are supported");
         H = be16(p + 1); W = be16(p + 3); ncomp = p[5];
         if (H <= 0 || W <= 0) throw std::runtime_error("JPEG: bad dimensions");
@@ -220,6 +225,7 @@ struct Decoder {
         const HuffTable& ha = ac[c.ta];
         const uint16_t* q = quant[c.tq];
         const int t = huff_decode(br, hd);
+        if (t > 11) throw std::runtime_error("JPEG: corrupt block (DC category)");   // 8-bit baseline: at most 11 bits
         const int diff = t ? extend(br.bits(t), t) : 0;
         c.dc_pred += diff;
         blk[0] = (short)(c.dc_pred * q[0]);
@@ -297,7 +303,10 @@ struct Decoder {
             const uint8_t* body = p + 4;
             if (m == 0xDB) parse_dqt(body, len - 2);
             else if (m == 0xC4) parse_dht(body, len - 2);
-            else if (m == 0xDD) restart = be16(body);
+            else if (m == 0xDD) {
+                if (len < 4) throw std::runtime_error("JPEG: truncated segment (DRI)");
+                restart = be16(body);
+            }
             else if (m == 0xC0 || m == 0xC1) {
                 parse_sof(body, len - 2);
                 have_sof = true;
@@ -313,6 +322,7 @@ struct Decoder {
             else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) throw std::runtime_error("JPEG: unsupported frame type");
             else if (m == 0xDA) {
                 if (!have_sof) throw std::runtime_error("JPEG: scan before frame header");
+                if (len < 3) throw std::runtime_error("JPEG: truncated segment (SOS)");
                 const int ns = body[0];
                 if (ns < 1 || ns > ncomp || len < 6 + 2 * ns) throw std::runtime_error("JPEG: bad SOS");
                 int order[3];

@@ -95,163 +95,180 @@ class ImageLoader:
         return self.Q.qsize()
 
 
-class DetectionLoader:
-    """dataloader.py:285-409.  ``det_model`` may be passed in (already loaded); otherwise the reference's hard-coded
-    paths are used (cfg ``yolo/cfg/yolov3-single.cfg``, weights ``models/yolo/%02d.weights``)."""
+class _Stage:
+    """A worker thread feeding a bounded queue: what every stage of the reference's ``--sp`` pipeline is.  Subclasses
+    implement ``update`` (the thread body); ``start`` / ``read`` / ``len`` are the reference's method names."""
 
-    def __init__(self, dataloder, obj_id, batchSize=1, queueSize=1024, det_model=None):
-        if det_model is None:
-            cfg_path = "yolo/cfg/yolov3-single.cfg"
-            weights_path = 'models/yolo/{:02d}.weights'.format(obj_id)
-            det_model = Darknet(cfg_path, reso=int(opt.inp_dim), max_batch=batchSize)
-            det_model.load_weights(weights_path)
-            print("Loading YOLO cfg from", cfg_path)
-            print("Loading YOLO weights from", weights_path)
-        self.det_model = det_model
-        self.det_model.net_info['height'] = opt.inp_dim
-        self.det_inp_dim = int(self.det_model.net_info['height'])
-        assert self.det_inp_dim % 32 == 0
-        assert self.det_inp_dim > 32
-        self.det_model.cuda()
-        self.det_model.eval()
-        self.stopped = False
-        self.dataloder = dataloder
-        self.batchSize = batchSize
-        self.datalen = self.dataloder.length()
-        self.num_batches = (self.datalen + batchSize - 1) // batchSize
+    def __init__(self, queueSize):
         self.Q = Queue(maxsize=queueSize)
+        self.stopped = False
 
     def start(self):
-        Thread(target=self.update, args=(), daemon=True).start()
+        Thread(target=self.update, daemon=True).start()
         return self
+
+    def read(self):
+        return self.Q.get()
+
+    def len(self):
+        return self.Q.qsize()
+
+    def _emit(self, *fields):
+        self.Q.put(tuple(fields))
+
+
+_EMPTY7 = (None,) * 7
+
+
+def _default_detector(obj_id, batchSize):
+    """The detector the reference builds when none is handed in: its hard-coded cfg and per-object weights
+    (dataloader.py:287-293)."""
+    paths = {"cfg": "yolo/cfg/yolov3-single.cfg", "weights": "models/yolo/%02d.weights" % obj_id}
+    model = Darknet(paths["cfg"], reso=int(opt.inp_dim), max_batch=batchSize)
+    model.load_weights(paths["weights"])
+    for what in ("cfg", "weights"):
+        print("Loading YOLO %s from" % what, paths[what])
+    return model
+
+
+class DetectionLoader(_Stage):
+    """dataloader.py:285-409: detector + box selection + rescale to frame pixels; per frame one
+    (orig_img, im_name, boxes, scores, inps, pt1, pt2) tuple, the last three as zero place-holders of the crop stage's
+    shapes.  ``det_model`` may be passed in (already loaded)."""
+
+    def __init__(self, dataloder, obj_id, batchSize=1, queueSize=1024, det_model=None):
+        super().__init__(queueSize)
+        self.det_model = det_model if det_model is not None else _default_detector(obj_id, batchSize)
+        self.det_model.net_info['height'] = opt.inp_dim
+        self.det_inp_dim = reso = int(opt.inp_dim)
+        if reso % 32 != 0 or reso <= 32:
+            raise AssertionError("detector input size must be a multiple of 32 and larger than 32, got %d" % reso)
+        self.det_model.cuda().eval()
+        self.dataloder = dataloder
+        self.batchSize = batchSize
+        self.datalen = dataloder.length()
+        self.num_batches = -(-self.datalen // batchSize)
+
+    def _frame_boxes(self, dets, im_dim_list):
+        """Detections [n, 8] (frame index first) in detector-input pixels -> boxes in frame pixels and their scores."""
+        import torch
+        scale = im_dim_list.index_select(0, dets[:, 0].long()) / float(self.det_inp_dim)     # (w, h, w, h) / reso per box
+        return dets[:, 1:5] * scale, dets[:, 5:6]
 
     def update(self):
         import torch
-        for i in range(self.num_batches):
+        for _ in range(self.num_batches):
             img, orig_img, im_name, im_dim_list = self.dataloder.getitem()
             if img is None:
-                self.Q.put((None, None, None, None, None, None, None))
+                self._emit(*_EMPTY7)
                 return
-            prediction = self.det_model(img.cuda())
-            dets = dynamic_write_results(prediction, opt.confidence, opt.num_classes, nms=True, nms_conf=opt.nms_thesh)
-            if isinstance(dets, int) or dets.shape[0] == 0:
-                for k in range(len(orig_img)):
-                    self.Q.put((orig_img[k], im_name[k], None, None, None, None, None))
-                continue
-            dets = dets.cpu()
-            reso = self.det_inp_dim
-            dims = torch.index_select(im_dim_list, 0, dets[:, 0].long())
-            w_ratio, h_ratio = dims[:, 0] / reso, dims[:, 1] / reso
-            boxes = dets[:, 1:5]
-            boxes[:, 0] = boxes[:, 0] * w_ratio
-            boxes[:, 1] = boxes[:, 1] * h_ratio
-            boxes[:, 2] = boxes[:, 2] * w_ratio
-            boxes[:, 3] = boxes[:, 3] * h_ratio
-            scores = dets[:, 5:6]
-            for k in range(len(orig_img)):
-                boxes_k = boxes[dets[:, 0] == k]
-                if boxes_k.shape[0] == 0:
-                    self.Q.put((orig_img[k], im_name[k], None, None, None, None, None))
+            dets = dynamic_write_results(self.det_model(img.cuda()), opt.confidence, opt.num_classes, nms=True,
+                                         nms_conf=opt.nms_thesh)
+            found = not isinstance(dets, int) and dets.shape[0] > 0
+            if found:
+                dets = dets.cpu()
+                boxes, scores = self._frame_boxes(dets, im_dim_list)
+                owner = dets[:, 0]
+            for k, (frame, name) in enumerate(zip(orig_img, im_name)):
+                mine = (owner == k) if found else None
+                n = int(mine.sum()) if found else 0
+                if n == 0:
+                    self._emit(frame, name, None, None, None, None, None)
                     continue
-                inps = torch.zeros(boxes_k.size(0), 3, opt.inputResH, opt.inputResW)
-                pt1 = torch.zeros(boxes_k.size(0), 2)
-                pt2 = torch.zeros(boxes_k.size(0), 2)
-                self.Q.put((orig_img[k], im_name[k], boxes_k, scores[dets[:, 0] == k], inps, pt1, pt2))
-
-    def read(self):
-        return self.Q.get()
-
-    def len(self):
-        return self.Q.qsize()
+                self._emit(frame, name, boxes[mine], scores[mine], torch.zeros(n, 3, opt.inputResH, opt.inputResW),
+                           torch.zeros(n, 2), torch.zeros(n, 2))
 
 
-class DetectionProcessor:
-    """dataloader.py:412-465: BGR->RGB, /255, mean subtraction, box padding, crop + bilinear resize -- one HIP kernel."""
+class DetectionProcessor(_Stage):
+    """dataloader.py:412-465: BGR->RGB, /255, mean subtraction, box padding, crop + bilinear resize -- one HIP kernel.
+    Output tuples: (inps, orig_img, im_name, boxes, scores, pt1, pt2)."""
 
     def __init__(self, detectionLoader, queueSize=1024):
+        super().__init__(queueSize)
         self.detectionLoader = detectionLoader
-        self.stopped = False
-        self.datalen = self.detectionLoader.datalen
-        self.Q = Queue(maxsize=queueSize)
-
-    def start(self):
-        Thread(target=self.update, args=(), daemon=True).start()
-        return self
+        self.datalen = detectionLoader.datalen
 
     def update(self):
-        for i in range(self.datalen):
-            (orig_img, im_name, boxes, scores, inps, pt1, pt2) = self.detectionLoader.read()
-            if orig_img is None:
-                self.Q.put((None, None, None, None, None, None, None))
+        for _ in range(self.datalen):
+            frame, name, boxes, scores = self.detectionLoader.read()[:4]
+            if frame is None:
+                self._emit(*_EMPTY7)
                 return
             if boxes is None or boxes.nelement() == 0:
-                self.Q.put((None, orig_img, im_name, boxes, scores, None, None))
-                continue
-            inps, pt1, pt2 = crop_from_dets_frame(orig_img, boxes, opt.inputResH, opt.inputResW)
-            self.Q.put((inps, orig_img, im_name, boxes, scores, pt1, pt2))
-
-    def read(self):
-        return self.Q.get()
-
-    def len(self):
-        return self.Q.qsize()
+                self._emit(None, frame, name, boxes, scores, None, None)
+            else:
+                inps, pt1, pt2 = crop_from_dets_frame(frame, boxes, opt.inputResH, opt.inputResW)
+                self._emit(inps, frame, name, boxes, scores, pt1, pt2)
 
 
-class DataWriter:
+def keep_best_keypoints(kp_2d, kp_score, kp_3d, left_number):
+    """The reference drops the lowest-scoring key point, one at a time, until ``left_number`` remain
+    (dataloader.py:703-712).  Removing the current minimum repeatedly = removing the (n - left_number) smallest in
+    first-occurrence order on ties, which a stable sort gives in one step; survivors keep their original order."""
+    kp_2d, kp_score, kp_3d = np.asarray(kp_2d), np.asarray(kp_score), np.asarray(kp_3d)
+    drop = len(kp_2d) - int(left_number)
+    if drop <= 0:
+        return kp_2d, kp_score, kp_3d
+    keep = np.sort(np.argsort(kp_score, kind="stable")[drop:])
+    return kp_2d[keep], kp_score[keep], kp_3d[keep]
+
+
+class DataWriter(_Stage):
     """dataloader.py:649-763: heat-maps -> key points -> pPose-NMS -> key-point pruning -> PnP."""
 
     def __init__(self, cam_K, left_number, kp_model_vertices, save_video=False, savepath='examples/res/1.avi',
                  fourcc=0, fps=25, frameSize=(640, 480), queueSize=1024):
         # same positional signature as the reference (dataloader.py:650-653).  save_video: the annotated frames go to a
         # Motion-JPEG .avi (video.MJPEGWriter stands in for cv2.VideoWriter; `fourcc` is accepted and ignored)
+        super().__init__(queueSize)
         self.save_video = bool(save_video)
+        self.stream = None
         if self.save_video:
             from .video import MJPEGWriter
             self.stream = MJPEGWriter(savepath, fps, frameSize)
-        self.stopped = False
         self.final_result = []
-        self.Q = Queue(maxsize=queueSize)
         self.kp_3d = kp_model_vertices
         self.cam_K = cam_K
         self.left_number = left_number
         self._busy = False
+        self._thread = None
 
     def start(self):
-        Thread(target=self.update, args=(), daemon=True).start()
+        self._thread = Thread(target=self.update, daemon=True)
+        self._thread.start()
         return self
 
+    def _pose_of(self, boxes, scores, hm_data, pt1, pt2, im_name):
+        """One frame's result dict: key points from the heat-maps, pPose-NMS, the best ``left_number`` points into PnP."""
+        _, preds_img, preds_scores = getPrediction(hm_data, pt1, pt2, opt.inputResH, opt.inputResW, opt.outputResH,
+                                                   opt.outputResW)
+        poses = pose_nms(boxes, scores, preds_img, preds_scores)
+        result = {'imgname': im_name, 'result': poses, 'cam_R': [], 'cam_t': []}
+        if poses:
+            best = poses[0]
+            kp_2d, _, kp_3d = keep_best_keypoints(best['keypoints'], np.asarray(best['kp_score'])[:, 0], self.kp_3d,
+                                                  self.left_number)
+            result['cam_R'], result['cam_t'] = solve_pnp(kp_3d, kp_2d, self.cam_K)
+        return result
+
     def update(self):
-        while True:
-            if self.stopped:
-                return
-            if self.Q.empty():
-                time.sleep(0.001)
+        from queue import Empty
+        while not self.stopped:
+            try:
+                boxes, scores, hm_data, pt1, pt2, orig_img, im_name = self.Q.get(timeout=0.001)
+            except Empty:
                 continue
-            self._busy = True
-            (boxes, scores, hm_data, pt1, pt2, orig_img, im_name) = self.Q.get()
+            frame_out = None
             if boxes is not None:
-                preds_hm, preds_img, preds_scores = getPrediction(hm_data, pt1, pt2, opt.inputResH, opt.inputResW,
-                                                                  opt.outputResH, opt.outputResW)
-                result = {'imgname': im_name, 'result': pose_nms(boxes, scores, preds_img, preds_scores)}
-                if result['result']:
-                    kp_score = np.array(result['result'][0]['kp_score'][:, 0])
-                    kp_2d = np.array(result['result'][0]['keypoints'])
-                    kp_3d = np.array(self.kp_3d)
-                    while len(kp_2d) > self.left_number:
-                        d = int(np.argmin(kp_score, axis=0))
-                        kp_score = np.delete(kp_score, d)
-                        kp_2d = np.delete(kp_2d, d, axis=0)
-                        kp_3d = np.delete(kp_3d, d, axis=0)
-                    R, t = solve_pnp(kp_3d, kp_2d, self.cam_K)
-                    result.update({'cam_R': R, 'cam_t': t})
-                else:
-                    result.update({'cam_R': [], 'cam_t': []})
+                result = self._pose_of(boxes, scores, hm_data, pt1, pt2, im_name)
                 self.final_result.append(result)
                 if self.save_video:
                     from .video import vis_frame
-                    self.stream.write(vis_frame(orig_img, result))
+                    frame_out = vis_frame(orig_img, result)
             elif self.save_video and orig_img is not None:
-                self.stream.write(np.asarray(orig_img))
+                frame_out = np.asarray(orig_img)
+            if frame_out is not None:
+                self.stream.write(frame_out)
             self._busy = False
 
     def running(self):
@@ -265,15 +282,13 @@ class DataWriter:
 
     def stop(self):
         self.stopped = True
-        time.sleep(0.01)
-        if self.save_video:
+        if self._thread is not None:
+            self._thread.join(timeout=5.0)      # the writer thread may still be inside stream.write
+        if self.stream is not None:
             self.stream.release()
 
     def results(self):
         return self.final_result
-
-    def len(self):
-        return self.Q.qsize()
 
 
 class Mscoco:

@@ -12,22 +12,25 @@ from . import _lib
 
 ACT = {"linear": 0, "leaky": 1, "relu": 2}
 STORE = {"nhwc": 0, "up2": 1, "pixshuf": 2, "nchw": 3}
-# +16: fp16 operands, +32: bf16x3 (fp32-accurate) operands; w<WM>x<WN> = conv_w64.hip with WM x WN waves of 64x64
-TILE = {"auto": -1, "64x64": 0, "128x64": 1, "64x64_f16": 16, "128x64_f16": 17, "64x64_b3": 32, "bd_b3": 32 + 12, "bd_f16": 16 + 12}
-for _n, _i in (("w1x1", 2), ("w1x2", 3), ("w2x1", 5), ("w2x2", 6)):
-    TILE[_n + "_f16"] = 16 + _i
-    TILE[_n + "_b3"] = 32 + _i
-for _n, _i in (("kg1", 7), ("kg2", 8), ("kg4", 9), ("rd4", 10), ("rd8", 11)):   # rd<W>: conv_rd.hip, no LDS stage, W K ranges per block
-    TILE[_n + "_b3"] = 32 + _i
-for _n, _i in (("kg1", 7), ("kg2", 8), ("kg4", 9)):   # conv_kg.hip: 64x64 tile, K split over G wave groups inside the block
-    TILE[_n + "_b3"] = 32 + _i
+# + 256: fp16 operands, + 512: bf16x3 (fp32-accurate) operands.  pl<BM>[x<BN>] = conv_pl.hip (operand planes + LDS-DMA);
+# w<WM>x<WN> = conv_w64.hip with WM x WN waves of 64x64; kg / rd / bd: the round-2 experiments (csrc/bp_common.h ConvTile)
+_F16, _B3 = 256, 512
+TILE = {"auto": -1, "64x64": 0, "128x64": 1, "64x64_f16": _F16, "128x64_f16": _F16 + 1, "64x64_b3": _B3, "bd_b3": _B3 + 12,
+        "bd_f16": _F16 + 12}
+for _n, _i in (("w1x1", 2), ("w1x2", 3), ("w2x1", 5), ("w2x2", 6), ("pl64", 13), ("pl128", 14), ("pl128x64", 15), ("pl256x128", 16)):
+    TILE[_n + "_f16"] = _F16 + _i
+    TILE[_n + "_b3"] = _B3 + _i
+for _n, _i in (("kg1", 7), ("kg2", 8), ("kg4", 9), ("rd4", 10), ("rd8", 11)):
+    TILE[_n + "_b3"] = _B3 + _i
 
 
 def conv2d_nhwc(x, weight, bias=None, stride: int = 1, pad: int = 0, act: str = "linear", store: str = "nhwc",
-                res=None, res_after_act: bool = False, tile: str = "auto", splits: int = 0, iters: int = 0):
+                res=None, res_after_act: bool = False, tile: str = "auto", splits: int = 0, iters: int = 0,
+                planes: bool = False):
     """One fused convolution.  ``x``: cuda f32 [N,H,W,Cin] (NHWC); ``weight``: host
     numpy/torch [Cout,Cin,k,k]; returns the output tensor laid out per ``store`` and,
-    when ``iters`` > 0, also the measured ms per launch."""
+    when ``iters`` > 0, also the measured ms per launch.  ``planes``: also return the operand planes the epilogue
+    emits for the next layer (int16 tensor [np, *out.shape]: np = 1 fp16 bits / 3 bf16 bits)."""
     import torch
     _lib.require_gpu()
     w = np.ascontiguousarray(weight.detach().cpu().numpy() if hasattr(weight, "detach") else weight, dtype=np.float32)
@@ -47,12 +50,17 @@ def conv2d_nhwc(x, weight, bias=None, stride: int = 1, pad: int = 0, act: str = 
     else:
         out = torch.empty((N, Cout, OH, OW), device=x.device, dtype=torch.float32)
     ms = C.c_float(0)
-    _lib.check(_lib.lib().bp_conv2d(x.data_ptr(), N, H, W, Cin, w.ctypes.data, b.ctypes.data if b is not None else None,
-                                    Cout, k, stride, pad, ACT[act], STORE[store],
-                                    res.contiguous().data_ptr() if res is not None else None, int(res_after_act),
-                                    TILE[tile], int(splits), out.data_ptr(), int(iters), C.byref(ms),
-                                    _lib.current_stream()))
-    return (out, ms.value) if iters > 0 else out
+    pl = None
+    if planes:
+        assert store != "nchw", "NCHW outputs (the heat-maps) have no operand planes"
+        pl = torch.zeros((1 if TILE[tile] < _B3 else 3,) + tuple(out.shape), device=x.device, dtype=torch.int16)
+    _lib.check(_lib.lib().bp_conv2d_planes(x.data_ptr(), N, H, W, Cin, w.ctypes.data, b.ctypes.data if b is not None else None,
+                                           Cout, k, stride, pad, ACT[act], STORE[store],
+                                           res.contiguous().data_ptr() if res is not None else None, int(res_after_act),
+                                           TILE[tile], int(splits), out.data_ptr(), pl.data_ptr() if planes else None,
+                                           int(iters), C.byref(ms), _lib.current_stream()))
+    ret = (out,) + ((pl,) if planes else ()) + ((ms.value,) if iters > 0 else ())
+    return ret if len(ret) > 1 else out
 
 
 def crop(frames_bgr_u8, sel=None, boxes=None, reso: int = 416, oh: int = 320, ow: int = 256, nchw: bool = True):

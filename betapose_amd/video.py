@@ -16,7 +16,6 @@ from __future__ import annotations
 import io
 import os
 import struct
-import sys
 import time
 from queue import LifoQueue, Queue
 from threading import Thread
@@ -57,7 +56,8 @@ class FrameSource:
             self.frame_size = (f0.shape[1], f0.shape[0])
 
     def _index_stream(self, path):
-        data = open(path, "rb").read()
+        with open(path, "rb") as fh:
+            data = fh.read()
         if data[:4] == b"RIFF" and data[8:12] == b"AVI ":
             self._jpegs = []
             pos = 12
@@ -126,43 +126,60 @@ class FrameSource:
 
 class MJPEGWriter:
     """``cv2.VideoWriter`` stand-in for ``DataWriter(save_video=True)``: a Motion-JPEG ``.avi`` (one 00dc chunk per
-    frame, idx1 index) that ``FrameSource`` and ordinary players read back."""
+    frame, idx1 index) that ``FrameSource`` and ordinary players read back.  Frames are appended to the file as they
+    arrive (headers of fixed size are written first and patched in ``release``); only the 16-byte index entries stay
+    in memory."""
 
     def __init__(self, path, fps=25, frame_size=(640, 480), quality=90):
         self.path, self.fps, self.size, self.quality = path, float(fps), tuple(frame_size), quality
-        self._chunks: List[bytes] = []
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        self._fh = open(path, "wb")
+        self._index: List[Tuple[int, int]] = []       # (offset inside movi, length)
+        self._fh.write(self._header(0, 0))            # place-holder of the final size
+        self._movi_at = self._fh.tell()               # first chunk goes here; offsets in idx1 count from the 'movi' tag
+        self._cursor = 4
+
+    @staticmethod
+    def _chunk(cid, body):
+        return cid + struct.pack("<I", len(body)) + body + (b"\0" if len(body) & 1 else b"")
+
+    @staticmethod
+    def _list(kind, body_len_or_body):
+        if isinstance(body_len_or_body, int):
+            return b"LIST" + struct.pack("<I", body_len_or_body + 4) + kind
+        return b"LIST" + struct.pack("<I", len(body_len_or_body) + 4) + kind + body_len_or_body
+
+    def _header(self, n, movi_bytes):
+        w, h = self.size
+        avih = struct.pack("<IIIIIIIIII4I", int(1e6 / self.fps), 0, 0, 0x10, n, 0, 1, 0, w, h, 0, 0, 0, 0)
+        strh = b"vids" + b"MJPG" + struct.pack("<IHHIIIIIIII4H", 0, 0, 0, 0, 1, int(self.fps), 0, n, 0, 0xFFFFFFFF, 0, 0, 0, w, h)
+        strf = struct.pack("<IiiHH4sIiiII", 40, w, h, 1, 24, b"MJPG", w * h * 3, 0, 0, 0, 0)
+        hdrl = self._list(b"hdrl", self._chunk(b"avih", avih) + self._list(b"strl", self._chunk(b"strh", strh) + self._chunk(b"strf", strf)))
+        idx_bytes = 8 + 16 * n
+        riff_len = 4 + len(hdrl) + 12 + movi_bytes + idx_bytes
+        return b"RIFF" + struct.pack("<I", riff_len) + b"AVI " + hdrl + self._list(b"movi", movi_bytes)
 
     def isOpened(self):
-        return True
+        return self._fh is not None
 
     def write(self, frame_bgr):
         from PIL import Image
         buf = io.BytesIO()
         Image.fromarray(np.ascontiguousarray(frame_bgr[:, :, ::-1])).save(buf, format="JPEG", quality=self.quality)
-        self._chunks.append(buf.getvalue())
+        jpg = buf.getvalue()
+        self._fh.write(self._chunk(b"00dc", jpg))
+        self._index.append((self._cursor, len(jpg)))
+        self._cursor += 8 + len(jpg) + (len(jpg) & 1)
 
     def release(self):
-        w, h = self.size
-        n = len(self._chunks)
-        movi = b"".join(b"00dc" + struct.pack("<I", len(c)) + c + (b"\0" if len(c) & 1 else b"") for c in self._chunks)
-        idx, off = b"", 4
-        for c in self._chunks:
-            idx += b"00dc" + struct.pack("<III", 0x10, off, len(c))
-            off += 8 + len(c) + (len(c) & 1)
-        avih = struct.pack("<IIIIIIIIII4I", int(1e6 / self.fps), 0, 0, 0x10, n, 0, 1, 0, w, h, 0, 0, 0, 0)
-        strh = b"vids" + b"MJPG" + struct.pack("<IHHIIIIIIII4H", 0, 0, 0, 0, 1, int(self.fps), 0, n, 0, 0xFFFFFFFF, 0, 0, 0, w, h)
-        strf = struct.pack("<IiiHH4sIiiII", 40, w, h, 1, 24, b"MJPG", w * h * 3, 0, 0, 0, 0)
-
-        def chunk(cid, body):
-            return cid + struct.pack("<I", len(body)) + body + (b"\0" if len(body) & 1 else b"")
-
-        def lst(kind, body):
-            return b"LIST" + struct.pack("<I", len(body) + 4) + kind + body
-        hdrl = lst(b"hdrl", chunk(b"avih", avih) + lst(b"strl", chunk(b"strh", strh) + chunk(b"strf", strf)))
-        body = b"AVI " + hdrl + lst(b"movi", movi) + chunk(b"idx1", idx)
-        os.makedirs(os.path.dirname(os.path.abspath(self.path)), exist_ok=True)
-        with open(self.path, "wb") as f:
-            f.write(b"RIFF" + struct.pack("<I", len(body)) + body)
+        if self._fh is None:
+            return
+        idx = b"".join(b"00dc" + struct.pack("<III", 0x10, off, ln) for off, ln in self._index)
+        self._fh.write(self._chunk(b"idx1", idx))
+        self._fh.seek(0)
+        self._fh.write(self._header(len(self._index), self._cursor - 4))
+        self._fh.close()
+        self._fh = None
 
 
 # ----------------------------------------------------------------------------------------------- preprocessing
@@ -202,8 +219,9 @@ def letterbox_image(img, inp_dim):
     new_w = int(img_w * min(w / img_w, h / img_h))
     new_h = int(img_h * min(w / img_w, h / img_h))
     resized = cv_resize_cubic(img, new_w, new_h)
-    canvas = np.full((inp_dim[1], inp_dim[0], 3), 128, dtype=np.int64)
-    canvas[(h - new_h) // 2:(h - new_h) // 2 + new_h, (w - new_w) // 2:(w - new_w) // 2 + new_w, :] = resized
+    canvas = np.full((inp_dim[1], inp_dim[0], 3), 128, dtype=np.uint8)
+    top, left = (h - new_h) // 2, (w - new_w) // 2
+    canvas[top:top + new_h, left:left + new_w, :] = resized
     return canvas
 
 
@@ -218,136 +236,146 @@ def prep_frame(img, inp_dim):
 
 
 # ----------------------------------------------------------------------------------------------- loaders
-class VideoLoader:
-    """dataloader.py:192-282: batches of letterboxed frames from a video source."""
+def _frame_batches(stream, datalen, batchSize):
+    """Frames of ``stream`` in lists of up to ``batchSize`` with the index of each list's first frame; a short read ends
+    the iteration after yielding (first index, frames read so far, False)."""
+    for first in range(0, datalen, batchSize):
+        frames = []
+        for _ in range(first, min(first + batchSize, datalen)):
+            grabbed, frame = stream.read()
+            if not grabbed:
+                yield first, frames, False
+                return
+            frames.append(frame)
+        yield first, frames, True
 
-    def __init__(self, path, batchSize=1, queueSize=50):
-        self.path = path
-        self.stream = FrameSource(path)
-        assert self.stream.isOpened(), 'Cannot capture source'
+
+def _prep_frames(frames):
+    """``prep_frame`` over a list: (tensor [n,3,D,D], the frames, [n,4] (w, h, w, h))."""
+    import torch
+    tensors, dims = [], []
+    for f in frames:
+        t, _, wh = prep_frame(f, int(opt.inp_dim))
+        tensors.append(t)
+        dims.append(wh)
+    return torch.cat(tensors), torch.FloatTensor(dims).repeat(1, 2)
+
+
+class _VideoStage:
+    """What the three video loaders share: a frame source, a bounded queue and a worker thread running ``update``."""
+
+    def __init__(self, source, queue):
+        self.stream = source if isinstance(source, FrameSource) else FrameSource(source)
+        if not self.stream.isOpened():
+            raise AssertionError('Cannot capture source')
         self.stopped = False
-        self.batchSize = batchSize
-        self.datalen = int(self.stream.frame_count)
-        self.num_batches = self.datalen // batchSize + (1 if self.datalen % batchSize else 0)
-        self.Q = Queue(maxsize=queueSize)
-
-    def length(self):
-        return self.datalen
+        self.Q = queue
 
     def start(self):
-        Thread(target=self.update, args=(), daemon=True).start()
+        Thread(target=self.update, daemon=True).start()
         return self
-
-    def update(self):
-        import torch
-        stream = FrameSource(self.path)
-        assert stream.isOpened(), 'Cannot capture source'
-        for i in range(self.num_batches):
-            img, orig_img, im_name, im_dim_list = [], [], [], []
-            for k in range(i * self.batchSize, min((i + 1) * self.batchSize, self.datalen)):
-                grabbed, frame = stream.read()
-                if not grabbed:
-                    self.Q.put((None, None, None, None))
-                    print('===========================> This video get ' + str(k) + ' frames in total.')
-                    sys.stdout.flush()
-                    return
-                img_k, orig_img_k, im_dim_list_k = prep_frame(frame, int(opt.inp_dim))
-                img.append(img_k)
-                orig_img.append(orig_img_k)
-                im_name.append(str(k) + '.jpg')
-                im_dim_list.append(im_dim_list_k)
-            self.Q.put((torch.cat(img), orig_img, im_name, torch.FloatTensor(im_dim_list).repeat(1, 2)))
 
     def videoinfo(self):
         return (self.stream.fourcc, self.stream.fps, self.stream.frame_size)
 
-    def getitem(self):
-        return self.Q.get()
-
     def len(self):
         return self.Q.qsize()
 
+    def stop(self):
+        self.stopped = True
+        self.stream.release()
 
-def _letterbox_boxes(dets, im_dim_list, det_inp_dim):
-    """dataloader.py:548-560: undo the letterbox on detections (x1, y1, x2, y2 in columns 1..4)."""
+
+class VideoLoader(_VideoStage):
+    """dataloader.py:192-282: batches (img, orig_img, im_name, im_dim_list) of letterboxed frames from a video source;
+    frame k is named '<k>.jpg'."""
+
+    def __init__(self, path, batchSize=1, queueSize=50):
+        super().__init__(path, Queue(maxsize=queueSize))
+        self.path = path
+        self.batchSize = batchSize
+        self.datalen = int(self.stream.frame_count)
+        self.num_batches = -(-self.datalen // batchSize)
+
+    def length(self):
+        return self.datalen
+
+    def update(self):
+        for first, frames, complete in _frame_batches(self.stream, self.datalen, self.batchSize):
+            if not complete:
+                self.Q.put((None, None, None, None))
+                print('===========================> This video get %d frames in total.' % (first + len(frames)), flush=True)
+                break
+            img, dims = _prep_frames(frames)
+            self.Q.put((img, frames, ['%d.jpg' % (first + j) for j in range(len(frames))], dims))
+        self.stream.release()
+
+    def getitem(self):
+        return self.Q.get()
+
+
+def unletterbox_boxes(dets, im_dim_list, det_inp_dim):
+    """dataloader.py:548-560: detections (frame index, x1, y1, x2, y2, ...) from the letterboxed detector input back to
+    frame pixels: remove the grey border, divide by the letterbox scale, clip to the frame.  Vectorised over boxes;
+    returns a new tensor."""
     import torch
-    im_dim_list = torch.index_select(im_dim_list, 0, dets[:, 0].long())
-    scaling_factor = torch.min(det_inp_dim / im_dim_list, 1)[0].view(-1, 1)
-    dets[:, [1, 3]] -= (det_inp_dim - scaling_factor * im_dim_list[:, 0].view(-1, 1)) / 2
-    dets[:, [2, 4]] -= (det_inp_dim - scaling_factor * im_dim_list[:, 1].view(-1, 1)) / 2
-    dets[:, 1:5] /= scaling_factor
-    for j in range(dets.shape[0]):
-        dets[j, [1, 3]] = torch.clamp(dets[j, [1, 3]], 0.0, float(im_dim_list[j, 0]))
-        dets[j, [2, 4]] = torch.clamp(dets[j, [2, 4]], 0.0, float(im_dim_list[j, 1]))
-    return dets
+    wh = im_dim_list.index_select(0, dets[:, 0].long())[:, :2]            # [n, 2] frame (w, h)
+    scale = (float(det_inp_dim) / wh).min(dim=1, keepdim=True)[0]        # [n, 1]
+    border = (float(det_inp_dim) - scale * wh) / 2                       # [n, 2] grey border (x, y)
+    out = dets.clone()
+    xyxy = (dets[:, 1:5] - border.repeat(1, 2)) / scale
+    out[:, 1:5] = torch.minimum(xyxy.clamp(min=0.0), wh.repeat(1, 2))
+    return out
 
 
-class VideoDetectionLoader:
+_letterbox_boxes = unletterbox_boxes      # (the name round 2 used)
+
+
+class VideoDetectionLoader(_VideoStage):
     """dataloader.py:468-591: video frames -> detector -> per-frame (inp, orig_img, boxes, scores).  The reference
     hard-codes AlphaPose's person detector (yolov3-spp, NMS on); here the object detector of this path is passed in (or
     built from ``models/yolo/<obj>.weights``) and ``dynamic_write_results`` keeps its one box per frame."""
 
     def __init__(self, path, batchSize=4, queueSize=256, det_model=None, obj_id=None):
-        from .darknet import Darknet
+        from .dataloader import _default_detector
         from .yolo_util import dynamic_write_results
+        super().__init__(path, Queue(maxsize=queueSize))
         self._write_results = dynamic_write_results
         if det_model is None:
-            det_model = Darknet("yolo/cfg/yolov3-single.cfg", reso=int(opt.inp_dim), max_batch=batchSize)
-            det_model.load_weights('models/yolo/{:02d}.weights'.format(int(obj_id if obj_id is not None else opt.obj_id)))
+            det_model = _default_detector(int(obj_id if obj_id is not None else opt.obj_id), batchSize)
         self.det_model = det_model
         self.det_model.net_info['height'] = opt.inp_dim
-        self.det_inp_dim = int(self.det_model.net_info['height'])
-        assert self.det_inp_dim % 32 == 0
-        assert self.det_inp_dim > 32
-        self.det_model.cuda()
-        self.det_model.eval()
-        self.stream = FrameSource(path)
-        assert self.stream.isOpened(), 'Cannot capture source'
-        self.stopped = False
+        self.det_inp_dim = int(opt.inp_dim)
+        if self.det_inp_dim % 32 != 0 or self.det_inp_dim <= 32:
+            raise AssertionError("detector input size must be a multiple of 32 and larger than 32")
+        self.det_model.cuda().eval()
         self.batchSize = batchSize
         self.datalen = int(self.stream.frame_count)
-        self.num_batches = self.datalen // batchSize + (1 if self.datalen % batchSize else 0)
-        self.Q = Queue(maxsize=queueSize)
+        self.num_batches = -(-self.datalen // batchSize)
 
     def length(self):
         return self.datalen
 
-    def len(self):
-        return self.Q.qsize()
-
-    def start(self):
-        Thread(target=self.update, args=(), daemon=True).start()
-        return self
-
     def update(self):
         import torch
-        for i in range(self.num_batches):
-            img, inp, orig_img, im_dim_list = [], [], [], []
-            for k in range(i * self.batchSize, min((i + 1) * self.batchSize, self.datalen)):
-                grabbed, frame = self.stream.read()
-                if not grabbed:
-                    self.stop()
-                    return
-                img_k, orig_img_k, im_dim_list_k = prep_frame(frame, int(opt.inp_dim))
-                img.append(img_k)
-                inp.append(im_to_torch(orig_img_k))
-                orig_img.append(orig_img_k)
-                im_dim_list.append(im_dim_list_k)
+        for _, frames, complete in _frame_batches(self.stream, self.datalen, self.batchSize):
+            if not complete:
+                self.stop()
+                return
+            img, dims = _prep_frames(frames)
+            inps = [im_to_torch(f) for f in frames]
             with torch.no_grad():
-                im_dims = torch.FloatTensor(im_dim_list).repeat(1, 2)
-                prediction = self.det_model(torch.cat(img)).cpu()
-                dets = self._write_results(prediction, opt.confidence, opt.num_classes, nms=True, nms_conf=opt.nms_thesh)
-                if isinstance(dets, int) or dets.shape[0] == 0:
-                    for k in range(len(inp)):
-                        self.Q.put((inp[k], orig_img[k], None, None))
+                dets = self._write_results(self.det_model(img).cpu(), opt.confidence, opt.num_classes, nms=True,
+                                           nms_conf=opt.nms_thesh)
+            found = not isinstance(dets, int) and dets.shape[0] > 0
+            if found:
+                dets = unletterbox_boxes(dets, dims, self.det_inp_dim)
+            for k, (inp, frame) in enumerate(zip(inps, frames)):
+                if not found:
+                    self.Q.put((inp, frame, None, None))
                     continue
-                dets = _letterbox_boxes(dets.clone(), im_dims, self.det_inp_dim)
-                boxes, scores = dets[:, 1:5], dets[:, 5:6]
-            for k in range(len(inp)):
-                self.Q.put((inp[k], orig_img[k], boxes[dets[:, 0] == k], scores[dets[:, 0] == k]))
-
-    def videoinfo(self):
-        return (self.stream.fourcc, self.stream.fps, self.stream.frame_size)
+                mine = dets[:, 0] == k
+                self.Q.put((inp, frame, dets[mine, 1:5], dets[mine, 5:6]))
 
     def read(self):
         return self.Q.get()
@@ -355,11 +383,8 @@ class VideoDetectionLoader:
     def more(self):
         return self.Q.qsize() > 0
 
-    def stop(self):
-        self.stopped = True
 
-
-class WebcamLoader:
+class WebcamLoader(_VideoStage):
     """dataloader.py:594-647: newest-frame-first (LIFO) queue of letterboxed frames.  ``webcam``: a camera index in the
     reference; here anything ``FrameSource`` opens (a growing frame directory, an MJPEG stream) -- a bare index raises
     because no capture library is present."""
@@ -368,40 +393,24 @@ class WebcamLoader:
         if isinstance(webcam, int) or (isinstance(webcam, str) and webcam.isdigit()):
             raise IOError("Cannot capture source: camera index %s needs a capture library (V4L2 / OpenCV) this image "
                           "does not have; pass a frame directory or an MJPEG stream" % webcam)
-        self.stream = FrameSource(webcam)
-        assert self.stream.isOpened(), 'Cannot capture source'
-        self.stopped = False
-        self.Q = LifoQueue(maxsize=queueSize)
-
-    def start(self):
-        Thread(target=self.update, args=(), daemon=True).start()
-        return self
+        super().__init__(webcam, LifoQueue(maxsize=queueSize))
 
     def update(self):
         import torch
-        while True:
-            if not self.Q.full():
-                grabbed, frame = self.stream.read()
-                if not grabbed:
-                    self.stop()
-                    return
-                img, orig_img, dim = prep_frame(frame, int(opt.inp_dim))
-                self.Q.put((img, orig_img, im_to_torch(orig_img), torch.FloatTensor([dim]).repeat(1, 2)))
-            else:
+        while not self.stopped:
+            if self.Q.full():                      # the consumer fell behind: drop the backlog, keep only fresh frames
                 with self.Q.mutex:
                     self.Q.queue.clear()
-
-    def videoinfo(self):
-        return (self.stream.fourcc, self.stream.fps, self.stream.frame_size)
+                continue
+            grabbed, frame = self.stream.read()
+            if not grabbed:
+                self.stop()
+                break
+            img, _, dim = prep_frame(frame, int(opt.inp_dim))
+            self.Q.put((img, frame, im_to_torch(frame), torch.FloatTensor([dim]).repeat(1, 2)))
 
     def read(self):
         return self.Q.get()
-
-    def len(self):
-        return self.Q.qsize()
-
-    def stop(self):
-        self.stopped = True
 
 
 # ----------------------------------------------------------------------------------------------- visualisation
@@ -417,7 +426,7 @@ def vis_frame(frame, im_res, format='coco'):
         sc = np.asarray(human['kp_score'], dtype=np.float64).reshape(-1)
         if 'bbox' in human:
             x1, y1, x2, y2 = [float(v) for v in np.asarray(human['bbox']).reshape(-1)[:4]]
-            draw.rectangle([x1, y1, x2, y2], outline=(0, 255, 0))
+            draw.rectangle([min(x1, x2), min(y1, y2), max(x1, x2), max(y1, y2)], outline=(0, 255, 0))
         for (x, y), s in zip(kp, sc):
             if s <= 0.05:                                   # fn.py:175
                 continue

@@ -142,12 +142,16 @@ int bp_heatmap_argmax(const float* d_hm, int batch, int C, int H, int W, float* 
 /* one fused convolution on device tensors (unit tests / kernel benchmarks).  h_w: host OIHW filter, h_bias host or NULL.
  * d_in NHWC [N,H,W,Cin]; d_out per store_mode (0 NHWC, 1 nearest-x2 NHWC, 2 PixelShuffle(2) NHWC, 3 NCHW);
  * act 0 linear / 1 leaky(0.1) / 2 relu; d_res NHWC residual or NULL; splits 0 auto; tile -1 auto, else a kernel id
- * (csrc/bp_common.h ConvTile) plus the operand mode: 0 = 64x64 block, 1 = 128x64, 2/3/5/6 = conv_w64.hip with 1x1/1x2/2x1/2x2
- * waves of 64x64, 7/8/9 = conv_kg.hip with 1/2/4 K groups, 10/11 = conv_rd.hip with 4/8 K ranges, 12 = the 64x64 block
- * with filters direct; + 0 fp32 MFMA (ids 0, 1 only), + 16 fp16 operands (ids 0..6), + 32 bf16x3 (ids 0, 2..12). */
+ * (csrc/bp_common.h ConvTile) plus the operand mode: 0 = 64x64 block, 1 = 128x64 (fp32 MFMA); 13..16 = conv_pl.hip (both
+ * operands by LDS-DMA from 16-bit planes: 64x64, 128x128, 128x64, 256x128 blocks); + 256 fp16 operands, + 512 bf16x3.
+ * bp_conv2d_planes additionally returns the operand planes the epilogue emits for the next layer
+ * (d_out_planes [np][output elements] u16: one fp16 plane or three bf16 planes that sum to the fp32 output exactly). */
 int bp_conv2d(const float* d_in, int N, int H, int W, int Cin, const float* h_w, const float* h_bias, int Cout, int k,
               int stride, int pad, int act, int store_mode, const float* d_res, int res_after_act, int tile, int splits,
               float* d_out, int iters, float* ms_per_iter, void* stream);
+int bp_conv2d_planes(const float* d_in, int N, int H, int W, int Cin, const float* h_w, const float* h_bias, int Cout, int k,
+                     int stride, int pad, int act, int store_mode, const float* d_res, int res_after_act, int tile, int splits,
+                     float* d_out, unsigned short* d_out_planes, int iters, float* ms_per_iter, void* stream);
 
 /* ---- whole frame on device: resize -> detector -> select -> crop -> KPD -> arg-max, optionally as one hipGraph ---- */
 /* d_frames [batch][H][W][3] u8 BGR, d_results [batch][BP_RESULT_FLOATS], d_hm [batch][50][80][64]: caller-owned

@@ -352,3 +352,142 @@ def test_conv_filters_direct_is_bit_identical_to_the_staged_kernel(cuda, case, s
     a1 = ops.conv2d_nhwc(x, w, b, stride=st, pad=pad, act=act, tile="bd_" + mode, splits=splits)
     a2 = ops.conv2d_nhwc(x, w, b, stride=st, pad=pad, act=act, tile="64x64_" + mode, splits=splits)
     assert torch.equal(a1, a2)
+
+
+# ---- conv_pl.hip: both operands by LDS-DMA from 16-bit operand planes the PRODUCER wrote (three bf16 planes that sum to
+# the fp32 value exactly / one fp16 plane).  Same bars as the kernels above -- bf16x3 fp32-accurate, fp16 equal to a conv on
+# fp16-rounded operands up to accumulation order, every epilogue / store mode, bit-reproducible -- plus the planes the
+# epilogue emits for the next layer.
+PL_TILES = ["pl64", "pl128", "pl128x64", "pl256x128"]
+
+
+def _planes_to_f32(pl, mode):
+    """int16 planes [np, ...] -> fp32: bf16 planes summed in plane order (exact), or the fp16 plane widened."""
+    if mode == "f16":
+        return pl[0].view(torch.float16).float()
+    bits = pl.to(torch.int32) << 16
+    f = bits.view(torch.float32)
+    return (f[0] + f[1]) + f[2]
+
+
+@pytest.mark.parametrize("case", F16_CASES)
+@pytest.mark.parametrize("tile", PL_TILES)
+@pytest.mark.parametrize("splits", [1, 3])
+def test_conv_pl_bf16x3_is_fp32_accurate(cuda, case, tile, splits):
+    N, H, W, Cin, Cout, k, st, pad, act = case
+    g = torch.Generator().manual_seed(1500 + CASES.index(case))
+    x = torch.randn(N, H, W, Cin, generator=g) * torch.exp(2 * torch.randn(N, H, W, 1, generator=g))   # wide dynamic range
+    w = torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g)
+    if splits > 1 and Cin * k * k // 32 < 2 * splits:
+        pytest.skip("too few K-chunks to split")
+    OH, OW = (H + 2 * pad - k) // st + 1, (W + 2 * pad - k) // st + 1
+    res = torch.randn(N, OH, OW, Cout, generator=g)
+    for after in (False, True):
+        ref64 = _ref(x.double(), w.double(), b.double(), st, pad, act, res.double(), after)
+        out3, pl = ops.conv2d_nhwc(x.to(cuda), w, b, stride=st, pad=pad, act=act, res=res.to(cuda), res_after_act=after,
+                                   tile=tile + "_b3", splits=splits, planes=True)
+        out32 = ops.conv2d_nhwc(x.to(cuda), w, b, stride=st, pad=pad, act=act, res=res.to(cuda), res_after_act=after,
+                                tile="64x64", splits=splits)
+        again = ops.conv2d_nhwc(x.to(cuda), w, b, stride=st, pad=pad, act=act, res=res.to(cuda), res_after_act=after,
+                                tile=tile + "_b3", splits=splits)
+        assert torch.equal(out3, again)                         # fixed summation order: bit-reproducible
+        assert torch.equal(_planes_to_f32(pl, "b3"), out3)      # the emitted planes ARE the fp32 output, exactly
+        out3, out32 = out3.cpu().permute(0, 3, 1, 2), out32.cpu().permute(0, 3, 1, 2)
+        scale = float(ref64.abs().mean())
+        e3 = float((out3.double() - ref64).abs().max()) / scale
+        e32 = float((out32.double() - ref64).abs().max()) / scale
+        assert e3 <= max(1.5 * e32, 2e-6), (e3, e32)
+        _check(out3, ref64.float(), tol=2e-5 * max(1.0, scale))
+
+
+@pytest.mark.parametrize("case", F16_CASES)
+@pytest.mark.parametrize("tile", PL_TILES)
+@pytest.mark.parametrize("splits", [1, 3])
+def test_conv_pl_f16_operands(cuda, case, tile, splits):
+    N, H, W, Cin, Cout, k, st, pad, act = case
+    g = torch.Generator().manual_seed(1700 + CASES.index(case))
+    x = torch.randn(N, H, W, Cin, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g)
+    if splits > 1 and Cin * k * k // 32 < 2 * splits:
+        pytest.skip("too few K-chunks to split")
+    OH, OW = (H + 2 * pad - k) // st + 1, (W + 2 * pad - k) // st + 1
+    res = torch.randn(N, OH, OW, Cout, generator=g)
+    ref16 = _ref(x.half().float(), w.half().float(), b, st, pad, act, res, False)
+    ref32 = _ref(x, w, b, st, pad, act, res, False)
+    out, pl = ops.conv2d_nhwc(x.to(cuda), w, b, stride=st, pad=pad, act=act, res=res.to(cuda), tile=tile + "_f16",
+                              splits=splits, planes=True)
+    assert torch.equal(_planes_to_f32(pl, "f16"), out.half().float())    # the emitted plane = RNE fp16 of the fp32 output
+    out = out.cpu().permute(0, 3, 1, 2)
+    _check(out, ref16)                      # same operands: accumulation order only
+    assert float((out - ref32).abs().max()) < 2e-2 and float((out - ref32).abs().max()) > 1e-6   # really fp16 operands
+
+
+@pytest.mark.parametrize("tile", PL_TILES)
+@pytest.mark.parametrize("mode", ["b3", "f16"])
+def test_conv_pl_store_modes(cuda, tile, mode):
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(2, 10, 8, 64, generator=g)
+    w = torch.randn(128, 64, 3, 3, generator=g) / 24
+    b = torch.randn(128, generator=g)
+    if mode == "f16":
+        x, w = x.half().float(), w.half().float()
+    ref = _ref(x, w, b, 1, 1, "relu", None, False)
+    xd = x.to(cuda)
+    t = tile + "_" + mode
+    exact = (lambda o: o) if mode == "b3" else (lambda o: o.half().float())
+    up, pl = ops.conv2d_nhwc(xd, w, b, pad=1, act="relu", store="up2", tile=t, planes=True)
+    assert torch.equal(_planes_to_f32(pl, mode), exact(up))
+    _check(up.cpu().permute(0, 3, 1, 2), F.interpolate(ref, scale_factor=2, mode="nearest"))
+    ps, pl = ops.conv2d_nhwc(xd, w, b, pad=1, act="relu", store="pixshuf", tile=t, planes=True)
+    assert torch.equal(_planes_to_f32(pl, mode), exact(ps))
+    _check(ps.cpu().permute(0, 3, 1, 2), F.pixel_shuffle(ref, 2))
+    nc = ops.conv2d_nhwc(xd, w, b, pad=1, act="relu", store="nchw", tile=t, splits=2).cpu()
+    _check(nc, ref)
+    # Cout below the tile (detection head class): columns past Cout are never stored
+    w18 = torch.randn(18, 64, 1, 1, generator=g) / 8
+    b18 = torch.randn(18, generator=g)
+    if mode == "f16":
+        w18 = w18.half().float()
+    hd = ops.conv2d_nhwc(xd, w18, b18, tile=t).cpu().permute(0, 3, 1, 2)
+    _check(hd, _ref(x, w18, b18, 1, 0, "linear", None, False))
+
+
+def test_conv_planes_from_the_fp32_kernels(cuda):
+    """The RGB stems run on the fp32-MFMA kernel in every mode and feed 16-bit consumers: the shared epilogue
+    (conv_tail.inc) emits the planes for them too."""
+    g = torch.Generator().manual_seed(19)
+    x = torch.randn(1, 32, 32, 3, generator=g)
+    w = torch.randn(32, 3, 3, 3, generator=g) / 5
+    b = torch.randn(32, generator=g)
+    from betapose_amd import _lib
+    import ctypes as C
+    xd = x.to(cuda)
+    out = torch.empty((1, 32, 32, 32), device=cuda)
+    for np_, enc in ((3, 512), (1, 256)):
+        pl = torch.zeros((np_, 1, 32, 32, 32), device=cuda, dtype=torch.int16)
+        wn, bn = w.numpy().copy(), b.numpy().copy()
+        # tile 0 (64x64 fp32-MFMA kernel; the layer is not 16-bit eligible) with the mode's planes requested
+        rc = _lib.lib().bp_conv2d_planes(xd.data_ptr(), 1, 32, 32, 3, wn.ctypes.data, bn.ctypes.data, 32, 3, 1, 1, 1, 0, None, 0,
+                                         0, 1, out.data_ptr(), pl.data_ptr(), 0, None, _lib.current_stream())
+        assert rc != 0   # planes without a 16-bit mode are refused ...
+    # ... and through an engine they arrive: covered by tests/test_gpu_nets.py (every layer of both networks in both modes)
+
+
+def test_conv_pl_full_size_layers(cuda):
+    """Full-size layers of both networks: against the definition (fp64) and the size-independent linearity property."""
+    g = torch.Generator().manual_seed(23)
+    for (H, W, Cin, Cout, k, tile, splits) in [(52, 52, 128, 256, 3, "pl64", 2), (13, 13, 512, 1024, 3, "pl64", 5),
+                                               (104, 104, 64, 128, 3, "pl128", 1), (20, 16, 1024, 256, 1, "pl64", 5),
+                                               (208, 208, 64, 32, 1, "pl128x64", 1), (26, 26, 32, 64, 1, "pl64", 1),
+                                               (52, 52, 128, 256, 3, "pl256x128", 1), (40, 32, 160, 64, 1, "pl64", 1)]:
+        x1 = torch.randn(1, H, W, Cin, generator=g)
+        x2 = torch.randn(1, H, W, Cin, generator=g)
+        w = torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k)
+        y1 = ops.conv2d_nhwc(x1.to(cuda), w, None, pad=k // 2, tile=tile + "_b3", splits=splits)
+        y2 = ops.conv2d_nhwc(x2.to(cuda), w, None, pad=k // 2, tile=tile + "_b3", splits=splits)
+        y3 = ops.conv2d_nhwc((2.0 * x1 + x2).to(cuda), w, None, pad=k // 2, tile=tile + "_b3", splits=splits)
+        assert float((y3 - (2.0 * y1 + y2)).abs().max()) < 5e-5
+        ref = F.conv2d(x1.double().permute(0, 3, 1, 2), w.double(), padding=k // 2).float()
+        _check(y1.cpu().permute(0, 3, 1, 2), ref)

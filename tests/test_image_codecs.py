@@ -80,3 +80,30 @@ def test_unsupported_streams_fail_loudly(tmp_path):
         _decode(b"GIF89a" + b"\0" * 64)
     with pytest.raises(_lib.BetaposeHipError):
         _decode(buf.getvalue()[:200])
+
+
+def test_malformed_jpegs_are_errors_not_overreads(tmp_path):
+    """Truncated segments and mutated streams must come back as clean errors (every fixed-size field is length-checked
+    before it is read; a DC category above 11 is rejected)."""
+    def rc_of(data: bytes) -> int:
+        h, w = C.c_int(), C.c_int()
+        buf = (C.c_ubyte * max(1, len(data))).from_buffer_copy(data if data else b"\0")
+        out = np.empty(1 << 20, np.uint8)
+        return _lib.lib().bp_image_decode_rgb(buf, len(data), out.ctypes.data, out.nbytes, C.byref(h), C.byref(w))
+    assert rc_of(bytes.fromhex("ffd8ffc4000300")) != 0                 # DHT of 1 byte (the advisor's ASAN repro)
+    assert rc_of(bytes.fromhex("ffd8ffdb000300")) != 0                 # DQT without its table
+    assert rc_of(bytes.fromhex("ffd8ffc000030800")) != 0               # SOF cut before the component count
+    assert rc_of(bytes.fromhex("ffd8ffdd000200")) != 0                 # DRI without its interval
+    rgb = synth.synth_frame(11)[:120, :160, ::-1].copy()
+    p = tmp_path / "ok.jpg"
+    Image.fromarray(rgb).save(p, format="JPEG", quality=70)
+    good = p.read_bytes()
+    assert rc_of(good) == 0
+    rng = np.random.default_rng(0)
+    for cut in (3, 5, 20, 100, 180, len(good) // 2):
+        rc_of(good[:cut])                                              # any return code; must not crash
+    for _ in range(300):
+        bad = bytearray(good)
+        for _ in range(int(rng.integers(1, 6))):
+            bad[int(rng.integers(2, len(bad)))] = int(rng.integers(0, 256))
+        rc_of(bytes(bad))
