@@ -34,7 +34,11 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_F16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: BF16/F16 ~2.5 PF dense (v_mfma_f32_32x32x16_f16)
 PEAK_BF16X3_TFLOPS = 2500.0 / 6  # fp32-accurate mode: six bf16 MFMA products per algorithmic multiply
+PEAK_HBM_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (~6.3 TB/s achievable)
 TILE_NAMES = {0: "1, 1", 1: "2, 1", 2: "1, 1", 3: "1, 2", 5: "2, 1", 6: "2, 2"}
+# conv_pl.hip instantiations (csrc/conv_pl.hip launch_pl_np): tile id -> {planes: "WM, WN, TM, TN, NST, CPS"}
+PL_TILE_ARGS = {13: {3: "2, 2, 1, 1, 3, 1", 1: "2, 2, 1, 1, 3, 2"}, 14: {3: "2, 2, 2, 2, 3, 1", 1: "2, 2, 2, 2, 4, 1"},
+                15: {3: "2, 2, 2, 1, 3, 1", 1: "2, 2, 2, 1, 3, 2"}, 16: {3: "4, 2, 2, 2, 2, 1", 1: "4, 2, 2, 2, 3, 2"}}
 
 
 def parse_args():
@@ -51,6 +55,12 @@ def parse_args():
                          "the same workload and report them under \"other_precisions\" (never as \"value\"); '' = skip")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-side-runs", action="store_true", help="skip the one-frame-at-a-time and H2D-inclusive runs")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="K-step timed regions run back to back: `value` is the FIRST (the contract's region), \"repeats\" "
+                         "reports p50 / min / max over all of them")
+    ap.add_argument("--insitu", default="", metavar="PATH",
+                    help="N=1: after the timed regions, time every convolution WHILE the frames are in flight (s_memtime "
+                         "stamps written by the kernels themselves) and write the per-layer table to PATH")
     ap.add_argument("--partition", type=int, default=0,
                     help="give each of the --streams frames in flight its own 1/PARTITION slice of the CUs of every "
                          "XCD (hipExtStreamCreateWithCUMask); 0 = ordinary streams sharing the chip")
@@ -212,6 +222,8 @@ def roofline(det, pose, batch):
         if mode == "f32":
             return "bp::conv_igemm_kernel<%s, %d>" % (TILE_NAMES.get(tile, "?"), key[1])
         np_ = 1 if mode == "f16" else 3
+        if tile in PL_TILE_ARGS:
+            return "bp::conv_pl_kernel<%d, %s>" % (np_, PL_TILE_ARGS[tile][np_])
         if tile == 12:
             return "bp::conv_igemm_h_kernel<1, 1, 3, true>"        # filters direct
         if tile in (7, 8, 9):
@@ -250,7 +262,156 @@ def roofline(det, pose, batch):
                      "all_conv": {"achieved": round(conv_flops / (conv_ms * 1e-3) / 1e12, 2), "ms_per_step": round(conv_ms, 4)},
                      "device_ms_per_step_eager_sum": round(total_ms, 4)},
         "gflop_per_step": round(conv_flops / 1e9, 2), **extra,
+        "layer_classes": layer_classes(det, pose, batch, peak),
+        "algorithmic_bytes_per_step": sum(float(n_.op_stats()[1].sum()) for n_ in (det, pose)),
     }
+
+
+def op_class(name: str, is_conv: bool) -> str:
+    """The layer classes of the roofline table.  ``name`` = "<layer> k<ksize> <OH>x<OW> <Cin>-><Cout> s<stride>" for convs."""
+    import re
+    if not is_conv:
+        return "se (pool + fc)" if ".se." in name else "other (max-pool, shuffle)"
+    m = re.search(r" k(\d+) (\d+)x(\d+) (\d+)->(\d+) s(\d+)$", name)
+    k, oh, ow, cin, cout = (int(m.group(i)) for i in range(1, 6))
+    if cin <= 4:
+        return "stems (RGB input, fp32 MFMA)"
+    if cout < 64:
+        return "heads (YOLO 1x1 -> 18, conv_out 3x3 -> 50)"
+    if oh * ow <= 320:
+        return "13x13 / 10x8 / 20x16 weight-bound (M <= 320)"
+    return "3x3 mid (M > 320)" if k == 3 else "1x1 (M > 320)"
+
+
+def layer_classes(det, pose, batch, peak_mode):
+    """Per layer class, from the eager pass (every op alone between HIP events): launches, device time, achieved TFLOP/s
+    against the MFMA roof of the class's arithmetic and ALGORITHMIC bytes (fp32 operands and results, weights
+    once per launch) per second against the 8 TB/s HBM peak."""
+    cls = {}
+    for net in (det, pose):
+        ms, info = net.profile(batch=batch, iters=10)
+        flops, byts = net.op_stats()
+        for i, (nm, is_conv) in enumerate(net.op_names()):
+            c = cls.setdefault(op_class(nm, is_conv), {"launches": 0, "ms": 0.0, "gflop": 0.0, "MB": 0.0})
+            c["launches"] += 1
+            c["ms"] += float(ms[i])
+            c["gflop"] += float(flops[i]) * batch / 1e9
+            c["MB"] += float(byts[i]) / 1e6
+    out = {}
+    for k, c in sorted(cls.items(), key=lambda kv: -kv[1]["ms"]):
+        pk = PEAK_FP32_MFMA_TFLOPS if k.startswith("stems") else peak_mode
+        tf = c["gflop"] / c["ms"] if c["ms"] > 0 else 0.0          # GFLOP / ms = TFLOP/s
+        gbps = c["MB"] / c["ms"] if c["ms"] > 0 else 0.0           # MB / ms = GB/s
+        out[k] = {"launches": c["launches"], "us_per_step": round(c["ms"] * 1e3, 1), "gflop": round(c["gflop"], 2),
+                  "achieved_TFLOPs": round(tf, 1), "mfma_frac": round(tf / pk, 4) if c["gflop"] > 0 else None,
+                  "algorithmic_GBps": round(gbps, 1), "hbm_frac": round(gbps / PEAK_HBM_GBPS, 4)}
+    return out
+
+
+def hbm_block(alg_bytes_per_step: float, fps: float, batch: int):
+    """HBM GB/s of the whole pipeline at the measured rate: counter bytes per frame from the committed rocprofv3 PMC pass
+    (tools/pmc_frame_traffic.sh: FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate passes) x frames/s, beside the algorithmic
+    bytes per frame x frames/s."""
+    src, counter = None, None
+    try:
+        import glob
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_frame_traffic*.json")))[::-1]:
+            t = json.load(open(f))
+            counter = (t["fetch_MB_per_frame(x2 corrected)"] + t["write_MB_per_frame"]) * 1e6
+            src = os.path.relpath(f, ROOT)
+            break
+    except Exception:
+        pass
+    alg = alg_bytes_per_step / batch
+    return {"achieved_GBps": round(counter * fps / 1e9, 1) if counter else None,
+            "algorithmic_GBps": round(alg * fps / 1e9, 1), "peak": PEAK_HBM_GBPS,
+            "frac": round(counter * fps / 1e9 / PEAK_HBM_GBPS, 4) if counter else None,
+            "counter_bytes_per_frame": counter, "algorithmic_bytes_per_frame": alg,
+            "traffic_over_algorithmic": round(counter / alg, 2) if counter else None, "source": src,
+            "note": "achieved = HBM-side bytes per frame (PMC, fetch doubled per MI355X_MICROARCH.md) x the frames/s of this run"}
+
+
+def insitu_layers(dets, poses, run, S, batch, path, precision):
+    """Per-layer timing WHILE the pipeline runs (S frames in flight, graph replay): every conv kernel stamps s_memtime at
+    its blocks' entry, K-loop end and last store (bp_*_set_stamps); a layer's span = first entry -> last mark of its grid.
+    rocprofv3 cannot give this (its tracer serialises the streams).  Writes the table to ``path``."""
+    import ctypes
+    import torch
+    from betapose_amd import _lib
+    SLOTS = 4096
+    nets = []
+    for k in range(S):
+        for tag, net in (("yolo", dets[k]), ("kpd", poses[k])):
+            names = net.op_names()
+            nconv = sum(1 for _, c in names if c)
+            buf = torch.zeros(nconv * SLOTS * 8, dtype=torch.int64, device="cuda")
+            net.set_stamps(buf, SLOTS)
+            nets.append((k, tag, net, [n for n, c in names if c], buf))
+    run(2 * S, False)                 # graphs re-captured with the stamp pointers, pipeline warm
+    torch.cuda.synchronize()
+    for *_, buf in nets:
+        buf.zero_()
+    n = 6 * S
+    t0 = time.perf_counter()
+    run(n, False)
+    torch.cuda.synchronize()
+    wall_ms = (time.perf_counter() - t0) * 1e3
+    ms = ctypes.c_float(0)
+    TICKS = 20_000_000
+    _lib.check(_lib.lib().bp_calibrate_ticks(TICKS, ctypes.byref(ms), _lib.current_stream()))
+    ghz = TICKS / (ms.value * 1e-3) / 1e9
+    rows, spans = [], []
+    for k, tag, net, names, buf in nets:
+        a = buf.cpu().numpy().reshape(len(names), SLOTS, 8)
+        for c, nm in enumerate(names):
+            blk = a[c][a[c, :, 0] != 0]
+            if not len(blk):
+                rows.append((k, tag, c, nm, 0, None))
+                continue
+            entry = blk[:, 0]
+            last = blk[:, 3:7].max(axis=1)
+            kloop = (blk[:, 3] - blk[:, 0])[blk[:, 3] != 0]
+            rows.append((k, tag, c, nm, len(blk), (int(entry.min()), int(last.max()), float(kloop.mean()) if len(kloop) else 0.0,
+                                                    float((last - np.maximum(blk[:, 3], entry)).mean()))))
+            spans.append((int(entry.min()), int(last.max())))
+        net.set_stamps(None, 0)
+    us = lambda t: t / ghz / 1e3
+    # layers in flight at once over the stamped window (the last frame of each stream): sum of spans / union of spans
+    ev = sorted([(s0, 1) for s0, _ in spans] + [(s1, -1) for _, s1 in spans])
+    busy = depth = 0
+    prev = ev[0][0]
+    for t, d in ev:
+        if depth > 0:
+            busy += t - prev
+        depth += d
+        prev = t
+    conc = sum(s1 - s0 for s0, s1 in spans) / max(busy, 1)
+    per_class, lines = {}, []
+    for k, tag, c, nm, nb, r in rows:
+        if r is None:
+            lines.append("%d %-4s %3d %-58s grid > %d blocks: not stamped" % (k, tag, c, nm, SLOTS))
+            continue
+        e0, e1, kl, tail = r
+        lines.append("%d %-4s %3d %-58s blocks %5d  span %7.2f us  K loop (mean per block) %7.2f us  tail %6.2f us" % (
+            k, tag, c, nm, nb, us(e1 - e0), us(kl), us(tail)))
+        pc = per_class.setdefault(op_class(nm, True), {"launches": 0, "span_us": 0.0, "kloop_us": 0.0})
+        pc["launches"] += 1
+        pc["span_us"] += us(e1 - e0)
+        pc["kloop_us"] += us(kl)
+    for v in per_class.values():
+        v["launches"] //= S
+        v["span_us"] = round(v["span_us"] / S, 1)
+        v["kloop_us"] = round(v["kloop_us"] / S, 1)
+    summary = {"frames_in_flight": S, "stamp_clock_GHz": round(ghz, 3), "mean_layers_in_flight": round(conc, 2),
+               "per_class_us_per_frame": per_class, "table": os.path.relpath(path, ROOT) if path.startswith(ROOT) else path,
+               "fps_while_stamping": round(n * batch / (wall_ms * 1e-3), 1)}
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    with open(path, "w") as f:
+        f.write("# in-situ per-layer times: %d frames in flight, precision %s, the LAST frame of every stream; clock %.3f GHz\n"
+                "# (bench.py --insitu; stamps = s_memtime written by the conv kernels: entry / K loop done / last store per block)\n"
+                "# span = first block entry -> last mark of the layer's grid; %.2f layers in flight on average\n" % (S, precision, ghz, conc))
+        f.write("# stream net conv layer\n" + "\n".join(lines) + "\n# " + json.dumps(summary) + "\n")
+    return summary
 
 
 def main():
@@ -376,6 +537,20 @@ def main():
     lat_flight = np.array(lat["ms"]) if lat["ms"] else np.zeros(1)
     rank_fps = bpd.gather_floats(a.steps * a.batch / t_own)
 
+    # ---- more K-step regions, back to back, each bracketed like the first (barrier + synchronize both sides, max over
+    # ranks): a single 20-step region is a 20 ms window
+    region_fps = [world * a.steps * a.batch / el]
+    for _ in range(max(0, a.repeats - 1)):
+        torch.cuda.synchronize()
+        bpd.barrier()
+        torch.cuda.synchronize()
+        tr = time.perf_counter()
+        run(a.steps, False)
+        torch.cuda.synchronize()
+        bpd.barrier()
+        torch.cuda.synchronize()
+        region_fps.append(world * a.steps * a.batch / bpd.max_over_ranks(time.perf_counter() - tr))
+
     # ---- side measurements on the same pipelines (never `value`): strictly one frame at a time, and the same
     # multi-frame run with every frame uploaded from pinned host memory inside the timed region
     side = {}
@@ -429,6 +604,9 @@ def main():
                            "p95": round(float(np.percentile(lat_flight, 95)), 4),
                            "definition": "frame handed to the stream -> its record (post-processing input) on the host",
                            **({"one_frame_at_a_time": side["single"]} if "single" in side else {})},
+            "repeats": {"regions": len(region_fps), "steps_each": a.steps, "fps": [round(v, 2) for v in region_fps],
+                        "p50": round(float(np.percentile(region_fps, 50)), 2), "min": round(min(region_fps), 2),
+                        "max": round(max(region_fps), 2), "note": "`value` is region 0"},
             "detections": stats["det"], "poses": stats["pose"],
             "records_gathered": int((gathered[:, 0].view(np.int32) >= -1).sum()) if gathered is not None else 0,
         }
@@ -456,6 +634,9 @@ def main():
                            **{k: v for k, v in rf.items() if k not in ("bound", "peak", "unit", "traffic")}}
         if a.precision == "bf16x3":
             out["roofline"]["frac_of_executed_mfma"] = round(6 * agg / PEAK_F16_MFMA_TFLOPS, 4)
+        out["roofline"]["hbm"] = hbm_block(rf["algorithmic_bytes_per_step"], out["value"] / world, a.batch)
+    if rank == 0 and world == 1 and a.insitu:
+        out.setdefault("roofline", {})["insitu"] = insitu_layers(dets, poses, run, S, a.batch, a.insitu, a.precision)
     if rank == 0 and world == 1 and a.other_modes:
         # the opt-in precisions on the same workload, for the record: 4 frames in flight, same
         # graph pipeline (re-captured on the precision change), a short timed run each

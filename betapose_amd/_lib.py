@@ -52,6 +52,11 @@ PROTOTYPES = {
     "bp_kpd_set_policy": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "bp_yolo_set_precision": (C.c_int, [vp, C.c_int]),
     "bp_kpd_set_precision": (C.c_int, [vp, C.c_int]),
+    "bp_calibrate_ticks": (C.c_int, [C.c_longlong, c_float_p, vp]),
+    "bp_yolo_set_stamps": (C.c_int, [vp, vp, C.c_int]),
+    "bp_kpd_set_stamps": (C.c_int, [vp, vp, C.c_int]),
+    "bp_yolo_op_name": (C.c_int, [vp, C.c_int, C.c_char_p, C.c_int]),
+    "bp_kpd_op_name": (C.c_int, [vp, C.c_int, C.c_char_p, C.c_int]),
     "bp_yolo_op_stats": (C.c_int, [vp, c_double_p, c_double_p, C.c_int]),
     "bp_kpd_op_stats": (C.c_int, [vp, c_double_p, c_double_p, C.c_int]),
     "bp_yolo_device_bytes": (C.c_size_t, [vp]),

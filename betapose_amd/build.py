@@ -12,13 +12,16 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbetapose_hip.so")
-SOURCES = ["conv_igemm.hip", "conv_pl.hip", "conv_w64.hip", "conv_kg.hip", "conv_rd.hip", "aux_kernels.hip", "engine.cpp", "host_post.cpp", "frame_io.cpp", "jpeg_bmp.cpp", "c_api.cpp", "darknet_compat.cpp"]
+SOURCES = ["conv_igemm.hip", "conv_pl.hip", "aux_kernels.hip", "engine.cpp", "host_post.cpp", "frame_io.cpp", "jpeg_bmp.cpp", "c_api.cpp", "darknet_compat.cpp"]
 HEADERS = ["bp_common.h", "engine.h", "frame_io.h", "conv_tail.inc", "conv_dev.h", os.path.join("..", "..", "include", "betapose_hip.h"),
            os.path.join("..", "..", "include", "yolo_v2_class_compat.h")]
+# measured-and-superseded kernels (round-1/2 experiments): compiled only into libbetapose_hip_exp.so (--experimental)
+EXP_SOURCES = ["conv_w64.hip", "conv_kg.hip", "conv_rd.hip"]
 ARCH = "gfx950"
 # Host launch stubs every HIP object must export.  hipcc has been seen to drop a kernel's host stub SILENTLY (the object
 # links, the launch then fails at run time) -- DESIGN.md §3.1d -- so the build counts them.
-MIN_STUBS = {"conv_igemm.hip": 11, "conv_pl.hip": 11, "conv_w64.hip": 8, "conv_kg.hip": 3, "conv_rd.hip": 2, "aux_kernels.hip": 19}
+MIN_STUBS = {"conv_igemm.hip": 6, "conv_pl.hip": 11, "aux_kernels.hip": 16}
+MIN_STUBS_EXP = {"conv_igemm.hip": 11, "conv_pl.hip": 11, "conv_w64.hip": 8, "conv_kg.hip": 3, "conv_rd.hip": 2, "aux_kernels.hip": 20}
 
 
 def hipcc() -> str:
@@ -32,7 +35,7 @@ def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    deps = [os.path.join(CSRC, s) for s in SOURCES + EXP_SOURCES + HEADERS]
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
@@ -51,7 +54,8 @@ def _build(force: bool, verbose: bool, LIB: str, objdir: str, extra) -> str:
     objs = []
     os.makedirs(objdir, exist_ok=True)
     procs = []
-    for src in SOURCES:
+    sources = SOURCES + (EXP_SOURCES if extra else [])
+    for src in sources:
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         cmd = [cc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c",
                os.path.join(CSRC, src), "-o", obj] + list(extra) + os.environ.get("BP_CFLAGS", "").split()
@@ -66,7 +70,7 @@ def _build(force: bool, verbose: bool, LIB: str, objdir: str, extra) -> str:
         if verbose and out.strip():
             print(out)
     nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
-    for src, want in MIN_STUBS.items():
+    for src, want in (MIN_STUBS_EXP if extra else MIN_STUBS).items():
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         syms = subprocess.run([nm, obj], stdout=subprocess.PIPE, text=True).stdout
         have = syms.count("__device_stub__")

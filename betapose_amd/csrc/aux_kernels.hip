@@ -6,6 +6,23 @@
 
 namespace bp {
 
+// ---- operand planes (bp_common.h ConvParams::out16) from the small producers: one fp16 plane or three bf16 planes that
+// sum to the fp32 value exactly, at the same element index as the fp32 store
+__device__ __forceinline__ void store_plane(unsigned short* planes, long long idx, long long plane_elems, int np, float v) {
+    if (np == 1) {
+        const _Float16 h = (_Float16)v;
+        planes[idx] = __builtin_bit_cast(unsigned short, h);
+    } else if (np == 3) {
+        const __bf16 h1 = (__bf16)v;
+        const float r1 = v - (float)h1;
+        const __bf16 h2 = (__bf16)r1;
+        const __bf16 h3 = (__bf16)(r1 - (float)h2);
+        planes[idx] = __builtin_bit_cast(unsigned short, h1);
+        planes[idx + plane_elems] = __builtin_bit_cast(unsigned short, h2);
+        planes[idx + 2 * plane_elems] = __builtin_bit_cast(unsigned short, h3);
+    }
+}
+
 static inline int grid_for(long long n, int block = 256, int cap = 4096) {
     BP_CHECK(n < (1ll << 31), "tensor too large for 32-bit indexing");
     long long g = (n + block - 1) / block;
@@ -49,7 +66,7 @@ void launch_nhwc_to_nchw(const float* in, int in_ld, float* out, int N, int C, i
 
 // ---------------------------------------------------------------- max-pool 3x3 / stride 2 / pad 1 (NHWC)
 __global__ void maxpool3s2p1_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int H, int W, int C,
-                                    int OH, int OW) {
+                                    int OH, int OW, unsigned short* __restrict__ planes, long long plane_elems, int np) {
     const int C4 = C >> 2;
     const long long total = (long long)N * OH * OW * C4;
     // 32-bit index math: every tensor on this path has < 2^31 elements (checked by the launchers), and 64-bit
@@ -72,13 +89,20 @@ __global__ void maxpool3s2p1_kernel(const float* __restrict__ in, float* __restr
                 m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
             }
         }
-        *reinterpret_cast<float4*>(out + (((long long)n * OH + oy) * OW + ox) * C + c4 * 4) = m;
+        const long long o = (((long long)n * OH + oy) * OW + ox) * C + c4 * 4;
+        *reinterpret_cast<float4*>(out + o) = m;
+        if (np) {
+            store_plane(planes, o, plane_elems, np, m.x); store_plane(planes, o + 1, plane_elems, np, m.y);
+            store_plane(planes, o + 2, plane_elems, np, m.z); store_plane(planes, o + 3, plane_elems, np, m.w);
+        }
     }
 }
-void launch_maxpool3s2p1(const float* in, float* out, int N, int H, int W, int C, int OH, int OW, hipStream_t s) {
+void launch_maxpool3s2p1(const float* in, float* out, int N, int H, int W, int C, int OH, int OW, hipStream_t s,
+                         unsigned short* planes, long long plane_elems, int np) {
     BP_CHECK(C % 4 == 0, "maxpool: C % 4");
     const long long total = (long long)N * OH * OW * (C / 4);
-    hipLaunchKernelGGL(maxpool3s2p1_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, out, N, H, W, C, OH, OW);
+    hipLaunchKernelGGL(maxpool3s2p1_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, out, N, H, W, C, OH, OW,
+                       planes, plane_elems, planes ? np : 0);
 }
 
 // ---------------------------------------------------------------- residual add / channel copy / upsample (fallbacks)
@@ -134,7 +158,8 @@ void launch_upsample2(const float* in, int in_ld, float* out, int out_ld, int N,
 }
 
 // PixelShuffle(2), NHWC in [N][H][W][C] -> out [N][2H][2W][C/4]; NCHW semantics: out[c, 2h+i, 2w+j] = in[c*4+i*2+j, h, w]
-__global__ void pixel_shuffle2_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int H, int W, int C) {
+__global__ void pixel_shuffle2_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int H, int W, int C,
+                                      unsigned short* __restrict__ planes, long long plane_elems, int np) {
     const int Co = C >> 2;
     const long long total = (long long)N * H * W * C;
     // 32-bit index math: every tensor on this path has < 2^31 elements (checked by the launchers), and 64-bit
@@ -147,11 +172,15 @@ __global__ void pixel_shuffle2_kernel(const float* __restrict__ in, float* __res
         const int y = (int)(t % (2 * H));
         const int n = (int)(t / (2 * H));
         const int ci = co * 4 + (y & 1) * 2 + (x & 1);
-        out[e] = in[(((long long)n * H + (y >> 1)) * W + (x >> 1)) * C + ci];
+        const float v = in[(((long long)n * H + (y >> 1)) * W + (x >> 1)) * C + ci];
+        out[e] = v;
+        if (np) store_plane(planes, e, plane_elems, np, v);
     }
 }
-void launch_pixel_shuffle2(const float* in, float* out, int N, int H, int W, int C, hipStream_t s) {
-    hipLaunchKernelGGL(pixel_shuffle2_kernel, dim3(grid_for((long long)N * H * W * C)), dim3(256), 0, s, in, out, N, H, W, C);
+void launch_pixel_shuffle2(const float* in, float* out, int N, int H, int W, int C, hipStream_t s,
+                           unsigned short* planes, long long plane_elems, int np) {
+    hipLaunchKernelGGL(pixel_shuffle2_kernel, dim3(grid_for((long long)N * H * W * C)), dim3(256), 0, s, in, out, N, H, W, C,
+                       planes, plane_elems, planes ? np : 0);
 }
 
 // ---------------------------------------------------------------- SE: global average pool + FC
@@ -541,6 +570,7 @@ void launch_resize_bicubic(const uint8_t* in, int batch, int H, int W, uint8_t* 
                        out_nhwc, out_u8, oh, t.vb, t.vk, t.ksize_v, swap_rb);
 }
 
+#ifdef BP_EXPERIMENTAL   // filter formats of the round-1/2 16-bit kernels (conv_igemm_h / conv_w64 / conv_kg / conv_rd)
 // ---- packed filters fp32 -> fp16 (RNE), once per weight store when the fp16-MFMA path is switched on
 __global__ void f32_to_f16_kernel(const float* __restrict__ in, _Float16* __restrict__ out, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -615,6 +645,8 @@ void launch_f32_to_f16_staged(const float* in, unsigned short* out, int CoutPad,
                        reinterpret_cast<_Float16*>(out), CoutPad, Kpad);
 }
 
+#endif   // BP_EXPERIMENTAL
+
 // ---- placement probe: which XCD / CU every workgroup of a grid landed on (CU-mask experiments, tests)
 __global__ void probe_placement_kernel(int* out) {
     if (threadIdx.x == 0) {
@@ -624,6 +656,13 @@ __global__ void probe_placement_kernel(int* out) {
         out[2 * blockIdx.x + 1] = (int)hw;
     }
 }
+
+// ---- clock calibration for the s_memtime stamps of the convolution kernels (c_api.cpp bp_calibrate_ticks)
+__global__ void spin_ticks_kernel(long long ticks) {
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    while ((long long)(__builtin_readcyclecounter() - t0) < ticks) __builtin_amdgcn_s_sleep(1);
+}
+void launch_spin_ticks(long long ticks, hipStream_t s) { hipLaunchKernelGGL(spin_ticks_kernel, dim3(1), dim3(1), 0, s, ticks); }
 
 void launch_probe_placement(int* d_out, int blocks, hipStream_t s) {
     hipLaunchKernelGGL(probe_placement_kernel, dim3(blocks), dim3(64), 0, s, d_out);

@@ -78,6 +78,7 @@ struct ConvParams {
     unsigned short* out16;        // planes of `out` (null: not emitted)
     long long out16_plane;
     int out_np;                   // planes the epilogue emits: 0 none, 1 fp16, 3 bf16x3
+    int skip_f32;                 // 1: every reader of `out` takes the planes -- the fp32 store is dropped (engine.cpp plan_planes)
     int abl;                      // timing ablations, experimental builds only (-DBP_EXPERIMENTAL; tools/abl_pl.sh): 0 in the product
     const unsigned short* wpl;    // filters as conv_pl.hip's LDS image: [CoutPad/64][nchunks][plane][64 rows][64 B swizzled]
 };
@@ -118,10 +119,13 @@ void launch_conv_pl(const ConvParams& p, int tile, hipStream_t s);    // conv_pl
 bool conv_tile_is_pl(int tile);
 bool conv_pl_eligible(const ConvParams& p);   // planes + wpl present, Cin % 32 == 0, taps fit the 32-bit mask
 // filters [CoutPad][Kpad] fp32 -> conv_pl.hip's LDS image, np = 1 (fp16) or 3 (exact bf16 split)
-void launch_pack_wpl(const float* in, unsigned short* out, int CoutPad, int Kpad, int np, hipStream_t s);
+void launch_pack_wpl(const float* in, unsigned short* out, int CoutPad, int Kpad, int Cin, int ksize, int np, hipStream_t s);
 // fp32 NHWC view -> its operand planes (producers that are not convolutions; tests)
 void launch_f32_to_planes(const float* in, int ld, long long pixels, int C, unsigned short* planes, long long plane_elems,
                           int np, hipStream_t s);
+// ... and back (test taps of tensors whose fp32 store was dropped): exact for np == 3
+void launch_planes_to_f32(const unsigned short* planes, long long plane_elems, int np, float* out, int ld, long long pixels, int C,
+                          hipStream_t s);
 int conv_tiles(const ConvParams& p, int tile);   // blocks per K-slice
 int conv_tile_bm(int tile);
 int conv_tile_bn(int tile);
@@ -129,12 +133,15 @@ int conv_tile_bn(int tile);
 // ---- auxiliary kernels (aux_kernels.hip) ----
 void launch_nchw_to_nhwc(const float* in, float* out, int N, int C, int H, int W, hipStream_t s);
 void launch_nhwc_to_nchw(const float* in, int in_ld, float* out, int N, int C, int H, int W, hipStream_t s);
-void launch_maxpool3s2p1(const float* in, float* out, int N, int H, int W, int C, int OH, int OW, hipStream_t s);
+// planes / plane_elems / np: operand planes of `out` written alongside (ConvParams::out16; null = none)
+void launch_maxpool3s2p1(const float* in, float* out, int N, int H, int W, int C, int OH, int OW, hipStream_t s,
+                         unsigned short* planes = nullptr, long long plane_elems = 0, int np = 0);
 void launch_add(const float* a, int a_ld, const float* b, int b_ld, float* out, int out_ld,
                 long long pixels, int C, hipStream_t s);
 void launch_upsample2(const float* in, int in_ld, float* out, int out_ld, int N, int H, int W, int C, hipStream_t s);
 void launch_copy_channels(const float* in, int in_ld, float* out, int out_ld, long long pixels, int C, hipStream_t s);
-void launch_pixel_shuffle2(const float* in, float* out, int N, int H, int W, int C, hipStream_t s);
+void launch_pixel_shuffle2(const float* in, float* out, int N, int H, int W, int C, hipStream_t s,
+                           unsigned short* planes = nullptr, long long plane_elems = 0, int np = 0);
 // out [N][P][C] per-slice sums, P = avgpool_parts(HW); the consumer (launch_fc, in_parts=P) finishes the mean
 int avgpool_parts(int HW);
 void launch_avgpool(const float* in, int in_ld, float* out, int N, int HW, int C, hipStream_t s);
@@ -165,6 +172,7 @@ void launch_f32_to_bf16x3(const float* in, unsigned short* out_planes, long long
 void launch_f32_to_f16_staged(const float* in, unsigned short* out, int CoutPad, int Kpad, hipStream_t s);      // ... fp16 mode
 void launch_f32_to_bf16x3_staged(const float* in, unsigned short* out, int CoutPad, int Kpad, hipStream_t s);   // conv_kg.hip's layout
 void launch_probe_placement(int* d_out, int blocks, hipStream_t s);
+void launch_spin_ticks(long long ticks, hipStream_t s);   // one thread spinning until s_memtime has advanced by `ticks`
 
 // crop stage (dataloader.py:794-835 + img.py:242-262) on device.
 //  frames: BGR u8 [batch][H][W][3]; sel: [batch][8] select records (box in YOLO-input pixels) or boxes [batch][4];

@@ -375,6 +375,38 @@ int bp_kpd_profile(bp_kpd* k, int batch, int iters, float* ms, int* info, int ca
     return k->net->profile(batch, iters, ms, info, cap, (hipStream_t)stream);
     BP_CATCH
 }
+int bp_calibrate_ticks(long long ticks, float* ms, void* stream) {
+    BP_TRY
+    BP_CHECK(ms && ticks > 0, "arguments");
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    BP_HIP(hipEventCreate(&e0));
+    BP_HIP(hipEventCreate(&e1));
+    bp::launch_spin_ticks(1000, s);            // warm
+    BP_HIP(hipEventRecord(e0, s));
+    bp::launch_spin_ticks(ticks, s);
+    BP_HIP(hipEventRecord(e1, s));
+    BP_HIP(hipEventSynchronize(e1));
+    BP_HIP(hipEventElapsedTime(ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return 0;
+    BP_CATCH
+}
+int bp_yolo_set_stamps(bp_yolo* y, unsigned long long* d_buf, int slots) { y->net->set_stamps(d_buf, slots); return 0; }
+int bp_kpd_set_stamps(bp_kpd* k, unsigned long long* d_buf, int slots) { k->net->set_stamps(d_buf, slots); return 0; }
+static int op_name(const bp::Net& net, int i, char* out, int cap) {
+    if (i < 0 || i >= (int)net.ops().size() || !out || cap <= 0) return -1;
+    const bp::Op& op = net.ops()[i];
+    if (op.type == bp::OP_CONV)   // "<name> k<ksize> <OH>x<OW> <Cin>-><Cout> s<stride>"
+        std::snprintf(out, (size_t)cap, "%s k%d %dx%d %d->%d s%d", net.op_name(i), op.conv.ksize, op.conv.OH, op.conv.OW, op.conv.Cin,
+                      op.conv.Cout, op.conv.stride);
+    else
+        std::snprintf(out, (size_t)cap, "%s", net.op_name(i));
+    return op.type == bp::OP_CONV ? 1 : 0;
+}
+int bp_yolo_op_name(const bp_yolo* y, int i, char* out, int cap) { return op_name(*y->net, i, out, cap); }
+int bp_kpd_op_name(const bp_kpd* k, int i, char* out, int cap) { return op_name(*k->net, i, out, cap); }
 size_t bp_yolo_device_bytes(const bp_yolo* y) { return y->net->device_bytes(); }
 size_t bp_kpd_device_bytes(const bp_kpd* k) { return k->net->device_bytes(); }
 
@@ -457,8 +489,12 @@ int bp_conv2d_planes(const float* d_in, int N, int H, int W, int Cin, const floa
     if (t >= 256) {   // + 256: fp16-MFMA operands, + 512: bf16x3 split operands
         prec = t >= 512 ? bp::PREC_BF16X3 : bp::PREC_F16;
         t -= t >= 512 ? 512 : 256;
+        BP_CHECK(Cin % 32 == 0, "layer is not eligible for the 16-bit MFMA paths (needs Cin % 32 == 0)");
         net.set_precision(prec);
-        BP_CHECK(net.ops_[0].conv.mfma_mode == prec, "layer is not eligible for the 16-bit MFMA paths (needs Cin % 32 == 0)");
+        net.ops_[0].conv.mfma_mode = prec;
+#ifndef BP_EXPERIMENTAL
+        BP_CHECK(bp::conv_tile_is_pl(t), "this kernel id exists only in the experimental library (python -m betapose_amd.build --experimental, BP_LIB)");
+#endif
     } else {
         BP_CHECK(t <= bp::TILE_128x64, "this tile needs a 16-bit precision mode (tile + 256 / + 512)");
     }
@@ -477,7 +513,7 @@ int bp_conv2d_planes(const float* d_in, int N, int H, int W, int Cin, const floa
         auto it = packed.find(p.w);
         if (it == packed.end()) {
             unsigned short* d = (unsigned short*)net.weight_store()->arena.alloc_bytes((size_t)np * p.CoutPad * p.Kpad * 2);
-            bp::launch_pack_wpl(p.w, d, p.CoutPad, p.Kpad, np, s);
+            bp::launch_pack_wpl(p.w, d, p.CoutPad, p.Kpad, p.Cin, p.ksize, np, s);
             it = packed.emplace(p.w, d).first;
         }
         p.wpl = it->second;

@@ -8,6 +8,14 @@
 
 #include "bp_common.h"
 
+// The timing ablations (BP_ABLATE_*: parts of a kernel compiled out, WRONG results) and the measured-and-superseded
+// kernels exist only in the experimental library: `python -m betapose_amd.build --experimental` defines BP_EXPERIMENTAL.
+#if !defined(BP_EXPERIMENTAL) && (defined(BP_ABLATE_SPLIT) || defined(BP_ABLATE_MFMA) || defined(BP_ABLATE_KLOOP) || defined(BP_ABLATE_PREFETCH) || \
+    defined(BP_ABLATE_TAIL) || defined(BP_ABLATE_SLABSTORE) || defined(BP_ABLATE_ACKWAIT) || defined(BP_ABLATE_REDUCE) || defined(BP_ABLATE_EPILOGUE) || \
+    defined(BP_W64_DEBUG))
+#error "BP_ABLATE_* / BP_W64_DEBUG are timing experiments with wrong results: build them with -DBP_EXPERIMENTAL only (build.py --experimental)"
+#endif
+
 namespace bp {
 
 // compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N-1>{}) -- for bodies whose
@@ -47,12 +55,14 @@ static constexpr unsigned OOB = 0x7fffff00u;   // byte offset beyond any descrip
 struct PlaneDesc {
     __amdgpu_buffer_rsrc_t r0, r1, r2;   // one descriptor per plane, each ending at row M: rows past the tensor are dropped
     int np;
+    bool f32;                            // the fp32 tensor is stored too (false: every reader takes the planes)
 };
 __device__ __forceinline__ PlaneDesc make_plane_desc(const ConvParams& p) {
     PlaneDesc d;
     unsigned short* base = p.out16 ? p.out16 : reinterpret_cast<unsigned short*>(p.out);
     const int bytes = (int)min((long long)p.M * p.out_ld * 2, (long long)0x7fffff00);
     d.np = p.out16 ? p.out_np : 0;
+    d.f32 = !(p.out16 && p.skip_f32);
     d.r0 = __builtin_amdgcn_make_buffer_rsrc(base, 0, bytes, 0x00020000);
     d.r1 = __builtin_amdgcn_make_buffer_rsrc(base + (d.np == 3 ? p.out16_plane : 0), 0, bytes, 0x00020000);
     d.r2 = __builtin_amdgcn_make_buffer_rsrc(base + (d.np == 3 ? 2 * p.out16_plane : 0), 0, bytes, 0x00020000);
@@ -118,9 +128,10 @@ __device__ __forceinline__ void epilogue_store(const ConvParams& p, int m, int n
     if (!p.res_after_act) v += r;
     v = apply_act(v, p.act);
     if (p.res_after_act) v += r;
+    const bool keep32 = !(p.out16 && p.skip_f32);
     switch (p.store_mode) {
         case ST_NHWC:
-            p.out[(long long)m * p.out_ld + n] = v;
+            if (keep32) p.out[(long long)m * p.out_ld + n] = v;
             emit_plane1(p, (long long)m * p.out_ld + n, v);
             break;
         case ST_UP2: {
@@ -128,10 +139,12 @@ __device__ __forceinline__ void epilogue_store(const ConvParams& p, int m, int n
             const int W2 = 2 * p.OW;
             const long long i0 = ((long long)(b * 2 * p.OH + 2 * oy) * W2 + 2 * ox) * p.out_ld + n;
             float* o = p.out + i0;
-            o[0] = v;
-            o[p.out_ld] = v;
-            o[(long long)W2 * p.out_ld] = v;
-            o[(long long)(W2 + 1) * p.out_ld] = v;
+            if (keep32) {
+                o[0] = v;
+                o[p.out_ld] = v;
+                o[(long long)W2 * p.out_ld] = v;
+                o[(long long)(W2 + 1) * p.out_ld] = v;
+            }
             emit_plane1(p, i0, v);
             emit_plane1(p, i0 + p.out_ld, v);
             emit_plane1(p, i0 + (long long)W2 * p.out_ld, v);
@@ -143,7 +156,7 @@ __device__ __forceinline__ void epilogue_store(const ConvParams& p, int m, int n
             const int ij = n / cq, c = n - ij * cq;
             const int y = 2 * oy + (ij >> 1), x = 2 * ox + (ij & 1);
             const long long i0 = ((long long)(b * 2 * p.OH + y) * (2 * p.OW) + x) * p.out_ld + c;
-            p.out[i0] = v;
+            if (keep32) p.out[i0] = v;
             emit_plane1(p, i0, v);
         } break;
         case ST_NCHW:
@@ -154,14 +167,14 @@ __device__ __forceinline__ void epilogue_store(const ConvParams& p, int m, int n
 
 // 16 accumulators of one lane: column n, rows m_base + (r&3) + 8*(r>>2) -- element-wise epilogue for the store
 // modes / alignments the staged float4 path does not cover (heads with 18 channels, upsample, PixelShuffle, NCHW)
-__device__ __forceinline__ void epilogue_tile(const ConvParams& p, const float* v, int m_base, int n) {
+__device__ __forceinline__ void epilogue_tile(const ConvParams& p, const f32x16& v, int m_base, int n) {
     if (n >= p.Cout) return;
     const float bias = p.bias[n];
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
+    static_for<16>([&](auto ec) __attribute__((always_inline)) {
+        constexpr int e = decltype(ec)::value;
         const int m = m_base + (e & 3) + 8 * (e >> 2);
         if (m < p.M) epilogue_store(p, m, n, v[e], bias);
-    }
+    });
 }
 
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, int soff) {
@@ -220,7 +233,7 @@ __device__ __forceinline__ void epilogue_rows(const float* srow, int s_step, f32
         }
         if constexpr (RES == 2) v += r4;
         const u32x4 o = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-        __builtin_amdgcn_raw_buffer_store_b128(o, rsrcO, (int)off_o, 0, 0);
+        if (pd.f32) __builtin_amdgcn_raw_buffer_store_b128(o, rsrcO, (int)off_o, 0, 0);
         emit_planes4(pd, v, off_o >> 1);      // the planes mirror the fp32 view: same element index, half the bytes
         srow += s_step;
         off_o += step_o;

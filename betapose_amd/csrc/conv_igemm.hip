@@ -292,6 +292,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     if (p.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); BP_STAMP(4); }
 }
 
+#ifdef BP_EXPERIMENTAL   // round-1/2 kernels with fp32 activations converted in the K loop: measured, superseded by conv_pl.hip,
+                         // kept for A/B timing in the experimental library only (build.py --experimental)
 // =====================================================================================================================
 // 16-bit-operand MFMA variants.  Same tiling, K walk, split-K hand-off and epilogue (conv_tail.inc) as the fp32 kernel;
 // what changes is what the matrix cores multiply.  Activations stay fp32 in HBM and are converted when a chunk is
@@ -581,6 +583,8 @@ __global__ __launch_bounds__(256) void conv_igemm_h_kernel(const ConvParams p) {
 #undef BH_PHASE
 }
 
+#endif   // BP_EXPERIMENTAL
+
 thread_local ConvProfHook* g_conv_prof = nullptr;
 
 int conv_tile_bm(int tile) {
@@ -621,6 +625,7 @@ static void launch_t(const ConvParams& p, hipStream_t s) {
     }
 }
 
+#ifdef BP_EXPERIMENTAL
 template <int TM, int TN, int NP, bool BD = false>
 static void launch_h_t(const ConvParams& p, hipStream_t s) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
@@ -630,6 +635,8 @@ static void launch_h_t(const ConvParams& p, hipStream_t s) {
     else
         hipLaunchKernelGGL((conv_igemm_h_kernel<TM, TN, NP, BD>), grid, dim3(256), 0, s, p);
 }
+
+#endif
 
 int conv_vec_mode(const ConvParams& p) {
     if ((p.Cin % 32 == 0) && (p.in_ld % 4 == 0) && p.ksize <= 8) return 1;
@@ -655,6 +662,7 @@ void launch_conv(const ConvParams& p, int tile, hipStream_t s) {
              "output / residual tensor too large for 32-bit offsets");
     if (conv_tile_is_pl(tile)) {
         launch_conv_pl(p, tile, s);
+#ifdef BP_EXPERIMENTAL
     } else if (conv_tile_is_w64(tile)) {
         launch_conv_w64(p, tile, s);
     } else if (conv_tile_is_kg(tile)) {
@@ -679,7 +687,10 @@ void launch_conv(const ConvParams& p, int tile, hipStream_t s) {
         } else {
             launch_h_t<1, 1, 3>(p, s);
         }
+#endif
     } else {
+        BP_CHECK(tile == TILE_64x64 || tile == TILE_128x64,
+                 "this kernel id exists only in the experimental library (python -m betapose_amd.build --experimental, BP_LIB)");
         switch (tile) {
             case TILE_128x64: launch_t<2, 1>(p, s); break;
             default: launch_t<1, 1>(p, s); break;

@@ -52,7 +52,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_pl_kernel(const ConvParams 
     constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64;        // bytes per plane and chunk
     constexpr int CHUNK = NP * (A_PLANE + B_PLANE);
     constexpr int STAGE = CPS * CHUNK;
-    constexpr int EPI_BYTES = BM * LDT * 4;
+    constexpr int EP_SLABS_ = BM > 128 ? BM / 64 : 1;       // epilogue staging in 64-row slabs on the big tiles (conv_tail.inc)
+    constexpr int EPI_BYTES = (BM / EP_SLABS_) * LDT * 4;
     constexpr int SMEM_BYTES = (NST * STAGE > EPI_BYTES ? NST * STAGE : EPI_BYTES) + 16;
     // the ONE LDS object of the kernel (a second one makes hipcc drain vmcnt before every fragment read)
     __shared__ __attribute__((aligned(16))) float smem[SMEM_BYTES / 4];
@@ -111,6 +112,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_pl_kernel(const ConvParams 
         const int hw = p.OH * p.OW;
         const float rcp_hw = 1.0f / (float)hw, rcp_ow = 1.0f / (float)p.OW;
         const int gsw = (lane & 3) ^ ((lane >> 4) & 3);       // the granule this lane fetches (swizzle on the source)
+        unsigned row_pattern = 0;                             // bit ksize * ky for every filter row (wave-uniform)
+        for (int ky = 0; ky < p.ksize; ++ky) row_pattern |= 1u << (ky * p.ksize);
 #pragma unroll
         for (int gi = 0; gi < GA; ++gi) {
             const int m = m0 + 16 * (wave + NW * gi) + (lane >> 2);
@@ -124,10 +127,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_pl_kernel(const ConvParams 
             a_base[gi] = (unsigned)((((b * p.H + iy0) * p.W + ix0) * p.in_ld + gsw * 8) * 2);
             const int kx_lo = max(0, -ix0), kx_hi = min(p.ksize, p.W - ix0);
             const int ky_lo = max(0, -iy0), ky_hi = min(p.ksize, p.H - iy0);
+            // taps (ky, kx) inside the image = [ky_lo, ky_hi) x [kx_lo, kx_hi): the kx run, repeated at bit ksize * ky for
+            // every ky of the range -- one multiply by the 'one bit per filter row' pattern (no overlap: the run is < 2^ksize)
             unsigned mask = 0;
-            if (ok && kx_hi > kx_lo) {
+            if (ok && kx_hi > kx_lo && ky_hi > ky_lo) {
                 const unsigned rowbits = ((1u << kx_hi) - 1u) & ~((1u << kx_lo) - 1u);
-                for (int ky = ky_lo; ky < ky_hi; ++ky) mask |= rowbits << (ky * p.ksize);
+                const unsigned kyrange = (ky_hi * p.ksize >= 32 ? 0xffffffffu : (1u << (ky_hi * p.ksize)) - 1u) & ~((1u << (ky_lo * p.ksize)) - 1u);
+                mask = rowbits * (row_pattern & kyrange);
             }
             a_mask[gi] = mask;
         }
@@ -144,60 +150,74 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_pl_kernel(const ConvParams 
     const unsigned b_voff = (unsigned)(lane * 16);
     constexpr int IPW = CPS * NP * (GA + KB);     // DMA instructions per wave and stage
 
-    // ---- wave-uniform walk over K in 32-k chunks: chunk -> (tap bit, byte offset of the tap's channel run)
+    // ---- wave-uniform walk over K in 32-k chunks.  K ORDER: (32-channel group, ky, kx, channel) -- the filter taps are
+    // the INNER loop.  A 3x3 layer re-reads every activation row once per tap; tap-major order (the order of the round-1/2
+    // kernels) puts those nine reads a whole channel sweep apart, and at batch 28 the rows an XCD's blocks hold between two
+    // reads of the same line exceed its 4 MB L2 (tools/micro/dma_bw.hip: LDS-DMA moves 55 B/clk/CU from L2, 14 from the
+    // memory side).  With the taps innermost the nine reads of a 64-B channel run are nine CONSECUTIVE stages.
+    // chunk c -> (group c / taps, tap c % taps); the packed filters (launch_pack_wpl) use the same order.
     int w_left = c_end - c_begin;                 // chunks of this block's K range not yet requested
-    int w_ci, w_kx;
-    unsigned w_tapbit, w_delta;
+    int w_kx, w_tap;
+    unsigned w_delta;
     int w_bsrc = c_begin * (NP * 4096);
+    const int k_ks = p.ksize, k_taps = p.ksize * p.ksize;
     {
-        const int cpt = p.Cin >> 5;
-        const int tap = c_begin / cpt;
-        const int ky = tap / p.ksize;
-        w_kx = tap - ky * p.ksize;
-        w_ci = (c_begin - tap * cpt) << 5;
-        w_tapbit = 1u << tap;
-        w_delta = (unsigned)(((ky * p.W + w_kx) * p.in_ld + w_ci) * 2);
+        const int grp = c_begin / k_taps;
+        w_tap = c_begin - grp * k_taps;
+        const int ky = w_tap / p.ksize;
+        w_kx = w_tap - ky * p.ksize;
+        w_delta = (unsigned)(((ky * p.W + w_kx) * p.in_ld + grp * 32) * 2);
     }
-    const int k_cin = p.Cin, k_ks = p.ksize;
-    const unsigned k_step_tap = (unsigned)((p.in_ld - p.Cin + 32) * 2);       // last chunk of a tap -> first chunk of the next
-    const unsigned k_step_row = (unsigned)(((p.W - p.ksize) * p.in_ld) * 2);  // ... and on to the next filter row
+    const unsigned k_step_kx = (unsigned)(p.in_ld * 2);                                      // next tap in the filter row
+    const unsigned k_step_row = (unsigned)(((p.W - (p.ksize - 1)) * p.in_ld) * 2);           // ... first tap of the next row
+    const unsigned k_d_row = k_step_row - k_step_kx;
+    const unsigned k_step_grp = (unsigned)(64 - (((p.ksize - 1) * p.W + (p.ksize - 1)) * p.in_ld) * 2);   // ... tap 0 of the next group
 
-    // all DMAs of the stage the walk points at -> LDS ring slot at byte offset `so`; advances the walk.  Past the K range
-    // every offset is out of range (no memory traffic; zeros land in a slot nobody reads), so the loop body is branch-free
-    // and every stage issues the same number of instructions -- which is what the counted waits count.
-    auto issue_stage = [&](int so) __attribute__((always_inline)) {
+    const unsigned k_d_grp = k_step_grp - k_step_row;
+    // ---- one stage's DMA list, addressed by a compile-time index so that every instruction can be pinned into its own
+    // MFMA slot.  Per chunk j of the stage: GA x NP activation pieces (row group, plane), then NP x KB filter pieces.
+    // The per-lane / per-wave offsets of the stage are computed once (stage_addr) from the walk, BEFORE the stage wait.
+    // Past the K range every offset is out of range (no memory traffic; zeros land in a slot nobody reads), so the loop
+    // body is branch-free and every stage issues the same number of instructions -- what the counted waits count.
+    constexpr int DPC = NP * (GA + KB);           // pieces per chunk
+    static_assert(IPW == CPS * DPC, "");
+    unsigned st_va[CPS][GA], st_vb[CPS];
+    int st_bs[CPS];
+    auto stage_addr = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < CPS; ++j) {
-            const unsigned tapbit = w_left > 0 ? w_tapbit : 0u;
+            const unsigned tapbit = w_left > 0 ? (1u << w_tap) : 0u;
             const unsigned dead = w_left > 0 ? 0u : OOB;
-            char* const dst = sb + so + j * CHUNK;
 #pragma unroll
-            for (int gi = 0; gi < GA; ++gi) {
-                const unsigned va = (a_mask[gi] & tapbit) ? a_base[gi] + w_delta : OOB;
-                char* const d = dst + (wave + NW * gi) * 1024;
-                if (abl & 1) continue;
-                dma16(rsrcA, d, va, 0);
-                if constexpr (NP == 3) {
-                    dma16(rsrcA, d + A_PLANE, va, (int)pl_bytes);
-                    dma16(rsrcA, d + 2 * A_PLANE, va, (int)(2 * pl_bytes));
-                }
-            }
-            const unsigned vb = b_voff | dead;
-#pragma unroll
-            for (int pl = 0; pl < NP; ++pl)
-#pragma unroll
-                for (int k = 0; k < KB; ++k)
-                    if (!(abl & 2)) dma16(rsrcB, dst + b_lds0 + pl * B_PLANE + k * (NW * 1024), vb, b_src0 + w_bsrc + k * b_srck + pl * 4096);
+            for (int gi = 0; gi < GA; ++gi) st_va[j][gi] = (a_mask[gi] & tapbit) ? a_base[gi] + w_delta : OOB;
+            st_vb[j] = b_voff | dead;
+            st_bs[j] = b_src0 + w_bsrc;
             --w_left;
             w_bsrc += NP * 4096;
-            const bool wrap = w_ci + 32 == k_cin;
-            w_ci = wrap ? 0 : w_ci + 32;
-            w_delta += wrap ? k_step_tap : 64u;
-            w_tapbit = wrap ? w_tapbit << 1 : w_tapbit;
-            const int kx1 = w_kx + (wrap ? 1 : 0);
-            const bool wrap2 = kx1 == k_ks;
-            w_kx = wrap2 ? 0 : kx1;
-            w_delta += wrap2 ? k_step_row : 0u;
+            // (plain sums of selected increments: with the nested select `a ? x : (b ? y : z)` on this captured state hipcc
+            // kept the whole walk in scratch and wrapped every DMA in a readfirstlane waterfall loop -- 2-3x slower)
+            const int last_tap = (w_tap + 1 == k_taps) ? 1 : 0;
+            const int last_kx = (w_kx + 1 == k_ks) ? 1 : 0;
+            w_delta += k_step_kx + (last_kx ? k_d_row : 0u) + (last_tap ? k_d_grp : 0u);
+            w_tap = last_tap ? 0 : w_tap + 1;
+            w_kx = last_kx ? 0 : w_kx + 1;
+        }
+    };
+    auto dma_piece = [&](int so, auto dc) __attribute__((always_inline)) {
+        constexpr int d = decltype(dc)::value;
+        constexpr int j = d / DPC, e = d % DPC;
+        char* const dst = sb + so + j * CHUNK;
+        if constexpr (e < GA * NP) {
+            constexpr int gi = e / NP, pl = e % NP;
+            if (abl & 1) return;
+            const unsigned va = st_va[j][gi];
+            dma16(rsrcA, dst + pl * A_PLANE + (wave + NW * gi) * 1024, va, pl == 0 ? 0 : (pl == 1 ? (int)pl_bytes : (int)(2 * pl_bytes)));
+        } else {
+            constexpr int pl = (e - GA * NP) / KB, k = (e - GA * NP) % KB;
+            if (abl & 2) return;
+            const unsigned vb = st_vb[j];
+            const int so_ = st_bs[j] + k * b_srck + pl * 4096;
+            dma16(rsrcB, dst + b_lds0 + pl * B_PLANE + k * (NW * 1024), vb, so_);
         }
     };
 
@@ -218,63 +238,86 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_pl_kernel(const ConvParams 
     constexpr int PA[6] = {2, 1, 0, 1, 0, 0};     // partial products (A plane, B plane), smallest first
     constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
     constexpr int NSTEP = 2 * CPS;                 // 16-k MFMA steps per stage
+    constexpr int NMF = NPROD * TM * TN;           // MFMAs per step
+    constexpr int NRD = NP * (TM + TN);            // fragments per step
     frag_t fa[2][NP][TM], fb[2][NP][TN];
-
-    auto read_step = [&](int so, auto sc, auto setc) __attribute__((always_inline)) {
-        constexpr int s = decltype(sc)::value, fs = decltype(setc)::value;
+    // fragment r of a step, in the order the step's MFMAs first need them: (A plane 2, B plane 0), (A 1, B 1), (A 0, B 2)
+    constexpr int RPA[3] = {2, 1, 0}, RPB[3] = {0, 1, 2};
+    auto read_frag = [&](int so, auto sc, auto rc) __attribute__((always_inline)) {
+        constexpr int s = decltype(sc)::value, r = decltype(rc)::value, fs = s & 1;
         constexpr int j = s >> 1, ks = s & 1;
-        const char* const base = sb + so + j * CHUNK;
+        constexpr int grp = r / (TM + TN), e = r % (TM + TN);
         if (abl & 8) return;
-#pragma unroll
-        for (int pl = 0; pl < NP; ++pl) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                fa[fs][pl][i] = *reinterpret_cast<const frag_t*>(base + pl * A_PLANE + i * (32 * 64) + (ks ? (a_rd ^ 32) : a_rd));
-#pragma unroll
-            for (int jn = 0; jn < TN; ++jn)
-                fb[fs][pl][jn] = *reinterpret_cast<const frag_t*>(base + pl * B_PLANE + jn * (32 * 64) + (ks ? (b_rd ^ 32) : b_rd));
+        const char* const base = sb + so + j * CHUNK;
+        if constexpr (e < TM) {
+            constexpr int pl = NP == 1 ? 0 : RPA[grp];
+            fa[fs][pl][e] = *reinterpret_cast<const frag_t*>(base + pl * A_PLANE + e * (32 * 64) + (ks ? (a_rd ^ 32) : a_rd));
+        } else {
+            constexpr int pl = NP == 1 ? 0 : RPB[grp];
+            fb[fs][pl][e - TM] = *reinterpret_cast<const frag_t*>(base + pl * B_PLANE + (e - TM) * (32 * 64) + (ks ? (b_rd ^ 32) : b_rd));
         }
     };
-    auto mfma_step = [&](auto setc) __attribute__((always_inline)) {
-        constexpr int fs = decltype(setc)::value;
+    auto mfma_one = [&](auto sc, auto mc) __attribute__((always_inline)) {
+        constexpr int fs = decltype(sc)::value & 1, m = decltype(mc)::value;
+        constexpr int q = m / (TM * TN), i = (m / TN) % TM, jn = m % TN;
         if (abl & 4) return;
-#pragma unroll
-        for (int q = 0; q < NPROD; ++q)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int jn = 0; jn < TN; ++jn)
-                    acc[i][jn] = HalfOps<NP>::mfma(fa[fs][NP == 1 ? 0 : PA[q]][i], fb[fs][NP == 1 ? 0 : PB[q]][jn], acc[i][jn]);
+        acc[i][jn] = HalfOps<NP>::mfma(fa[fs][NP == 1 ? 0 : PA[q]][i], fb[fs][NP == 1 ? 0 : PB[q]][jn], acc[i][jn]);
     };
 
 #define PL_STAMP(k_) if (p.stamps && tid == 0) p.stamps[(long long)blockIdx.x * 8 + (k_)] = __builtin_readcyclecounter();
+#define PL_SB() __builtin_amdgcn_sched_barrier(0)
     if (p.stamps && tid == 0) p.stamps[(long long)blockIdx.x * 8 + 0] = t_entry;
     PL_STAMP(1);   // index math done
     unsigned long long t_wait = 0;     // debug (p.stamps): cycles parked at the stage waits
+    // One stage = NSTEP x NMF MFMA slots.  An LDS-DMA instruction costs the issuing wave 60-180 cycles and a wave issues in
+    // order, so a stage's DMAs in one clump leave the matrix pipe idle for their whole issue time (measured: 1 130 cycles
+    // per 384-cycle stage that way, of which 120 parked at the wait).  So every non-MFMA instruction is pinned into the
+    // shadow of an MFMA (sched_barrier): behind the barrier the first step's fragments are requested, N0 DMAs are issued
+    // while they arrive, and every MFMA slot then carries its share of the remaining DMAs and of the NEXT step's
+    // fragment reads (front-loaded into the first half of the step, so the last ones are back before they are needed).
+    constexpr int SLOTS = NSTEP * NMF;
+    constexpr int N0 = IPW < 2 ? IPW : 2;
+    constexpr int DREM = IPW - N0;
+    constexpr int HALF = NMF / 2 > 0 ? NMF / 2 : 1;
     {   // (launches give every K slice at least one chunk)
         // prologue: NST - 1 stages in flight
-#pragma unroll
-        for (int s = 0; s < NST - 1; ++s) issue_stage(s * STAGE);
+        static_for<NST - 1>([&](auto sc) __attribute__((always_inline)) {
+            stage_addr();
+            static_for<IPW>([&](auto dc) __attribute__((always_inline)) { dma_piece(decltype(sc)::value * STAGE, dc); });
+        });
         int rd_off = 0, wr_off = (NST - 1) * STAGE;
         int c = c_begin;
         do {
+            stage_addr();
             // this wave's DMAs of the oldest stage have landed (NST - 2 younger stages stay in flight); behind the barrier
             // everybody's have, and everybody is done reading the slot the next issue overwrites
+#ifdef BP_EXPERIMENTAL
             const unsigned long long tw0 = p.stamps ? __builtin_readcyclecounter() : 0ull;
+#endif
             asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"((NST - 2) * IPW) : "memory");
-            if (p.stamps) {
-                t_wait += __builtin_readcyclecounter() - tw0;
-                if (c == c_begin) PL_STAMP(2);   // first stage in LDS
-            }
-            issue_stage(wr_off);
-            wr_off = (wr_off + STAGE == NST * STAGE) ? 0 : wr_off + STAGE;
-            read_step(rd_off, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-            static_for<NSTEP>([&](auto sc) __attribute__((always_inline)) {
-                constexpr int s = decltype(sc)::value;
-                if constexpr (s + 1 < NSTEP)
-                    read_step(rd_off, std::integral_constant<int, s + 1>{}, std::integral_constant<int, (s + 1) & 1>{});
-                mfma_step(std::integral_constant<int, s & 1>{});
+#ifdef BP_EXPERIMENTAL
+            if (p.stamps) t_wait += __builtin_readcyclecounter() - tw0;
+#endif
+            static_for<NRD>([&](auto rc) __attribute__((always_inline)) { read_frag(rd_off, std::integral_constant<int, 0>{}, rc); });
+            PL_SB();
+            static_for<N0>([&](auto dc) __attribute__((always_inline)) { dma_piece(wr_off, dc); });
+            PL_SB();
+            static_for<SLOTS>([&](auto gc) __attribute__((always_inline)) {
+                constexpr int g = decltype(gc)::value, s = g / NMF, m = g % NMF;
+                mfma_one(std::integral_constant<int, s>{}, std::integral_constant<int, m>{});
+                constexpr int d_lo = N0 + (g * DREM + SLOTS - 1) / SLOTS, d_hi = N0 + ((g + 1) * DREM + SLOTS - 1) / SLOTS;
+                static_for<d_hi - d_lo>([&](auto k) __attribute__((always_inline)) {
+                    dma_piece(wr_off, std::integral_constant<int, d_lo + decltype(k)::value>{});
+                });
+                if constexpr (s + 1 < NSTEP && m < HALF) {
+                    constexpr int r_lo = (m * NRD + HALF - 1) / HALF, r_hi = ((m + 1) * NRD + HALF - 1) / HALF;
+                    static_for<r_hi - r_lo>([&](auto k) __attribute__((always_inline)) {
+                        read_frag(rd_off, std::integral_constant<int, s + 1>{}, std::integral_constant<int, r_lo + decltype(k)::value>{});
+                    });
+                }
+                PL_SB();
             });
+            wr_off = (wr_off + STAGE == NST * STAGE) ? 0 : wr_off + STAGE;
             rd_off = (rd_off + STAGE == NST * STAGE) ? 0 : rd_off + STAGE;
             c += CPS;
         } while (c < c_end);
@@ -289,13 +332,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_pl_kernel(const ConvParams 
 #define BP_SLAST (reinterpret_cast<int*>(smem)[SMEM_BYTES / 4 - 1])
 #define BP_EARLY_BIAS bias_early
 #define BP_TAIL_STAMP(k_) PL_STAMP(k_)
+#define BP_EP_SLABS EP_SLABS_
 #include "conv_tail.inc"
+#undef BP_EP_SLABS
 #undef BP_NT
 #undef BP_SLAST
 #undef BP_EARLY_BIAS
 #undef BP_TAIL_STAMP
     if (p.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PL_STAMP(4); }
 #undef PL_STAMP
+#undef PL_SB
 }
 
 bool conv_tile_is_pl(int tile) { return tile == TILE_PL64 || tile == TILE_PL128 || tile == TILE_PL128x64 || tile == TILE_PL256x128; }
@@ -321,7 +367,7 @@ static void launch_pl_np(const ConvParams& p, int tile, hipStream_t s) {
         case TILE_PL64: launch_pl_t<NP, 2, 2, 1, 1, 3, NP == 1 ? 2 : 1>(p, s); break;
         case TILE_PL128: launch_pl_t<NP, 2, 2, 2, 2, NP == 1 ? 4 : 3, 1>(p, s); break;
         case TILE_PL128x64: launch_pl_t<NP, 2, 2, 2, 1, 3, NP == 1 ? 2 : 1>(p, s); break;
-        case TILE_PL256x128: launch_pl_t<NP, 4, 2, 2, 2, NP == 1 ? 3 : 2, NP == 1 ? 2 : 1>(p, s); break;
+        case TILE_PL256x128: launch_pl_t<NP, 4, 2, 2, 2, NP == 1 ? 3 : 2, 1>(p, s); break;
         default: throw Error("not a conv_pl tile");
     }
 }
@@ -335,13 +381,14 @@ void launch_conv_pl(const ConvParams& p, int tile, hipStream_t s) {
     else throw Error("conv_pl tiles need a 16-bit precision mode");
 }
 
-// ---- filters fp32 [CoutPad][Kpad] -> the LDS image above
+// ---- filters fp32 [CoutPad][Kpad] (K order ky, kx, ci) -> the LDS image above in the kernel's K order (channel group, ky, kx, ci % 32)
 template <int NP>
-__global__ void pack_wpl_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, int CoutPad, int Kpad) {
+__global__ void pack_wpl_kernel(const float* __restrict__ in, unsigned short* __restrict__ out, int CoutPad, int Kpad, int Cin, int taps) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)CoutPad * Kpad) return;
     const int n = (int)(i / Kpad), k = (int)(i - (long long)n * Kpad);
-    const int t64 = n >> 6, r = n & 63, c = k >> 5, kk = k & 31;
+    const int tap = k / Cin, ci = k - tap * Cin;
+    const int t64 = n >> 6, r = n & 63, c = (ci >> 5) * taps + tap, kk = ci & 31;
     const int slot = (kk >> 3) ^ ((r >> 2) & 3);
     const long long base = (((long long)t64 * (Kpad >> 5) + c) * NP) * 2048 + r * 32 + slot * 8 + (kk & 7);
     const float x = in[i];
@@ -360,11 +407,11 @@ __global__ void pack_wpl_kernel(const float* __restrict__ in, unsigned short* __
     }
 }
 
-void launch_pack_wpl(const float* in, unsigned short* out, int CoutPad, int Kpad, int np, hipStream_t s) {
+void launch_pack_wpl(const float* in, unsigned short* out, int CoutPad, int Kpad, int Cin, int ksize, int np, hipStream_t s) {
     const long long n = (long long)CoutPad * Kpad;
-    BP_CHECK(CoutPad % 64 == 0 && Kpad % 32 == 0, "pack_wpl: padded filter shape");
-    if (np == 1) hipLaunchKernelGGL(pack_wpl_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, CoutPad, Kpad);
-    else hipLaunchKernelGGL(pack_wpl_kernel<3>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, CoutPad, Kpad);
+    BP_CHECK(CoutPad % 64 == 0 && Cin % 32 == 0 && Kpad == ksize * ksize * Cin, "pack_wpl: filter shape");
+    if (np == 1) hipLaunchKernelGGL(pack_wpl_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, CoutPad, Kpad, Cin, ksize * ksize);
+    else hipLaunchKernelGGL(pack_wpl_kernel<3>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, out, CoutPad, Kpad, Cin, ksize * ksize);
 }
 
 // ---- fp32 NHWC view -> operand planes, for producers that are not convolutions
@@ -397,6 +444,31 @@ void launch_f32_to_planes(const float* in, int ld, long long pixels, int C, unsi
     const long long total = pixels * (C / 4);
     const int grid = (int)std::min<long long>((total + 255) / 256, 4096);
     hipLaunchKernelGGL(f32_to_planes_kernel, dim3(grid < 1 ? 1 : grid), dim3(256), 0, s, in, ld, (int)pixels, C / 4, planes, plane_elems, np);
+}
+
+__global__ void planes_to_f32_kernel(const unsigned short* __restrict__ planes, long long plane_elems, int np, float* __restrict__ out,
+                                     int ld, int pixels, int C) {
+    const int total = pixels * C;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int c = e % C, px = e / C;
+        const long long idx = (long long)px * ld + c;
+        float v;
+        if (np == 1) {
+            v = (float)__builtin_bit_cast(_Float16, planes[idx]);
+        } else {
+            const float a = __uint_as_float((unsigned)planes[idx] << 16), b = __uint_as_float((unsigned)planes[plane_elems + idx] << 16),
+                        c3 = __uint_as_float((unsigned)planes[2 * plane_elems + idx] << 16);
+            v = (a + b) + c3;      // exact: 8 + 8 + 8 significand bits
+        }
+        out[idx] = v;
+    }
+}
+
+void launch_planes_to_f32(const unsigned short* planes, long long plane_elems, int np, float* out, int ld, long long pixels, int C,
+                          hipStream_t s) {
+    BP_CHECK(pixels * C < (1ll << 31) && (np == 1 || np == 3), "planes_to_f32: arguments");
+    const int grid = (int)std::min<long long>((pixels * C + 255) / 256, 4096);
+    hipLaunchKernelGGL(planes_to_f32_kernel, dim3(grid < 1 ? 1 : grid), dim3(256), 0, s, planes, plane_elems, np, out, ld, (int)pixels, C);
 }
 
 }  // namespace bp

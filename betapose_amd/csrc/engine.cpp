@@ -142,6 +142,7 @@ static const PlanEntry kPlanB3[] = {
     { 43264,    64,    9, TILE_64x64_BD,  1},
     {0, 0, 0, 0, 0},
 };
+#ifdef BP_EXPERIMENTAL
 // (fp16, batch 1: the filters-direct variant wins 40 of 47 shapes alone by 4.5 % in the sum, profiles/r02_tune_f16.txt, and
 // LOSES in the pipeline -- 1 329 against 1 381 frames/s, A/B on one box -- so the batch-1 rows stay on the staged kernel)
 static const PlanEntry kPlanF16[] = {
@@ -226,6 +227,7 @@ static const PlanEntry kPlanF16[] = {
     {1211392,    64,    9, 1,  1},
     {0, 0, 0, 0, 0},
 };
+#endif   // BP_EXPERIMENTAL
 
 // experiment hook (tools only): BP_PLAN_FILE names a text file of "M CoutPad nchunks tile splits" lines that take
 // precedence over the built-in bf16x3 table, so a tuning sweep can be tried in the whole pipeline without a rebuild
@@ -244,39 +246,123 @@ static const std::vector<PlanEntry>& plan_file_entries() {
     return entries;
 }
 
+// conv_pl.hip, bf16x3 mode, batch 1: {M, CoutPad, K-chunks} -> {tile, slices}, every conv shape of the two networks timed alone with the
+// epilogue the networks run (residual + operand planes; tools/tune_conv.py --pl, profiles/r03_tune_pl_b3.txt)
+static const PlanEntry kPlanPL3[] = {
+    {    80,   512,   64, TILE_PL64,  6},
+    {    80,   512,  144, TILE_PL64, 10},
+    {    80,  2048,   16, TILE_PL64,  3},
+    {    80,  2048,   32, TILE_PL64,  3},
+    {   169,    64,   32, TILE_PL64, 10},
+    {   169,   256,   16, TILE_PL64,  4},
+    {   169,   512,   32, TILE_PL64,  4},
+    {   169,  1024,  144, TILE_PL64,  5},
+    {   320,   256,   32, TILE_PL64,  4},
+    {   320,   256,   72, TILE_PL64,  5},
+    {   320,   512,   32, TILE_PL64,  3},
+    {   320,  1024,    8, TILE_PL64,  1},
+    {   320,  1024,   16, TILE_PL64,  1},
+    {   320,  1024,  144, TILE_PL64,  3},
+    {   676,    64,   16, TILE_PL64,  5},
+    {   676,   128,    8, TILE_PL64,  1},
+    {   676,   256,   16, TILE_PL64,  3},
+    {   676,   256,   24, TILE_PL64,  3},
+    {   676,   512,   72, TILE_PL64,  2},
+    {  1280,   128,   16, TILE_PL64,  3},
+    {  1280,   128,   36, TILE_PL64,  4},
+    {  1280,   256,   16, TILE_PL64,  1},
+    {  1280,   512,    4, TILE_PL64,  1},
+    {  1280,   512,    8, TILE_PL64,  1},
+    {  1280,   512,   72, TILE_PL64,  3},
+    {  2704,    64,    8, TILE_PL64,  1},
+    {  2704,   128,    8, TILE_PL64,  1},
+    {  2704,   128,   12, TILE_PL64,  1},
+    {  2704,   256,   36, TILE_PL64,  1},
+    {  5120,    64,    2, TILE_PL64,  1},
+    {  5120,    64,    8, TILE_PL64,  1},
+    {  5120,    64,   18, TILE_PL64,  1},
+    {  5120,    64,   36, TILE_PL64,  2},
+    {  5120,   128,    8, TILE_PL64,  1},
+    {  5120,   256,    2, TILE_PL64,  1},
+    { 10816,    64,    4, TILE_PL64,  1},
+    { 10816,   128,   18, TILE_PL64,  1},
+    { 43264,    64,    2, TILE_PL64,  1},
+    { 43264,    64,    9, TILE_PL64,  1},
+    {0, 0, 0, 0, 0},
+};
+// ... fp16 mode (tools/tune_conv.py --pl --f16, profiles/r03_tune_pl_f16.txt)
+static const PlanEntry kPlanPL1[] = {
+    {    80,   512,   64, TILE_PL64,  4},
+    {    80,   512,  144, TILE_PL64,  6},
+    {    80,  2048,   16, TILE_PL64,  1},
+    {    80,  2048,   32, TILE_PL64,  1},
+    {   169,    64,   32, TILE_PL64,  4},
+    {   169,   256,   16, TILE_PL64,  3},
+    {   169,   512,   32, TILE_PL64,  4},
+    {   169,  1024,  144, TILE_PL64,  4},
+    {   320,   256,   32, TILE_PL64,  4},
+    {   320,   256,   72, TILE_PL64,  4},
+    {   320,   512,   32, TILE_PL64,  3},
+    {   320,  1024,    8, TILE_PL64,  1},
+    {   320,  1024,   16, TILE_PL64,  1},
+    {   320,  1024,  144, TILE_PL64,  3},
+    {   676,    64,   16, TILE_PL64,  1},
+    {   676,   128,    8, TILE_PL64,  1},
+    {   676,   256,   16, TILE_PL64,  1},
+    {   676,   256,   24, TILE_PL64,  1},
+    {   676,   512,   72, TILE_PL64,  2},
+    {  1280,   128,   16, TILE_PL64,  1},
+    {  1280,   128,   36, TILE_PL64,  3},
+    {  1280,   256,   16, TILE_PL64,  1},
+    {  1280,   512,    4, TILE_PL64,  1},
+    {  1280,   512,    8, TILE_PL64,  1},
+    {  1280,   512,   72, TILE_PL64,  3},
+    {  2704,    64,    8, TILE_PL64,  1},
+    {  2704,   128,    8, TILE_PL64,  1},
+    {  2704,   128,   12, TILE_PL64,  1},
+    {  2704,   256,   36, TILE_PL64,  1},
+    {  5120,    64,    2, TILE_PL64,  1},
+    {  5120,    64,    8, TILE_PL64,  1},
+    {  5120,    64,   18, TILE_PL64,  1},
+    {  5120,    64,   36, TILE_PL64,  1},
+    {  5120,   128,    8, TILE_PL64,  1},
+    {  5120,   256,    2, TILE_PL64,  1},
+    { 10816,    64,    4, TILE_PL64,  1},
+    { 10816,   128,   18, TILE_PL64,  1},
+    { 43264,    64,    2, TILE_PL64,  1},
+    { 43264,    64,    9, TILE_PL64,  1},
+    {0, 0, 0, 0, 0},
+};
+
 // conv_pl.hip (operand planes + LDS-DMA): which block tile, how many K slices
 static void choose_pl(const ConvParams& c, long long M, int mode, int sk_max, int* tile, int* splits) {
     for (const PlanEntry& e : plan_file_entries())
         if (e.M == (int)M && e.CoutPad == c.CoutPad && e.nchunks == c.nchunks && conv_tile_is_pl(e.tile)) { *tile = e.tile; *splits = e.splits; return; }
+    for (const PlanEntry* e = (mode == PREC_F16 ? kPlanPL1 : kPlanPL3); e->M != 0; ++e)   // tables end with a zero row
+        if (e->M == (int)M && e->CoutPad == c.CoutPad && e->nchunks == c.nchunks) { *tile = e->tile; *splits = e->splits; return; }
+    // other shapes (batched runs): the 128x128 block once its grid covers the chip (half the operand bytes per FLOP of the
+    // 64x64 block: profiles/r03_bench_pl_batch28.txt), else the 64x64 block with enough K slices to fill it
     const long long tiles128 = ((M + 127) / 128) * ((c.CoutPad + 127) / 128);
     int t = (c.CoutPad >= 128 && tiles128 >= 192) ? TILE_PL128 : TILE_PL64;
     int s = 1;
     if (t == TILE_PL64) {
-        bool hit = false;
-        for (const PlanEntry* e = kPlanB3; e->M != 0; ++e)   // the measured batch-1 slice counts of the 64x64 block
-            if (e->M == (int)M && e->CoutPad == c.CoutPad && e->nchunks == c.nchunks) { s = e->splits; hit = true; break; }
-        if (!hit) {
-            const long long blocks = ((M + 63) / 64) * (c.CoutPad / 64);
-            const int min_chunks = mode == PREC_F16 ? 8 : 4;
-            while (blocks * s < 512 && c.nchunks / (s + 1) >= min_chunks && s < sk_max) ++s;
-        }
+        const long long blocks = ((M + 63) / 64) * (c.CoutPad / 64);
+        const int min_chunks = mode == PREC_F16 ? 8 : 4;
+        while (blocks * s < 256 && c.nchunks / (s + 1) >= min_chunks && s < sk_max) ++s;
     }
     *tile = t; *splits = s;
 }
 
 static void choose_h16(const ConvParams& c, long long M, int mode, int sk_max, int* tile, int* splits) {
-    if (conv_pl_eligible(c)) { choose_pl(c, M, mode, sk_max, tile, splits); return; }
+#ifdef BP_EXPERIMENTAL   // BP_LEGACY=1: plan the round-2 kernels instead (A/B runs of the whole pipeline)
+    static const bool legacy = std::getenv("BP_LEGACY") != nullptr;
+    if (conv_pl_eligible(c) && !legacy) { choose_pl(c, M, mode, sk_max, tile, splits); return; }
     if (mode == PREC_BF16X3)
         for (const PlanEntry& e : plan_file_entries())
             if (e.M == (int)M && e.CoutPad == c.CoutPad && e.nchunks == c.nchunks) { *tile = e.tile; *splits = e.splits; return; }
     for (const PlanEntry* e = (mode == PREC_F16 ? kPlanF16 : kPlanB3); e->M != 0; ++e)   // tables end with a zero row
         if (e->M == (int)M && e->CoutPad == c.CoutPad && e->nchunks == c.nchunks) { *tile = e->tile; *splits = e->splits; return; }
-    // heuristic from the batch-4 / batch-28 sweeps (profiles/r02_tune_b3_batch{4,28}.txt): the 128x128 block of
-    // conv_w64.hip (64x64 per wave, half the filter re-reads) wins once its tile grid covers about half the CUs;
-    // below that the 64x64-block kernels, which reach the same block count with fewer K slices
     const long long tiles128 = ((M + 127) / 128) * ((c.CoutPad + 127) / 128);
-    // ... in the fp16 mode.  In the bf16x3 mode the filters-direct 64x64 kernel beats every w64 shape at every batch
-    // size tried (profiles/r02_tune_b3_batch28.txt: 46 of 47 shapes at batch 28, by 11 % in the sum)
     int t = (mode == PREC_BF16X3 && c.w16s) ? TILE_64x64_BD : ((c.CoutPad >= 128 && tiles128 >= 128) ? TILE_W64_2x2 : TILE_64x64);
     const int bm = conv_tile_bm(t), bn = conv_tile_bn(t);
     const long long blocks = ((M + bm - 1) / bm) * ((c.CoutPad + bn - 1) / bn);
@@ -285,6 +371,20 @@ static void choose_h16(const ConvParams& c, long long M, int mode, int sk_max, i
     int s = 1;
     while (blocks * s < target && c.nchunks / (s + 1) >= min_chunks && s < sk_max) ++s;
     *tile = t; *splits = s;
+#else
+    choose_pl(c, M, mode, sk_max, tile, splits);   // (a 16-bit mode is only ever set on layers conv_pl.hip can run)
+#endif
+}
+
+// a forced kernel id (bp_*_set_policy, tests and sweeps) applies to the layers it can run and is ignored for the others:
+// the fp32-MFMA tiles run any layer (they read the fp32 activations), the operand-plane tiles the layers with planes
+static bool tile_runs(int tile, const ConvParams& c) {
+    if (tile == TILE_64x64 || tile == TILE_128x64) return true;
+    if (conv_tile_is_pl(tile)) return c.mfma_mode != PREC_F32 && conv_pl_eligible(c);
+#ifdef BP_EXPERIMENTAL
+    if (tile >= 0 && tile <= TILE_LAST) return c.mfma_mode != PREC_F32 && conv_h16_eligible(c);
+#endif
+    return false;
 }
 
 static void choose_launch(const Op& op, int batch, int force_tile, int sk_target, int sk_min_chunks, int sk_max,
@@ -296,7 +396,7 @@ static void choose_launch(const Op& op, int batch, int force_tile, int sk_target
     int s = 1;
     if (mode != PREC_F32) {
         choose_h16(c, M, mode, sk_max, &t, &s);
-        if (force_tile >= 0) t = force_tile;
+        if (force_tile >= 0 && tile_runs(force_tile, c)) t = force_tile;
         if (!(sk_target == 512 && sk_min_chunks == 4 && sk_max == 8)) {   // explicit policy (tests, sweeps)
             const long long blocks = ((M + conv_tile_bm(t) - 1) / conv_tile_bm(t)) *
                                      ((c.CoutPad + conv_tile_bn(t) - 1) / conv_tile_bn(t));
@@ -304,7 +404,7 @@ static void choose_launch(const Op& op, int batch, int force_tile, int sk_target
             while (blocks * s < sk_target && c.nchunks / (s + 1) >= sk_min_chunks && s < sk_max) ++s;
         }
     } else {
-        if (force_tile >= 0 && !conv_tile_is_w64(force_tile) && !conv_tile_is_kg(force_tile) && !conv_tile_is_rd(force_tile) && force_tile != TILE_64x64_BD) t = force_tile;
+        if (force_tile == TILE_64x64 || force_tile == TILE_128x64) t = force_tile;
         const int bm = conv_tile_bm(t);
         const long long blocks = ((M + bm - 1) / bm) * (c.CoutPad / 64);
         while (blocks * s < sk_target && c.nchunks / (s + 1) >= sk_min_chunks && s < sk_max) ++s;
@@ -372,7 +472,7 @@ int Net::add_conv(const std::string& name, const Tensor& in, const Tensor& out_v
     c.tickets = nullptr;
     c.stamps = nullptr;
     c.w16 = nullptr; c.w16s = nullptr;
-    c.in16 = nullptr; c.out16 = nullptr; c.wpl = nullptr; c.in16_plane = c.out16_plane = 0; c.out_np = 0; c.abl = 0;
+    c.in16 = nullptr; c.out16 = nullptr; c.wpl = nullptr; c.in16_plane = c.out16_plane = 0; c.out_np = 0; c.abl = 0; c.skip_f32 = 0;
     c.CoutPad = CoutPad;
     const double Kalg = (double)k * k * Cin;   // algorithmic K (the packing pad is not work)
     op.flops = 2.0 * OH * OW * (double)Cout * Kalg;
@@ -414,6 +514,7 @@ void Net::finalize() {
 
 void Net::set_precision(int prec) {
     BP_CHECK(prec == PREC_F32 || prec == PREC_F16 || prec == PREC_BF16X3, "unknown precision");
+#ifdef BP_EXPERIMENTAL   // filter copies of the round-1/2 kernels (experimental library only)
     if (prec != PREC_F32) {
         std::lock_guard<std::mutex> lk(store_->f16_mutex);
         auto& copies = prec == PREC_F16 ? store_->f16 : store_->bf16x3;
@@ -455,6 +556,10 @@ void Net::set_precision(int prec) {
             BP_HIP(hipDeviceSynchronize());
         }
     }
+#else
+    for (Op& op : ops_)
+        if (op.type == OP_CONV) { op.conv.w16 = nullptr; op.conv.w16s = nullptr; }
+#endif
     plan_planes(prec);
     for (Op& op : ops_)
         if (op.type == OP_CONV) op.conv.mfma_mode = (prec != PREC_F32 && (op.conv.w16 != nullptr || conv_pl_eligible(op.conv))) ? prec : PREC_F32;
@@ -481,9 +586,13 @@ Net::ActAlloc* Net::find_act(const float* p) {
 void Net::plan_planes(int prec) {
     for (Op& op : ops_) {
         op.out16 = nullptr; op.out16_plane = 0;
-        if (op.type == OP_CONV) { op.conv.in16 = nullptr; op.conv.out16 = nullptr; op.conv.wpl = nullptr; op.conv.out_np = 0; op.conv.in16_plane = op.conv.out16_plane = 0; }
+        if (op.type == OP_CONV) { op.conv.in16 = nullptr; op.conv.out16 = nullptr; op.conv.wpl = nullptr; op.conv.out_np = 0; op.conv.in16_plane = op.conv.out16_plane = 0; op.conv.skip_f32 = 0; }
     }
+    for (ActAlloc& a : acts_) a.f32_read = true;
     if (prec == PREC_F32) return;
+#ifdef BP_EXPERIMENTAL
+    if (std::getenv("BP_LEGACY")) return;   // A/B runs: the round-2 data path (fp32 activations only, converted in the K loops)
+#endif
     const int np = prec == PREC_F16 ? 1 : 3;
     auto pl_shape_ok = [](const ConvParams& c) { return (c.Cin % 32 == 0) && (c.in_ld % 8 == 0) && c.ksize * c.ksize <= 32; };
     bool made = false;
@@ -516,7 +625,7 @@ void Net::plan_planes(int prec) {
             auto it = packed.find(c.w);
             if (it == packed.end()) {
                 unsigned short* d = (unsigned short*)store_->arena.alloc_bytes((size_t)np * c.CoutPad * c.Kpad * sizeof(unsigned short));
-                launch_pack_wpl(c.w, d, c.CoutPad, c.Kpad, np, nullptr);
+                launch_pack_wpl(c.w, d, c.CoutPad, c.Kpad, c.Cin, c.ksize, np, nullptr);
                 it = packed.emplace(c.w, d).first;
                 made = true;
             }
@@ -532,6 +641,24 @@ void Net::plan_planes(int prec) {
         BP_HIP(hipGetLastError());
         BP_HIP(hipDeviceSynchronize());
     }
+    // Which fp32 tensors does anything still read?  Residual operands, the inputs of the pooling / shuffle / add kernels
+    // and of convolutions that run on the fp32 kernels; everything else that has planes is read through them only, and
+    // its producers drop the fp32 store (4 of 10 bytes per element in the bf16x3 mode, 4 of 6 in the fp16 mode; the
+    // dirty lines a kernel leaves behind are written back before its successor starts).  BP_KEEP_F32=1 keeps them all.
+    static const bool keep_all = std::getenv("BP_KEEP_F32") != nullptr;
+    for (ActAlloc& a : acts_) a.f32_read = keep_all || a.planes == nullptr;
+    auto mark = [&](const float* q) { if (q) if (ActAlloc* a = find_act(q)) a->f32_read = true; };
+    for (const Op& op : ops_) {
+        if (op.type == OP_CONV) {
+            mark(op.conv.res);
+            if (!(op.conv.in16 && op.conv.wpl)) mark(op.conv.in);
+        } else {
+            mark(op.a); mark(op.b);
+        }
+    }
+    for (Op& op : ops_)
+        if (op.type == OP_CONV && op.conv.out16)
+            if (ActAlloc* o = find_act(op.conv.out)) op.conv.skip_f32 = o->f32_read ? 0 : 1;
 }
 
 static int planes_np(int prec) { return prec == PREC_F16 ? 1 : 3; }
@@ -550,12 +677,18 @@ void Net::run_op(const Op& op, int batch, hipStream_t s) {
                 splits = (p.nchunks + cps - 1) / cps;
             }
             p.splits = splits; p.chunks_per_split = cps; p.partial = partial_; p.tickets = tickets_;
+            p.stamps = nullptr;
+            if (stamps_) {   // in-situ timing (set_stamps): this conv's region of the stamp buffer, when its grid fits
+                int ord = 0;
+                for (const Op* q = ops_.data(); q != &op; ++q) ord += q->type == OP_CONV;
+                if ((long long)conv_tiles(p, tile) * splits <= stamp_slots_) p.stamps = stamps_ + ((size_t)ord * stamp_slots_) * 8;
+            }
             launch_conv(p, tile, s);
         } break;
-        // (producers that are not convolutions: their operand planes come from a conversion launch behind them)
+        // (producers that are not convolutions: the pooling / shuffle kernels write their operand planes themselves; the
+        // unfused add / upsample / copy fall-backs, which the two networks' default cfgs never emit, convert behind them)
         case OP_MAXPOOL:
-            launch_maxpool3s2p1(op.a, op.out, batch, op.H, op.W, op.C, op.OH, op.OW, s);
-            if (op.out16) launch_f32_to_planes(op.out, op.C, (long long)batch * op.OH * op.OW, op.C, op.out16, op.out16_plane, planes_np(precision_), s);
+            launch_maxpool3s2p1(op.a, op.out, batch, op.H, op.W, op.C, op.OH, op.OW, s, op.out16, op.out16_plane, planes_np(precision_));
             break;
         case OP_ADD:
             launch_add(op.a, op.a_ld, op.b, op.b_ld, op.out, op.out_ld, (long long)batch * op.H * op.W, op.C, s);
@@ -570,8 +703,7 @@ void Net::run_op(const Op& op, int batch, hipStream_t s) {
             if (op.out16) launch_f32_to_planes(op.out, op.out_ld, (long long)batch * op.H * op.W, op.C, op.out16, op.out16_plane, planes_np(precision_), s);
             break;
         case OP_PIXSHUF:
-            launch_pixel_shuffle2(op.a, op.out, batch, op.H, op.W, op.C, s);
-            if (op.out16) launch_f32_to_planes(op.out, op.C / 4, (long long)batch * 4 * op.H * op.W, op.C / 4, op.out16, op.out16_plane, planes_np(precision_), s);
+            launch_pixel_shuffle2(op.a, op.out, batch, op.H, op.W, op.C, s, op.out16, op.out16_plane, planes_np(precision_));
             break;
         case OP_AVGPOOL:
             launch_avgpool(op.a, op.a_ld, op.out, batch, op.H * op.W, op.C, s);
@@ -626,8 +758,8 @@ int Net::profile(int batch, int iters, float* ms, int* info, int cap, hipStream_
             if (conv) {
                 choose_launch(ops_[i], batch, force_tile_, sk_target_, sk_min_chunks_, sk_max_splits_, &tile, &splits, &cps);
                 vec = conv_vec_mode(ops_[i].conv) ? 1 : 0;
-                if (ops_[i].conv.mfma_mode != PREC_F32 && conv_h16_eligible(ops_[i].conv))
-                    vec = 1 + ops_[i].conv.mfma_mode;   // 2 fp16-MFMA kernel, 3 bf16x3 kernel (conv_w64.hip)
+                if (ops_[i].conv.mfma_mode != PREC_F32 && tile != TILE_64x64 && tile != TILE_128x64)
+                    vec = 1 + ops_[i].conv.mfma_mode;   // 2 fp16 operands, 3 bf16x3 operands
             }
             info[4 * i] = conv; info[4 * i + 1] = tile; info[4 * i + 2] = vec; info[4 * i + 3] = splits;
         }
@@ -635,9 +767,14 @@ int Net::profile(int batch, int iters, float* ms, int* info, int cap, hipStream_
     return n;
 }
 
-void Net::tap_copy(int i, int batch, float* d_out_nchw, hipStream_t s) const {
+void Net::tap_copy(int i, int batch, float* d_out_nchw, hipStream_t s) {
     BP_CHECK(i >= 0 && i < (int)taps_.size(), "tap index");
     const Tensor& t = taps_[i];
+    // a tensor whose producers dropped the fp32 store (plan_planes) is rebuilt from its planes first: exact in the
+    // bf16x3 mode (the planes ARE the fp32 value), the fp16-rounded value in the fp16 mode
+    if (ActAlloc* a = find_act(t.p); a && a->planes && !a->f32_read && precision_ != PREC_F32)
+        launch_planes_to_f32(a->planes + (t.p - a->base), (long long)a->elems, precision_ == PREC_F16 ? 1 : 3, t.p, t.ld,
+                             (long long)batch * t.H * t.W, t.C, s);
     launch_nhwc_to_nchw(t.p, t.ld, d_out_nchw, batch, t.C, t.H, t.W, s);
     BP_HIP(hipGetLastError());
 }

@@ -85,7 +85,7 @@ public:
     int tap_count() const { return (int)taps_.size(); }
     const char* tap_name(int i) const { return tap_names_[i].c_str(); }
     void tap_shape(int i, int* C, int* H, int* W) const { *C = taps_[i].C; *H = taps_[i].H; *W = taps_[i].W; }
-    void tap_copy(int i, int batch, float* d_out_nchw, hipStream_t s) const;
+    void tap_copy(int i, int batch, float* d_out_nchw, hipStream_t s);
     void set_splitk_policy(int target_blocks, int min_chunks) { sk_target_ = target_blocks; sk_min_chunks_ = min_chunks; ++plan_version_; }
     void set_max_splits(int m) { sk_max_splits_ = m; ++plan_version_; }
     void set_force_tile(int t) { force_tile_ = t; ++plan_version_; }
@@ -93,6 +93,11 @@ public:
     void set_precision(int prec);
     int precision() const { return precision_; }
     unsigned plan_version() const { return plan_version_; }
+    // in-situ timing: every convolution launch whose grid has at most `slots` blocks writes 8 u64 s_memtime marks per block
+    // (entry, index math done, -, K loop done, stores done, slab parked, slices combined, -) at d_buf + (conv ordinal * slots +
+    // block) * 8; null switches it off.  Graphs must be re-captured (plan_version).
+    void set_stamps(unsigned long long* d_buf, int slots) { stamps_ = d_buf; stamp_slots_ = slots; ++plan_version_; }
+    const char* op_name(int i) const { return ops_[i].name.c_str(); }
 
 protected:
     // emit a fused conv; returns index into ops_
@@ -107,7 +112,8 @@ protected:
     float* upload_weights(const float* host, size_t count);   // through the shared store (reused by clones)
     // activation allocations (new_tensor) and their operand planes: planes mirror the fp32 allocation element for element
     // (bp_common.h ConvParams::in16), so every view (pointer, ld) into an allocation has its planes view for free
-    struct ActAlloc { float* base = nullptr; size_t elems = 0; unsigned short* planes = nullptr; bool wanted = false; };
+    struct ActAlloc { float* base = nullptr; size_t elems = 0; unsigned short* planes = nullptr; bool wanted = false;
+                      bool f32_read = true; };   // f32_read: something reads the fp32 tensor (a residual, a pooling kernel, a head)
     std::vector<ActAlloc> acts_;
     ActAlloc* find_act(const float* p);
     void plan_planes(int prec);   // allocate the planes 16-bit consumers need, point every producer / consumer at them
@@ -127,6 +133,8 @@ protected:
     int force_tile_ = -1;
     bool darknet_bn_ = false;
     int precision_ = PREC_F32;
+    unsigned long long* stamps_ = nullptr;
+    int stamp_slots_ = 0;
     unsigned plan_version_ = 0;   // bumped whenever launches would change (captured graphs must be rebuilt)
 };
 

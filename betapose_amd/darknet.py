@@ -198,6 +198,23 @@ class Darknet:
             _lib.check(rc)
         return np.array(ms, dtype=np.float64), np.array(info, dtype=np.int64).reshape(n, 4)
 
+    def set_stamps(self, buf=None, slots: int = 0):
+        """In-situ conv timing (include/betapose_hip.h bp_*_set_stamps): ``buf`` a cuda int64 tensor of
+        n_convs * slots * 8 elements, or None to switch it off."""
+        self._ensure()
+        _lib.check(_lib.lib().bp_yolo_set_stamps(self._h, buf.data_ptr() if buf is not None else None, int(slots)))
+
+    def op_names(self):
+        """[(layer name, is_convolution)] in op order."""
+        self._ensure()
+        n = _lib.lib().bp_yolo_op_stats(self._h, None, None, 0)
+        name = C.create_string_buffer(96)
+        out = []
+        for i in range(n):
+            is_conv = _lib.lib().bp_yolo_op_name(self._h, i, name, 96)
+            out.append((name.value.decode(), bool(is_conv == 1)))
+        return out
+
     def op_stats(self):
         self._ensure()
         n = _lib.lib().bp_yolo_op_stats(self._h, None, None, 0)

@@ -140,17 +140,21 @@ def gather_records(local_records: np.ndarray, local_indices: Sequence[int], n_to
     dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
     R = local_records.shape[1]
     per = (n_total + world - 1) // world           # pad every rank to the same count
+    # column R carries (global index + 1) as INT32 BITS inside the fp32 buffer (0 = padding row): exact for every index a
+    # 32-bit count can name, where the fp32 VALUE round 2 sent was exact only below 2^24 frames
     buf = torch.zeros((per, R + 1), dtype=torch.float32, device=dev)
     if len(local_indices):
         buf[:len(local_indices), :R] = torch.from_numpy(local_records).to(dev)
-        buf[:len(local_indices), R] = torch.tensor(list(local_indices), dtype=torch.float32, device=dev) + 1.0
+        idx = (torch.tensor(list(local_indices), dtype=torch.int64) + 1).to(torch.int32)
+        buf[:len(local_indices), R] = idx.view(torch.float32).to(dev)
     bufs = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(bufs, buf)
     if rank != dst:
         return None
     out = np.zeros((n_total, R), np.float32)
     for b in bufs:
-        b = b.cpu().numpy()
-        valid = b[:, R] > 0
-        out[(b[valid, R] - 1).astype(np.int64)] = b[valid, :R]
+        b = np.ascontiguousarray(b.cpu().numpy())
+        tag = np.ascontiguousarray(b[:, R]).view(np.int32)
+        valid = tag > 0
+        out[tag[valid].astype(np.int64) - 1] = b[valid, :R]
     return out

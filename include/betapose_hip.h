@@ -121,6 +121,16 @@ int bp_kpd_op_stats(const bp_kpd* k, double* flops, double* bytes, int cap);
  * ms[i] = mean device time of op i over `iters` runs; info[i*4..] = (is_conv, tile id, vec path, splits).
  * Returns the number of ops (arrays may be NULL to query). */
 int bp_yolo_profile(bp_yolo* y, int batch, int iters, float* ms, int* info, int cap, void* stream);
+/* in-situ timing of the convolutions WHILE the pipeline runs (several frames in flight, graph replay): every conv launch
+ * whose grid has at most `slots` blocks writes 8 u64 shader-clock marks per block (entry, index math done, -, K loop done,
+ * stores done, slab parked, slices combined, -) at d_buf + (conv ordinal * slots + block) * 8.  NULL switches it off; a
+ * captured pipeline graph is rebuilt on the next run.  op_name: the layer behind op i of bp_*_op_stats / bp_*_profile; returns 1 for a convolution, 0 for any other op, -1 on error. */
+/* how long `ticks` marks of the clock those stamps read take (one thread spinning on s_memtime between two events) */
+int bp_calibrate_ticks(long long ticks, float* ms, void* stream);
+int bp_yolo_set_stamps(bp_yolo* y, unsigned long long* d_buf, int slots);
+int bp_kpd_set_stamps(bp_kpd* k, unsigned long long* d_buf, int slots);
+int bp_yolo_op_name(const bp_yolo* y, int i, char* out, int cap);
+int bp_kpd_op_name(const bp_kpd* k, int i, char* out, int cap);
 int bp_kpd_profile(bp_kpd* k, int batch, int iters, float* ms, int* info, int cap, void* stream);
 size_t bp_yolo_device_bytes(const bp_yolo* y);
 size_t bp_kpd_device_bytes(const bp_kpd* k);

@@ -88,6 +88,22 @@ def crop_from_dets_frame(frame_bgr_u8: np.ndarray, boxes: torch.Tensor, resH: in
 
 
 # ----------------------------------------------------------------------------- heat-map decoding (a9)
+def unletterbox_boxes_ref(dets: torch.Tensor, im_dim_list: torch.Tensor, det_inp_dim: int) -> torch.Tensor:
+    """3_6Dpose_estimator/dataloader.py:548-560 (inside VideoDetectionLoader.update), statement for statement on a
+    copy: detections (frame index, x1, y1, x2, y2, ...) of the LETTERBOXED detector input back to frame pixels -- remove
+    the grey border, divide by the letterbox scale, clamp box by box to the frame."""
+    dets = dets.clone()
+    im_dim_list = torch.index_select(im_dim_list, 0, dets[:, 0].long())
+    scaling_factor = torch.min(det_inp_dim / im_dim_list, 1)[0].view(-1, 1)
+    dets[:, [1, 3]] -= (det_inp_dim - scaling_factor * im_dim_list[:, 0].view(-1, 1)) / 2
+    dets[:, [2, 4]] -= (det_inp_dim - scaling_factor * im_dim_list[:, 1].view(-1, 1)) / 2
+    dets[:, 1:5] /= scaling_factor
+    for j in range(dets.shape[0]):
+        dets[j, [1, 3]] = torch.clamp(dets[j, [1, 3]], 0.0, float(im_dim_list[j, 0]))
+        dets[j, [2, 4]] = torch.clamp(dets[j, [2, 4]], 0.0, float(im_dim_list[j, 1]))
+    return dets
+
+
 def transform_box_invert_batch(pt, ul, br, inpH, inpW, resH, resW):
     center = (br - 1 - ul) / 2
     size = br - ul

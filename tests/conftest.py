@@ -10,6 +10,8 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "experimental: needs a GPU AND the experimental library (BP_LIB=.../libbetapose_hip_exp.so): "
+                                       "kernels that were measured and superseded, not part of the product")
 
 
 def pytest_collection_modifyitems(config, items):
@@ -20,11 +22,13 @@ def pytest_collection_modifyitems(config, items):
         have = torch.cuda.is_available()
     except Exception:
         have = False
-    if have:
-        return
+    exp_lib = "libbetapose_hip_exp" in os.environ.get("BP_LIB", "")
     skip = pytest.mark.skip(reason="no GPU")
+    skip_exp = pytest.mark.skip(reason="experimental kernels: needs a GPU and BP_LIB=<libbetapose_hip_exp.so>")
     for it in items:
-        if "gpu" in it.keywords:
+        if "experimental" in it.keywords and not (have and exp_lib):
+            it.add_marker(skip_exp)
+        elif "gpu" in it.keywords and not have:
             it.add_marker(skip)
 
 

@@ -166,7 +166,8 @@ def test_streamed_runner_order_and_failure_cleanup(tmp_path, cuda, batch):
 
 def test_video_detection_loader_flow(tmp_path, cuda):
     """f4: frame sequence -> VideoDetectionLoader (letterbox, detector, box un-letterboxing) -> one box per frame inside
-    the frame; the same frames through an MJPEG .avi give the same count."""
+    the frame, equal to the oracle's box for the same letterboxed input."""
+    import torch
     from PIL import Image
     from betapose_amd import video
     from betapose_amd.darknet import Darknet
@@ -182,14 +183,31 @@ def test_video_detection_loader_flow(tmp_path, cuda):
     try:
         vd = video.VideoDetectionLoader(str(d), batchSize=2, det_model=det).start()
         assert vd.length() == 3
+        got = []
         for i in range(3):
             inp, orig, boxes, scores = vd.read()
             assert tuple(inp.shape) == (3, 480, 640) and np.array_equal(orig, fr[i])
             assert boxes.shape == (1, 4) and scores.shape == (1, 1)
             b = boxes[0].numpy()
             assert 0 <= b[0] < b[2] <= 640 and 0 <= b[1] < b[3] <= 480
+            got.append((boxes.clone(), scores.clone()))
     finally:
         opt.inp_dim, opt.confidence = old
+    # ... and the boxes ARE the oracle's: the same letterboxed tensor (prep_frame, pinned to the reference's in
+    # tests/test_video.py) through the oracle detector, dynamic_write_results and the oracle restatement of the
+    # reference's un-letterboxing (dataloader.py:548-560)
+    from betapose_amd import cfg as C, weights as W
+    from oracle import post_ref, yolo_ref
+    blocks = C.parse_cfg_text(C.yolov3_single_cfg_text())
+    convs = W.split_darknet_stream(blocks, helpers.yolo_stream())
+    for i, f in enumerate(fr):
+        t, _, dim = video.prep_frame(f, 416)
+        pred = yolo_ref.darknet_forward(blocks, convs, t)
+        dets = yolo_ref.write_results(pred, 0.01, 80)
+        ref = post_ref.unletterbox_boxes_ref(dets, torch.tensor([dim], dtype=torch.float32).repeat(1, 2), 416)
+        assert got[i][0].shape == ref[:, 1:5].shape
+        assert float((got[i][0] - ref[:, 1:5]).abs().max()) < 5e-3          # box corners, frame pixels (fp32 detector noise)
+        assert float((got[i][1] - ref[:, 5:6]).abs().max()) < 2e-5
 
 
 def test_fused_frames_per_launch_matches_one_frame_per_launch(tmp_path):

@@ -116,12 +116,12 @@ def test_occlusion_multi_object_units(tmp_path):
               "--left_keypoints", str(left), "--streams", "2"]
     script = os.path.join(ROOT, "occlusion_evaluate.py")
 
-    def run(nproc, extra, outdir):
+    def run(nproc, extra, outdir, backend="gloo"):
         if nproc == 1:
             r = subprocess.run([sys.executable, script] + common + extra + ["--outdir", str(outdir)], capture_output=True,
                                text=True, timeout=900, cwd=ROOT)
         else:
-            r = _launch(nproc, [script] + common + extra + ["--outdir", str(outdir)])
+            r = _launch(nproc, [script] + common + extra + ["--outdir", str(outdir)], backend=backend)
         assert r.returncode == 0, r.stdout + r.stderr
         return r.stdout
     out1 = run(1, ["--obj_ids", "1,5,6"], tmp_path / "m1")
@@ -129,6 +129,11 @@ def test_occlusion_multi_object_units(tmp_path):
         nums = dict(re.findall(r"(Mean add accuracy|2d reprojection accuracy with leftkeypoints \d+|Mean IoU) for seq %02d is: ([\d.nan]+)" % o, out1))
         assert list(nums.values()) == ["1.000"] * 3, out1
     run(2, ["--obj_ids", "1,5,6"], tmp_path / "m2")
+    if torch.cuda.device_count() >= 2:      # a multi-GPU node: the same units over RCCL, one rank per GPU (BASELINE configs[4])
+        run(2, ["--obj_ids", "1,5,6"], tmp_path / "m2n", backend="nccl")
+        for o in objs:
+            assert open(tmp_path / "m2" / ("obj_%02d" % o) / "Betapose-results.json").read() == \
+                open(tmp_path / "m2n" / ("obj_%02d" % o) / "Betapose-results.json").read()
     for o in objs:
         j1 = open(tmp_path / "m1" / ("obj_%02d" % o) / "Betapose-results.json").read()
         assert j1 == open(tmp_path / "m2" / ("obj_%02d" % o) / "Betapose-results.json").read()       # 1 rank == 2 ranks

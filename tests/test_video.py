@@ -1,6 +1,8 @@
 """Video / webcam loaders and visualisation (dataloader.py:192-282,468-647, yolo/preprocess.py:18-60,
 fn.py vis_frame) over the frame sources this image can decode.  CPU only (the detector-backed loader is in the GPU
 suite)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -99,3 +101,41 @@ def test_vis_frame_and_data_writer_video(tmp_path):
         pass
     dw.stop()
     assert video.FrameSource(str(tmp_path / "o" / "1.avi")).frame_count == 1
+
+
+def test_prep_frame_equals_the_reference_on_its_golden_frames(golden_dir):
+    """``letterbox_image`` / ``prep_frame`` against vectors produced by the reference's OWN functions (yolo/preprocess.py:
+    18-60, tools/make_golden_video.py) with the stated bicubic stand-in for its one ``cv2.resize`` call: canvas size and
+    colour, where the picture sits, the truncated new_w / new_h, BGR -> RGB, / 255, layout, the returned (w, h)."""
+    import torch
+    from betapose_amd import video
+    g = np.load(os.path.join(golden_dir, "video.npz"))
+    D = int(g["inp_dim"])
+    for i in range(4):
+        f = g["frame%d" % i]
+        lb = video.letterbox_image(f, (D, D))
+        assert lb.dtype == np.uint8 and np.array_equal(lb, g["canvas%d" % i])
+        t, orig, dim = video.prep_frame(f, D)
+        assert orig is f and tuple(dim) == tuple(int(v) for v in g["dim%d" % i])
+        assert torch.equal(t[0], torch.from_numpy(g["tensor_u8_%d" % i]).float().div(255.0))
+
+
+def test_unletterbox_boxes_equal_the_oracle():
+    """The vectorised box transform against the oracle's statement-for-statement restatement of dataloader.py:548-560
+    (bit-identical: the same float operations per element), frames of every aspect, boxes inside, across and beyond
+    the picture."""
+    import torch
+    from betapose_amd import video
+    from oracle import post_ref
+    rng = np.random.default_rng(5)
+    dims = torch.tensor([[640., 480.], [75., 125.], [139., 77.], [416., 416.]]).repeat(1, 2)
+    for D in (416, 608, 96):
+        n = 64
+        dets = torch.zeros(n, 8)
+        dets[:, 0] = torch.from_numpy(rng.integers(0, 4, n)).float()
+        dets[:, 1:5] = torch.from_numpy(rng.uniform(-40, D + 40, (n, 4))).float()
+        dets[:, 5:] = torch.from_numpy(rng.random((n, 3))).float()
+        got = video.unletterbox_boxes(dets, dims, D)
+        ref = post_ref.unletterbox_boxes_ref(dets, dims, D)
+        assert torch.equal(got, ref)
+        assert torch.equal(dets[:, 1:5], torch.from_numpy(np.asarray(dets[:, 1:5])))   # the input is left alone

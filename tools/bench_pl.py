@@ -29,6 +29,8 @@ ap.add_argument("--mode", default="b3")
 ap.add_argument("--tiles", default="")
 ap.add_argument("--only", default="")
 ap.add_argument("--splits", default="1,2,3,4,5,6,8,10")
+ap.add_argument("--engine-like", action="store_true", help="residual added after the activation + operand planes emitted, as inside the networks")
+ap.add_argument("--all-splits", action="store_true", help="print every slice count, not only the best")
 a = ap.parse_args()
 tiles = a.tiles.split(",") if a.tiles else (["bd", "pl64", "pl128x64", "pl128"] if a.mode == "b3" else ["64x64", "w2x2", "pl64", "pl128x64", "pl128", "pl256x128"])
 BMN = {"bd": (64, 64), "64x64": (64, 64), "w2x2": (128, 128), "pl64": (64, 64), "pl128": (128, 128), "pl128x64": (128, 64), "pl256x128": (256, 128), "128x64": (128, 64)}
@@ -46,6 +48,9 @@ for name, (H, W, Cin, Cout, k, st) in SHAPES.items():
     nch = Cin * k * k // 32
     fl = 2.0 * M * Cout * Cin * k * k
     line = "%-22s M=%7d N=%5d K=%5d |" % (name, M, Cout, Cin * k * k)
+    kw = {}
+    if a.engine_like:
+        kw = dict(res=torch.randn(a.batch, OH, OW, Cout, generator=g).to(dev), res_after_act=True, planes=True)
     for t in tiles:
         bm, bn = BMN[t]
         blocks = -(-M // bm) * -(-((Cout + 63) // 64 * 64) // bn)
@@ -54,7 +59,9 @@ for name, (H, W, Cin, Cout, k, st) in SHAPES.items():
             if sp > 1 and (nch // sp < 2 or blocks * sp > 2048):
                 continue
             try:
-                _, ms = ops.conv2d_nhwc(x, w, b, stride=st, pad=k // 2, act="leaky", tile=t + "_" + a.mode, splits=sp, iters=a.iters)
+                ms = ops.conv2d_nhwc(x, w, b, stride=st, pad=k // 2, act="leaky", tile=t + "_" + a.mode, splits=sp, iters=a.iters, **kw)[-1]
+                if a.all_splits:
+                    line += " s%d:%.1f" % (sp, ms * 1e3)
             except Exception as e:
                 ms = float("nan")
             if ms < best[0]:

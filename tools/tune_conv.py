@@ -51,8 +51,12 @@ SUF = "_f16" if F16 else "_b3"
 TILES = ["64x64"] if FP32 else ["64x64" + SUF, "w1x1" + SUF, "w1x2" + SUF, "w2x1" + SUF, "w2x2" + SUF] + (["128x64_f16", "bd_f16"] if F16 else ["bd_b3"])
 if "--kg" in sys.argv:             # batch-1 candidates only: the 64x64-block kernel against the K-group kernels
     TILES = ["64x64_b3", "bd_b3", "kg2_b3", "rd4_b3"]
-TILE_ID = {"64x64": 0, "128x64": 1, "w1x1": 2, "w1x2": 3, "w2x1": 5, "w2x2": 6, "kg1": 7, "kg2": 8, "kg4": 9, "rd4": 10, "rd8": 11, "bd": 12}
-BMN = {"64x64": (64, 64), "128x64": (128, 64), "w1x1": (64, 64), "w1x2": (64, 128), "w2x1": (128, 64), "w2x2": (128, 128),
+PL = "--pl" in sys.argv            # the operand-plane kernels (conv_pl.hip), the product's 16-bit kernels
+if PL:
+    TILES = [t + SUF for t in (["pl64", "pl128x64"] + (["pl128", "pl256x128"] if "--big" in sys.argv else []))]
+ENGINE_LIKE = PL                   # residual after the activation + operand planes emitted, as most layers of the networks run
+TILE_ID = {"pl64": 13, "pl128": 14, "pl128x64": 15, "pl256x128": 16, "64x64": 0, "128x64": 1, "w1x1": 2, "w1x2": 3, "w2x1": 5, "w2x2": 6, "kg1": 7, "kg2": 8, "kg4": 9, "rd4": 10, "rd8": 11, "bd": 12}
+BMN = {"pl64": (64, 64), "pl128": (128, 128), "pl128x64": (128, 64), "pl256x128": (256, 128), "64x64": (64, 64), "128x64": (128, 64), "w1x1": (64, 64), "w1x2": (64, 128), "w2x1": (128, 64), "w2x2": (128, 128),
        "kg1": (64, 64), "kg2": (64, 64), "kg4": (64, 64), "rd4": (64, 64), "rd8": (64, 64), "bd": (64, 64)}
 BATCH = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else 1
 dev = torch.device("cuda:0")
@@ -67,6 +71,7 @@ for (h, w_, cin, co, k, st), cnt in sorted(shapes.items()):
     oh = (h + 2 * ((k - 1) // 2) - k) // st + 1; ow = (w_ + 2 * ((k - 1) // 2) - k) // st + 1
     M = BATCH * oh * ow; nch = cin * k * k // 32; cpad = (co + 63) // 64 * 64
     best = (1e9, None, None); per_tile = []
+    res = torch.randn(BATCH, oh, ow, co, generator=g).to(dev) if ENGINE_LIKE else None
     for tile in TILES:
         base = tile.split("_")[0]
         bm, bn = BMN[base]
@@ -77,7 +82,8 @@ for (h, w_, cin, co, k, st), cnt in sorted(shapes.items()):
         for sp in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 24):
             if sp > 1 and (nch // sp < 2 or tiles * sp > 1400 or BATCH > 4):
                 continue
-            _, ms = ops.conv2d_nhwc(x, wt, None, stride=st, pad=(k - 1) // 2, act="leaky", splits=sp, iters=30, tile=tile)
+            kw = dict(res=res, res_after_act=True, planes=True) if ENGINE_LIKE else {}
+            ms = ops.conv2d_nhwc(x, wt, None, stride=st, pad=(k - 1) // 2, act="leaky", splits=sp, iters=30, tile=tile, **kw)[-1]
             if ms * 1e3 < tb[0]:
                 tb = (ms * 1e3, sp)
         per_tile.append("%s %d:%.1f" % (base, tb[1], tb[0]))
