@@ -570,7 +570,33 @@ void launch_resize_bicubic(const uint8_t* in, int batch, int H, int W, uint8_t* 
                        out_nhwc, out_u8, oh, t.vb, t.vk, t.ksize_v, swap_rb);
 }
 
-#ifdef BP_EXPERIMENTAL   // filter formats of the round-1/2 16-bit kernels (conv_igemm_h / conv_w64 / conv_kg / conv_rd)
+// ---- the same three planes, STAGE-PACKED for the filters-direct kernel (conv_igemm.hip; also conv_kg.hip / conv_rd.hip): per 64-row filter tile and 16-k stage one contiguous block
+// [plane][row 0..63][32 B] that already is the kernel's LDS image (granule g of row r at slot g ^ ((r >> 3) & 1)), so a
+// stage arrives by six 1 KB lane-linear DMA instructions from 6 KB of consecutive addresses
+__global__ void f32_to_bf16x3_staged_kernel(const float* __restrict__ in, __bf16* __restrict__ out, int CoutPad, int Kpad) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)CoutPad * Kpad) return;
+    const int n = (int)(i / Kpad), k = (int)(i - (long long)n * Kpad);
+    const float x = in[i];
+    const __bf16 h1 = (__bf16)x;
+    const float r1 = x - (float)h1;
+    const __bf16 h2 = (__bf16)r1;
+    const float r2 = r1 - (float)h2;
+    const int tile = n >> 6, r = n & 63, stage = k >> 4, kk = k & 15;
+    const int slot = (kk >> 3) ^ ((r >> 3) & 1);
+    const long long base = ((long long)tile * (Kpad >> 4) + stage) * (3 * 64 * 16) + r * 16 + slot * 8 + (kk & 7);
+    out[base] = h1;
+    out[base + 64 * 16] = h2;
+    out[base + 2 * 64 * 16] = (__bf16)r2;
+}
+
+void launch_f32_to_bf16x3_staged(const float* in, unsigned short* out, int CoutPad, int Kpad, hipStream_t s) {
+    const long long n = (long long)CoutPad * Kpad;
+    hipLaunchKernelGGL(f32_to_bf16x3_staged_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in,
+                       reinterpret_cast<__bf16*>(out), CoutPad, Kpad);
+}
+
+#ifdef BP_EXPERIMENTAL   // filter formats of the other round-1/2 16-bit kernels (conv_igemm_h staged / conv_w64)
 // ---- packed filters fp32 -> fp16 (RNE), once per weight store when the fp16-MFMA path is switched on
 __global__ void f32_to_f16_kernel(const float* __restrict__ in, _Float16* __restrict__ out, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -601,32 +627,6 @@ void launch_f32_to_bf16x3(const float* in, unsigned short* out, long long n, hip
     const int threads = 256;
     hipLaunchKernelGGL(f32_to_bf16x3_kernel, dim3((unsigned)((n + threads - 1) / threads)), dim3(threads), 0, s, in,
                        reinterpret_cast<__bf16*>(out), n);
-}
-
-// ---- the same three planes, STAGE-PACKED for conv_kg.hip: per 64-row filter tile and 16-k stage one contiguous block
-// [plane][row 0..63][32 B] that already is the kernel's LDS image (granule g of row r at slot g ^ ((r >> 3) & 1)), so a
-// stage arrives by six 1 KB lane-linear DMA instructions from 6 KB of consecutive addresses
-__global__ void f32_to_bf16x3_staged_kernel(const float* __restrict__ in, __bf16* __restrict__ out, int CoutPad, int Kpad) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long long)CoutPad * Kpad) return;
-    const int n = (int)(i / Kpad), k = (int)(i - (long long)n * Kpad);
-    const float x = in[i];
-    const __bf16 h1 = (__bf16)x;
-    const float r1 = x - (float)h1;
-    const __bf16 h2 = (__bf16)r1;
-    const float r2 = r1 - (float)h2;
-    const int tile = n >> 6, r = n & 63, stage = k >> 4, kk = k & 15;
-    const int slot = (kk >> 3) ^ ((r >> 3) & 1);
-    const long long base = ((long long)tile * (Kpad >> 4) + stage) * (3 * 64 * 16) + r * 16 + slot * 8 + (kk & 7);
-    out[base] = h1;
-    out[base + 64 * 16] = h2;
-    out[base + 2 * 64 * 16] = (__bf16)r2;
-}
-
-void launch_f32_to_bf16x3_staged(const float* in, unsigned short* out, int CoutPad, int Kpad, hipStream_t s) {
-    const long long n = (long long)CoutPad * Kpad;
-    hipLaunchKernelGGL(f32_to_bf16x3_staged_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in,
-                       reinterpret_cast<__bf16*>(out), CoutPad, Kpad);
 }
 
 // fp16 operands, stage-packed the same way (one plane: 2 KB per 64-row tile and 16-k stage)

@@ -493,7 +493,8 @@ int bp_conv2d_planes(const float* d_in, int N, int H, int W, int Cin, const floa
         net.set_precision(prec);
         net.ops_[0].conv.mfma_mode = prec;
 #ifndef BP_EXPERIMENTAL
-        BP_CHECK(bp::conv_tile_is_pl(t), "this kernel id exists only in the experimental library (python -m betapose_amd.build --experimental, BP_LIB)");
+        BP_CHECK(bp::conv_tile_is_pl(t) || (t == bp::TILE_64x64_BD && prec == bp::PREC_BF16X3),
+                 "this kernel id exists only in the experimental library (python -m betapose_amd.build --experimental, BP_LIB)");
 #endif
     } else {
         BP_CHECK(t <= bp::TILE_128x64, "this tile needs a 16-bit precision mode (tile + 256 / + 512)");

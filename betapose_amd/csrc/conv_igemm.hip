@@ -292,8 +292,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     if (p.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); BP_STAMP(4); }
 }
 
-#ifdef BP_EXPERIMENTAL   // round-1/2 kernels with fp32 activations converted in the K loop: measured, superseded by conv_pl.hip,
-                         // kept for A/B timing in the experimental library only (build.py --experimental)
+// The product launches ONE instantiation of the template below, <1, 1, 3, true> ("filters direct", the bf16x3 mode's planned
+// kernel: profiles/r03_ab_pipeline.txt); the LDS-staged variants, the fp16 variants and the 128x64 tile are instantiated in
+// the experimental library only (build.py --experimental).
 // =====================================================================================================================
 // 16-bit-operand MFMA variants.  Same tiling, K walk, split-K hand-off and epilogue (conv_tail.inc) as the fp32 kernel;
 // what changes is what the matrix cores multiply.  Activations stay fp32 in HBM and are converted when a chunk is
@@ -583,8 +584,6 @@ __global__ __launch_bounds__(256) void conv_igemm_h_kernel(const ConvParams p) {
 #undef BH_PHASE
 }
 
-#endif   // BP_EXPERIMENTAL
-
 thread_local ConvProfHook* g_conv_prof = nullptr;
 
 int conv_tile_bm(int tile) {
@@ -625,7 +624,6 @@ static void launch_t(const ConvParams& p, hipStream_t s) {
     }
 }
 
-#ifdef BP_EXPERIMENTAL
 template <int TM, int TN, int NP, bool BD = false>
 static void launch_h_t(const ConvParams& p, hipStream_t s) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
@@ -636,16 +634,14 @@ static void launch_h_t(const ConvParams& p, hipStream_t s) {
         hipLaunchKernelGGL((conv_igemm_h_kernel<TM, TN, NP, BD>), grid, dim3(256), 0, s, p);
 }
 
-#endif
-
 int conv_vec_mode(const ConvParams& p) {
     if ((p.Cin % 32 == 0) && (p.in_ld % 4 == 0) && p.ksize <= 8) return 1;
     if (p.cin_pack == 4 && p.Cin <= 4 && p.ksize <= 8) return 2;
     return 0;
 }
 
-bool conv_h16_eligible(const ConvParams& p) {
-    return p.w16 != nullptr && (p.Cin % 32 == 0) && (p.in_ld % 4 == 0) && p.ksize <= 8;
+bool conv_h16_eligible(const ConvParams& p) {   // the fp32-activation 16-bit kernels: a converted filter copy + whole 32-channel chunks
+    return (p.w16 != nullptr || p.w16s != nullptr) && (p.Cin % 32 == 0) && (p.in_ld % 4 == 0) && p.ksize <= 8;
 }
 
 int conv_tiles(const ConvParams& p, int tile) {
@@ -662,6 +658,10 @@ void launch_conv(const ConvParams& p, int tile, hipStream_t s) {
              "output / residual tensor too large for 32-bit offsets");
     if (conv_tile_is_pl(tile)) {
         launch_conv_pl(p, tile, s);
+    } else if (tile == TILE_64x64_BD && p.mfma_mode == PREC_BF16X3) {
+        BP_CHECK(conv_h16_eligible(p) && p.w16s != nullptr, "filters-direct tile needs the stage-packed filter copy and Cin % 32 == 0");
+        BP_CHECK((long long)3 * p.CoutPad * p.Kpad * 2 < (long long)OOB, "filter planes too large for 32-bit offsets");
+        launch_h_t<1, 1, 3, true>(p, s);
 #ifdef BP_EXPERIMENTAL
     } else if (conv_tile_is_w64(tile)) {
         launch_conv_w64(p, tile, s);
@@ -679,14 +679,8 @@ void launch_conv(const ConvParams& p, int tile, hipStream_t s) {
             default: launch_h_t<1, 1, 1>(p, s); break;
         }
     } else if (p.mfma_mode == PREC_BF16X3 && conv_h16_eligible(p)) {
-        BP_CHECK(tile == TILE_64x64 || tile == TILE_64x64_BD, "the bf16x3 kernel is built for the 64x64 tile");
-        if (tile == TILE_64x64_BD) {
-            BP_CHECK(p.w16s != nullptr, "filters-direct tile needs the stage-packed filter copy");
-            BP_CHECK((long long)3 * p.CoutPad * p.Kpad * 2 < (long long)OOB, "filter planes too large for 32-bit offsets");
-            launch_h_t<1, 1, 3, true>(p, s);
-        } else {
-            launch_h_t<1, 1, 3>(p, s);
-        }
+        BP_CHECK(tile == TILE_64x64 && p.w16 != nullptr, "the LDS-staged bf16x3 kernel is built for the 64x64 tile");
+        launch_h_t<1, 1, 3>(p, s);
 #endif
     } else {
         BP_CHECK(tile == TILE_64x64 || tile == TILE_128x64,

@@ -354,16 +354,27 @@ static void choose_pl(const ConvParams& c, long long M, int mode, int sk_max, in
 }
 
 static void choose_h16(const ConvParams& c, long long M, int mode, int sk_max, int* tile, int* splits) {
-#ifdef BP_EXPERIMENTAL   // BP_LEGACY=1: plan the round-2 kernels instead (A/B runs of the whole pipeline)
+    // layers with operand planes (the fp16 mode; bf16x3 under BP_B3_PLANES) run on conv_pl.hip
+#ifdef BP_EXPERIMENTAL   // BP_LEGACY=1: the fp32-activation kernels in every mode (A/B runs of the whole pipeline)
     static const bool legacy = std::getenv("BP_LEGACY") != nullptr;
+#else
+    constexpr bool legacy = false;
+#endif
     if (conv_pl_eligible(c) && !legacy) { choose_pl(c, M, mode, sk_max, tile, splits); return; }
     if (mode == PREC_BF16X3)
         for (const PlanEntry& e : plan_file_entries())
-            if (e.M == (int)M && e.CoutPad == c.CoutPad && e.nchunks == c.nchunks) { *tile = e.tile; *splits = e.splits; return; }
+            if (e.M == (int)M && e.CoutPad == c.CoutPad && e.nchunks == c.nchunks && !conv_tile_is_pl(e.tile)) { *tile = e.tile; *splits = e.splits; return; }
+#ifdef BP_EXPERIMENTAL
     for (const PlanEntry* e = (mode == PREC_F16 ? kPlanF16 : kPlanB3); e->M != 0; ++e)   // tables end with a zero row
+#else
+    for (const PlanEntry* e = kPlanB3; e->M != 0; ++e)
+#endif
         if (e->M == (int)M && e->CoutPad == c.CoutPad && e->nchunks == c.nchunks) { *tile = e->tile; *splits = e->splits; return; }
+    int t = TILE_64x64_BD;   // bf16x3: the filters-direct 64x64 kernel at every batch size (profiles/r02_tune_b3_batch28.txt)
+#ifdef BP_EXPERIMENTAL
     const long long tiles128 = ((M + 127) / 128) * ((c.CoutPad + 127) / 128);
-    int t = (mode == PREC_BF16X3 && c.w16s) ? TILE_64x64_BD : ((c.CoutPad >= 128 && tiles128 >= 128) ? TILE_W64_2x2 : TILE_64x64);
+    if (!(mode == PREC_BF16X3 && c.w16s)) t = (c.CoutPad >= 128 && tiles128 >= 128) ? TILE_W64_2x2 : TILE_64x64;
+#endif
     const int bm = conv_tile_bm(t), bn = conv_tile_bn(t);
     const long long blocks = ((M + bm - 1) / bm) * ((c.CoutPad + bn - 1) / bn);
     const int target = t == TILE_W64_2x2 ? 256 : (mode == PREC_F16 ? 128 : 512);
@@ -371,9 +382,6 @@ static void choose_h16(const ConvParams& c, long long M, int mode, int sk_max, i
     int s = 1;
     while (blocks * s < target && c.nchunks / (s + 1) >= min_chunks && s < sk_max) ++s;
     *tile = t; *splits = s;
-#else
-    choose_pl(c, M, mode, sk_max, tile, splits);   // (a 16-bit mode is only ever set on layers conv_pl.hip can run)
-#endif
 }
 
 // a forced kernel id (bp_*_set_policy, tests and sweeps) applies to the layers it can run and is ignored for the others:
@@ -381,6 +389,7 @@ static void choose_h16(const ConvParams& c, long long M, int mode, int sk_max, i
 static bool tile_runs(int tile, const ConvParams& c) {
     if (tile == TILE_64x64 || tile == TILE_128x64) return true;
     if (conv_tile_is_pl(tile)) return c.mfma_mode != PREC_F32 && conv_pl_eligible(c);
+    if (tile == TILE_64x64_BD) return c.mfma_mode == PREC_BF16X3 && conv_h16_eligible(c) && c.w16s != nullptr;
 #ifdef BP_EXPERIMENTAL
     if (tile >= 0 && tile <= TILE_LAST) return c.mfma_mode != PREC_F32 && conv_h16_eligible(c);
 #endif
@@ -514,37 +523,53 @@ void Net::finalize() {
 
 void Net::set_precision(int prec) {
     BP_CHECK(prec == PREC_F32 || prec == PREC_F16 || prec == PREC_BF16X3, "unknown precision");
-#ifdef BP_EXPERIMENTAL   // filter copies of the round-1/2 kernels (experimental library only)
+    // Two data paths for the 16-bit operand modes (A/B of the whole pipeline on one box, profiles/r03_ab_pipeline.txt):
+    //   fp16   -> operand planes written by the producers, both operands by LDS-DMA (conv_pl.hip): +24 % at batch 1, +42 % at
+    //             batch 28 over the round-2 kernels;
+    //   bf16x3 -> fp32 activations, split in the consumer's K loop, filter fragments straight into registers (conv_igemm.hip,
+    //             the filters-direct kernel): the plane path moves 6 bytes per activation element where this one moves 4 and
+    //             holds 72 KB of LDS per block against 24.5 KB, and runs the pipeline 5 % SLOWER at batch 1 and at batch 28;
+    //             BP_B3_PLANES=1 puts this mode on the plane path too (tests, A/B runs).
+    for (Op& op : ops_)
+        if (op.type == OP_CONV) { op.conv.w16 = nullptr; op.conv.w16s = nullptr; }
+    static const bool b3_planes = std::getenv("BP_B3_PLANES") != nullptr;
+    const bool plane_path = prec == PREC_F16 || (prec == PREC_BF16X3 && b3_planes);
     if (prec != PREC_F32) {
         std::lock_guard<std::mutex> lk(store_->f16_mutex);
-        auto& copies = prec == PREC_F16 ? store_->f16 : store_->bf16x3;
         bool made = false;
         for (Op& op : ops_) {
             if (op.type != OP_CONV) continue;
             ConvParams& c = op.conv;
-            c.w16 = nullptr;
-            c.w16s = nullptr;
             if (!((c.Cin % 32 == 0) && (c.in_ld % 4 == 0) && c.ksize <= 8)) continue;   // the RGB stems stay on the fp32 kernel
-            auto it = copies.find(c.w);
-            if (it == copies.end()) {
-                const size_t n = (size_t)c.CoutPad * c.Kpad;
-                const size_t planes = prec == PREC_F16 ? 1 : 3;
-                unsigned short* d = (unsigned short*)store_->arena.alloc_bytes(planes * n * sizeof(unsigned short));
-                if (prec == PREC_F16) launch_f32_to_f16(c.w, d, (long long)n, nullptr);
-                else launch_f32_to_bf16x3(c.w, d, (long long)n, nullptr);
-                it = copies.emplace(c.w, d).first;
-                made = true;
-            }
-            c.w16 = it->second;
-            c.w16s = nullptr;
+            const size_t planes = prec == PREC_F16 ? 1 : 3;
+#ifdef BP_EXPERIMENTAL   // unstaged copies: the LDS-staged round-1/2 kernels and conv_w64.hip (experimental library only)
             {
+                auto& copies = prec == PREC_F16 ? store_->f16 : store_->bf16x3;
+                auto it = copies.find(c.w);
+                if (it == copies.end()) {
+                    const size_t n = (size_t)c.CoutPad * c.Kpad;
+                    unsigned short* d = (unsigned short*)store_->arena.alloc_bytes(planes * n * sizeof(unsigned short));
+                    if (prec == PREC_F16) launch_f32_to_f16(c.w, d, (long long)n, nullptr);
+                    else launch_f32_to_bf16x3(c.w, d, (long long)n, nullptr);
+                    it = copies.emplace(c.w, d).first;
+                    made = true;
+                }
+                c.w16 = it->second;
+            }
+            const bool want_staged = true;
+#else
+            const bool want_staged = prec == PREC_BF16X3 && !plane_path;
+#endif
+            if (want_staged) {   // stage-packed copy: the filters-direct kernel's fragment image
                 auto& staged = prec == PREC_F16 ? store_->f16s : store_->bf16x3s;
                 auto is = staged.find(c.w);
                 if (is == staged.end()) {
-                    const size_t planes = prec == PREC_F16 ? 1 : 3;
                     unsigned short* d = (unsigned short*)store_->arena.alloc_bytes(planes * c.CoutPad * c.Kpad * sizeof(unsigned short));
+#ifdef BP_EXPERIMENTAL
                     if (prec == PREC_F16) launch_f32_to_f16_staged(c.w, d, c.CoutPad, c.Kpad, nullptr);
-                    else launch_f32_to_bf16x3_staged(c.w, d, c.CoutPad, c.Kpad, nullptr);
+                    else
+#endif
+                    launch_f32_to_bf16x3_staged(c.w, d, c.CoutPad, c.Kpad, nullptr);
                     is = staged.emplace(c.w, d).first;
                     made = true;
                 }
@@ -556,13 +581,9 @@ void Net::set_precision(int prec) {
             BP_HIP(hipDeviceSynchronize());
         }
     }
-#else
+    plan_planes(plane_path ? prec : PREC_F32);
     for (Op& op : ops_)
-        if (op.type == OP_CONV) { op.conv.w16 = nullptr; op.conv.w16s = nullptr; }
-#endif
-    plan_planes(prec);
-    for (Op& op : ops_)
-        if (op.type == OP_CONV) op.conv.mfma_mode = (prec != PREC_F32 && (op.conv.w16 != nullptr || conv_pl_eligible(op.conv))) ? prec : PREC_F32;
+        if (op.type == OP_CONV) op.conv.mfma_mode = (prec != PREC_F32 && (conv_h16_eligible(op.conv) || conv_pl_eligible(op.conv))) ? prec : PREC_F32;
     precision_ = prec;
     ++plan_version_;
     // the 16-bit plans split differently from the fp32 one the workspace was first sized for
@@ -591,7 +612,7 @@ void Net::plan_planes(int prec) {
     for (ActAlloc& a : acts_) a.f32_read = true;
     if (prec == PREC_F32) return;
 #ifdef BP_EXPERIMENTAL
-    if (std::getenv("BP_LEGACY")) return;   // A/B runs: the round-2 data path (fp32 activations only, converted in the K loops)
+    if (std::getenv("BP_LEGACY")) return;   // A/B runs: the fp32-activation data path in every mode
 #endif
     const int np = prec == PREC_F16 ? 1 : 3;
     auto pl_shape_ok = [](const ConvParams& c) { return (c.Cin % 32 == 0) && (c.in_ld % 8 == 0) && c.ksize * c.ksize <= 32; };

@@ -271,3 +271,51 @@ def test_conv_pl_full_size_layers(cuda):
         assert float((y3 - (2.0 * y1 + y2)).abs().max()) < 5e-5
         ref = F.conv2d(x1.double().permute(0, 3, 1, 2), w.double(), padding=k // 2).float()
         _check(y1.cpu().permute(0, 3, 1, 2), ref)
+
+
+# ---- the bf16x3 mode's planned kernel: conv_igemm.hip "filters direct" (fp32 activations split into three bf16 terms in the
+# K loop, filter fragments from the stage-packed copy straight into registers).  fp32-accurate: no further from an fp64 conv
+# than the fp32-MFMA kernel; bit-reproducible; every epilogue / store mode.
+@pytest.mark.parametrize("case", F16_CASES)
+@pytest.mark.parametrize("splits", [1, 3])
+def test_conv_filters_direct_bf16x3_is_fp32_accurate(cuda, case, splits):
+    N, H, W, Cin, Cout, k, st, pad, act = case
+    g = torch.Generator().manual_seed(1900 + CASES.index(case))
+    x = torch.randn(N, H, W, Cin, generator=g) * torch.exp(2 * torch.randn(N, H, W, 1, generator=g))   # wide dynamic range
+    w = torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g)
+    if splits > 1 and Cin * k * k // 32 < 2 * splits:
+        pytest.skip("too few K-chunks to split")
+    OH, OW = (H + 2 * pad - k) // st + 1, (W + 2 * pad - k) // st + 1
+    res = torch.randn(N, OH, OW, Cout, generator=g)
+    for after in (False, True):
+        ref64 = _ref(x.double(), w.double(), b.double(), st, pad, act, res.double(), after)
+        kw = dict(stride=st, pad=pad, act=act, res=res.to(cuda), res_after_act=after, splits=splits)
+        out3 = ops.conv2d_nhwc(x.to(cuda), w, b, tile="bd_b3", **kw)
+        out32 = ops.conv2d_nhwc(x.to(cuda), w, b, tile="64x64", **kw)
+        assert torch.equal(out3, ops.conv2d_nhwc(x.to(cuda), w, b, tile="bd_b3", **kw))     # fixed summation order
+        out3, out32 = out3.cpu().permute(0, 3, 1, 2), out32.cpu().permute(0, 3, 1, 2)
+        scale = float(ref64.abs().mean())
+        e3 = float((out3.double() - ref64).abs().max()) / scale
+        e32 = float((out32.double() - ref64).abs().max()) / scale
+        assert e3 <= max(1.5 * e32, 2e-6), (e3, e32)
+        _check(out3, ref64.float(), tol=2e-5 * max(1.0, scale))
+
+
+def test_conv_filters_direct_store_modes(cuda):
+    g = torch.Generator().manual_seed(18)
+    x = torch.randn(2, 10, 8, 64, generator=g)
+    w = torch.randn(128, 64, 3, 3, generator=g) / 24
+    b = torch.randn(128, generator=g)
+    ref = _ref(x, w, b, 1, 1, "relu", None, False)
+    xd = x.to(cuda)
+    up = ops.conv2d_nhwc(xd, w, b, pad=1, act="relu", store="up2", tile="bd_b3").cpu().permute(0, 3, 1, 2)
+    _check(up, F.interpolate(ref, scale_factor=2, mode="nearest"))
+    ps = ops.conv2d_nhwc(xd, w, b, pad=1, act="relu", store="pixshuf", tile="bd_b3").cpu().permute(0, 3, 1, 2)
+    _check(ps, F.pixel_shuffle(ref, 2))
+    nc = ops.conv2d_nhwc(xd, w, b, pad=1, act="relu", store="nchw", tile="bd_b3", splits=2).cpu()
+    _check(nc, ref)
+    w18 = torch.randn(18, 64, 1, 1, generator=g) / 8
+    b18 = torch.randn(18, generator=g)
+    hd = ops.conv2d_nhwc(xd, w18, b18, tile="bd_b3").cpu().permute(0, 3, 1, 2)
+    _check(hd, _ref(x, w18, b18, 1, 0, "linear", None, False))

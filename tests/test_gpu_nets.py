@@ -264,3 +264,48 @@ def test_bf16x3_mode_meets_the_fp32_parity_bar(cuda, pipe_gold):
         hm = kpd3(crops[i].to(cuda)).cpu()
         assert float((hm - kpd_ref.fastpose_forward(sd, crops[i])).abs().max()) <= HM_TOL
         assert np.array_equal(hm.view(50, -1).argmax(1).numpy(), pipe_gold["f%d_kp_idx" % i])
+
+
+def test_bf16x3_on_the_operand_plane_path_meets_the_fp32_parity_bar(cuda):
+    """The plane path (conv_pl.hip: producers write three bf16 planes, both operands by LDS-DMA) is the fp16 mode's planned
+    path; ``BP_B3_PLANES=1`` puts the bf16x3 mode on it too (slower there).  It is the same arithmetic -- an
+    exact 3-way split, six products, fp32 accumulation -- so it is held to the same bars as the default path: YOLO arg-max
+    index and KPD arg-max pixels of the golden frames, rows and heat-maps within the fp32 tolerances.  Own process: the
+    switch is read once per process."""
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, "tests")
+import helpers
+from betapose_amd import weights as W
+from betapose_amd.darknet import Darknet
+from betapose_amd.kpd import FastPoseHIP
+from oracle import kpd_ref, yolo_ref
+gold = np.load("tests/golden/pipeline.npz")
+net = Darknet("yolo/cfg/yolov3-single.cfg", reso=416, max_batch=1).load_stream(helpers.yolo_stream()).cuda().eval()
+net.set_precision("bf16x3")
+kpd = FastPoseHIP(helpers.kpd_state_dict(), n_classes=50, max_batch=1).cuda().eval()
+kpd.set_precision("bf16x3")
+blocks = helpers.yolo_blocks(); convs = W.split_darknet_stream(blocks, helpers.yolo_stream()); sd = helpers.kpd_state_dict()
+for i in range(2):
+    x = helpers.yolo_input_from_frame(helpers.frames()[i])
+    got = net(x.cuda()).cpu(); ref = yolo_ref.darknet_forward(blocks, convs, x)
+    assert int(got[0, :, 4].argmax()) == int(gold["f%d_obj_argmax" % i])
+    assert float((got[0, :, 4:] - ref[0, :, 4:]).abs().max()) <= 2e-5
+    d = (got[0, :, :4] - ref[0, :, :4]).abs()
+    assert bool((d <= 2e-3 + 3e-5 * ref[0, :, :4].abs()).all())
+    from oracle import post_ref
+    crop = post_ref.crop_from_dets_frame(helpers.frames()[i], torch.from_numpy(gold["f%d_boxes" % i]))[0]
+    hm = kpd(crop.cuda()).cpu()
+    assert float((hm - kpd_ref.fastpose_forward(sd, crop)).abs().max()) <= 2e-4
+    assert np.array_equal(hm.view(50, -1).argmax(1).numpy(), gold["f%d_kp_idx" % i])
+ms, info = net.profile(1, 1)
+assert (info[:, 1] == 13).sum() > 60, "the plane kernels did not run"
+print("PLANE-PATH-OK")
+'''
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT,
+                       env=dict(os.environ, BP_B3_PLANES="1"))
+    assert r.returncode == 0 and "PLANE-PATH-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
