@@ -48,6 +48,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=1, help="frames per step (1 = the reference's own batch)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--prefetch", action="store_true", help="lone-frame latency mode for the main run too (bp_*_set_prefetch): pays with --streams 1 only")
     ap.add_argument("--fixed-box", action="store_true", help="deterministic crop box (220,140,420,340)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--other-modes", default="f32,f16",
@@ -308,14 +309,15 @@ def layer_classes(det, pose, batch, peak_mode):
     return out
 
 
-def hbm_block(alg_bytes_per_step: float, fps: float, batch: int):
+def hbm_block(alg_bytes_per_step: float, fps: float, batch: int, precision: str = "bf16x3"):
     """HBM GB/s of the whole pipeline at the measured rate: counter bytes per frame from the committed rocprofv3 PMC pass
     (tools/pmc_frame_traffic.sh: FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate passes) x frames/s, beside the algorithmic
     bytes per frame x frames/s."""
     src, counter = None, None
     try:
         import glob
-        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_frame_traffic*.json")))[::-1]:
+        suffix = {"bf16x3": "", "f16": "_f16", "f32": "_f32"}[precision]
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_frame_traffic%s.json" % suffix)))[::-1]:
             t = json.load(open(f))
             counter = (t["fetch_MB_per_frame(x2 corrected)"] + t["write_MB_per_frame"]) * 1e6
             src = os.path.relpath(f, ROOT)
@@ -332,8 +334,8 @@ def hbm_block(alg_bytes_per_step: float, fps: float, batch: int):
 
 
 def insitu_layers(dets, poses, run, S, batch, path, precision):
-    """Per-layer timing WHILE the pipeline runs (S frames in flight, graph replay): every conv kernel stamps s_memtime at
-    its blocks' entry, K-loop end and last store (bp_*_set_stamps); a layer's span = first entry -> last mark of its grid.
+    """Per-layer timing WHILE the pipeline runs (S frames in flight, graph replay): every conv kernel stamps s_memrealtime (the device-wide
+    100 MHz reference clock) at its blocks' entry, K-loop end and last store (bp_*_set_stamps); a layer's span = first entry -> last mark of its grid.
     rocprofv3 cannot give this (its tracer serialises the streams).  Writes the table to ``path``."""
     import ctypes
     import torch
@@ -357,7 +359,7 @@ def insitu_layers(dets, poses, run, S, batch, path, precision):
     torch.cuda.synchronize()
     wall_ms = (time.perf_counter() - t0) * 1e3
     ms = ctypes.c_float(0)
-    TICKS = 20_000_000
+    TICKS = 2_000_000                 # 20 ms of the 100 MHz reference clock the stamps read
     _lib.check(_lib.lib().bp_calibrate_ticks(TICKS, ctypes.byref(ms), _lib.current_stream()))
     ghz = TICKS / (ms.value * 1e-3) / 1e9
     rows, spans = [], []
@@ -389,7 +391,7 @@ def insitu_layers(dets, poses, run, S, batch, path, precision):
     per_class, lines = {}, []
     for k, tag, c, nm, nb, r in rows:
         if r is None:
-            lines.append("%d %-4s %3d %-58s grid > %d blocks: not stamped" % (k, tag, c, nm, SLOTS))
+            lines.append("%d %-4s %3d %-58s no stamps (grid > %d blocks)" % (k, tag, c, nm, SLOTS))
             continue
         e0, e1, kl, tail = r
         lines.append("%d %-4s %3d %-58s blocks %5d  span %7.2f us  K loop (mean per block) %7.2f us  tail %6.2f us" % (
@@ -408,7 +410,7 @@ def insitu_layers(dets, poses, run, S, batch, path, precision):
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     with open(path, "w") as f:
         f.write("# in-situ per-layer times: %d frames in flight, precision %s, the LAST frame of every stream; clock %.3f GHz\n"
-                "# (bench.py --insitu; stamps = s_memtime written by the conv kernels: entry / K loop done / last store per block)\n"
+                "# (bench.py --insitu; stamps = s_memrealtime written by the conv kernels: entry / K loop done / last store per block)\n"
                 "# span = first block entry -> last mark of the layer's grid; %.2f layers in flight on average\n" % (S, precision, ghz, conc))
         f.write("# stream net conv layer\n" + "\n".join(lines) + "\n# " + json.dumps(summary) + "\n")
     return summary
@@ -456,6 +458,10 @@ def main():
     for d, p_ in zip(dets[1:], poses[1:]):
         d.set_policy(a.sk_target, a.sk_min, a.sk_max, a.tile)
         p_.set_policy(a.sk_target, a.sk_min, a.sk_max, a.tile)
+    if a.prefetch:
+        for d, p_ in zip(dets, poses):
+            d.set_prefetch(True)
+            p_.set_prefetch(True)
     pipes = [FramePipeline(dets[k], poses[k], 480, 640, batch=a.batch, confidence=0.01, num_classes=80,
                            use_graph=not a.no_graph) for k in range(S)]
     masked = []
@@ -556,17 +562,28 @@ def main():
     side = {}
     if world == 1 and not a.no_side_runs:
         n1 = min(a.steps, 100)
-        run(4, False, depth=0)
-        torch.cuda.synchronize()
-        lat["ms"], lat["on"] = [], True
-        t1 = time.perf_counter()
-        run(n1, False, depth=0)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter() - t1
-        lat["on"] = False
-        one = np.array(lat["ms"])
-        side["single"] = {"p50": round(float(np.percentile(one, 50)), 4), "p95": round(float(np.percentile(one, 95)), 4),
-                          "frames_per_sec": round(n1 * a.batch / t1, 2)}
+
+        def one_at_a_time(prefetch):
+            for d, p_ in zip(dets, poses):        # lone-frame latency mode: XCD-matched layout + next-layer filter prefetch
+                d.set_prefetch(prefetch)
+                p_.set_prefetch(prefetch)
+            run(2 * S, False, depth=0)            # (re-captures every stream's graph)
+            torch.cuda.synchronize()
+            lat["ms"], lat["on"] = [], True
+            t1 = time.perf_counter()
+            run(n1, False, depth=0)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter() - t1
+            lat["on"] = False
+            one = np.array(lat["ms"])
+            return {"p50": round(float(np.percentile(one, 50)), 4), "p95": round(float(np.percentile(one, 95)), 4),
+                    "frames_per_sec": round(n1 * a.batch / t1, 2)}
+
+        side["single"] = one_at_a_time(True)
+        side["single"]["filter_prefetch"] = True
+        side["single"]["without_filter_prefetch"] = one_at_a_time(a.prefetch)
+        if a.prefetch:
+            side["single"].pop("without_filter_prefetch")
         src["pool"] = pool_host
         n2 = min(a.steps, 200)
         run(2 * S, False)
@@ -634,7 +651,7 @@ def main():
                            **{k: v for k, v in rf.items() if k not in ("bound", "peak", "unit", "traffic")}}
         if a.precision == "bf16x3":
             out["roofline"]["frac_of_executed_mfma"] = round(6 * agg / PEAK_F16_MFMA_TFLOPS, 4)
-        out["roofline"]["hbm"] = hbm_block(rf["algorithmic_bytes_per_step"], out["value"] / world, a.batch)
+        out["roofline"]["hbm"] = hbm_block(rf["algorithmic_bytes_per_step"], out["value"] / world, a.batch, a.precision)
     if rank == 0 and world == 1 and a.insitu:
         out.setdefault("roofline", {})["insitu"] = insitu_layers(dets, poses, run, S, a.batch, a.insitu, a.precision)
     if rank == 0 and world == 1 and a.other_modes:

@@ -53,6 +53,8 @@ PROTOTYPES = {
     "bp_yolo_set_precision": (C.c_int, [vp, C.c_int]),
     "bp_kpd_set_precision": (C.c_int, [vp, C.c_int]),
     "bp_calibrate_ticks": (C.c_int, [C.c_longlong, c_float_p, vp]),
+    "bp_yolo_set_prefetch": (C.c_int, [vp, C.c_int]),
+    "bp_kpd_set_prefetch": (C.c_int, [vp, C.c_int]),
     "bp_yolo_set_stamps": (C.c_int, [vp, vp, C.c_int]),
     "bp_kpd_set_stamps": (C.c_int, [vp, vp, C.c_int]),
     "bp_yolo_op_name": (C.c_int, [vp, C.c_int, C.c_char_p, C.c_int]),

@@ -659,8 +659,8 @@ __global__ void probe_placement_kernel(int* out) {
 
 // ---- clock calibration for the s_memtime stamps of the convolution kernels (c_api.cpp bp_calibrate_ticks)
 __global__ void spin_ticks_kernel(long long ticks) {
-    const unsigned long long t0 = __builtin_readcyclecounter();
-    while ((long long)(__builtin_readcyclecounter() - t0) < ticks) __builtin_amdgcn_s_sleep(1);
+    const unsigned long long t0 = bp_clock();
+    while ((long long)(bp_clock() - t0) < ticks) __builtin_amdgcn_s_sleep(1);
 }
 void launch_spin_ticks(long long ticks, hipStream_t s) { hipLaunchKernelGGL(spin_ticks_kernel, dim3(1), dim3(1), 0, s, ticks); }
 

@@ -26,6 +26,11 @@ struct Error : std::runtime_error {
                                        ":" + std::to_string(__LINE__));                   \
     } while (0)
 
+// The clock of the kernels' debug / in-situ stamps (ConvParams::stamps): s_memrealtime, the constant 100 MHz reference clock
+// that is ONE counter for the whole device.  (s_memtime, the shader-cycle counter, is per XCD: marks of blocks on different
+// XCDs differ by seconds, so a layer's first-entry -> last-store span cannot be taken from it.)
+__device__ __forceinline__ unsigned long long bp_clock() { return __builtin_amdgcn_s_memrealtime(); }
+
 enum Act : int { ACT_LINEAR = 0, ACT_LEAKY = 1, ACT_RELU = 2 };
 
 // where the epilogue puts element (m = (b,oy,ox), n = out channel)
@@ -81,6 +86,23 @@ struct ConvParams {
     int skip_f32;                 // 1: every reader of `out` takes the planes -- the fp32 store is dropped (engine.cpp plan_planes)
     int abl;                      // timing ablations, experimental builds only (-DBP_EXPERIMENTAL; tools/abl_pl.sh): 0 in the product
     const unsigned short* wpl;    // filters as conv_pl.hip's LDS image: [CoutPad/64][nchunks][plane][64 rows][64 B swizzled]
+    // Filter prefetch for the NEXT convolution on the stream (engine.cpp run_op; conv_dev.h prefetch_block): the launch carries
+    // pf_blocks extra blocks past its work grid that pull pf_bytes of the next layer's filters toward the caches while this
+    // layer computes.  At batch 1 every layer's filters come cold from HBM (730 MB per frame do not stay in the 256 MB MALL),
+    // pulled by the few blocks that need them at 17-22 B/clk/CU where a cache hit delivers 27-60 (tools/micro/cold_fetch.hip).
+    // Both follow the XCD the hardware puts a block on (block b -> XCD b % 8, each XCD with its own 4 MB L2):
+    //  * xcd_map: the work grid is laid out so that ALL M-tiles of a (N-tile, K-slice) pair q run on XCD q % 8 -- its
+    //    filters are fetched into ONE L2, once, instead of by MT blocks on MT XCDs (used when there are >= 8 pairs);
+    //  * the prefetch block for pair q of the next layer runs on XCD q % 8 as well and pulls the head of that pair's filter
+    //    range, so the work blocks find it in their own L2 (46-60 B/clk/CU against 17-22 cold: tools/micro/cold_fetch.hip).
+    int xcd_map;                  // 1: block b -> XCD x = b % 8, i = b / 8: pair (i / mtiles) * 8 + x, M-tile i % mtiles
+    int mtiles, n_tiles;          // M-tiles, output tiles of the launch (set by the launchers)
+    int work_blocks;              // blocks of the work grid incl. padding (set by the launchers; 0 = the whole grid)
+    const void* pf_ptr;           // next layer's filters (nullptr: no prefetch blocks)
+    int pf_first;                 // first prefetch block (work_blocks rounded up to 8, set by the launchers)
+    int pf_pairs, pf_splits, pf_cps, pf_nchunks;   // the next launch: pairs, K slices, chunks per slice, chunks
+    int pf_tile_stride, pf_chunk_bytes;            // its filter layout: bytes per N-tile and per 32-k chunk (contiguous per pair)
+    int pf_cap;                   // bytes pulled per pair at most
 };
 
 // tile configuration ids for launch_conv
@@ -100,7 +122,9 @@ enum ConvTile : int { TILE_64x64 = 0, TILE_128x64 = 1, TILE_W64_1x1 = 2, TILE_W6
                       TILE_PL128 = 14,      // 128x128, 2x2 waves of 64x64
                       TILE_PL128x64 = 15,   // 128x64, 2x2 waves of 64x32
                       TILE_PL256x128 = 16,  // 256x128, 4x2 waves of 64x64
-                      TILE_LAST = 16 };
+                      TILE_PL64K2 = 18,     // 64x64, two K groups of 2x2 waves (8 waves, a ring per group): for launches of at most one block per CU
+                      TILE_PL128S = 17,     // 128x128, 2x2 compute waves of 64x64 + 4 loader waves (wave specialisation; no K slices)
+                      TILE_LAST = 18 };
 
 // when non-null, launch_conv brackets the implicit-GEMM kernel itself (not the split-K reduce) with these events
 struct ConvProfHook { hipEvent_t e0, e1; };
@@ -127,6 +151,10 @@ void launch_f32_to_planes(const float* in, int ld, long long pixels, int C, unsi
 void launch_planes_to_f32(const unsigned short* planes, long long plane_elems, int np, float* out, int ld, long long pixels, int C,
                           hipStream_t s);
 int conv_tiles(const ConvParams& p, int tile);   // blocks per K-slice
+void conv_grid_setup(ConvParams& q, int bm, int bn);   // fills mtiles / n_tiles / work_blocks / pf_first from M, CoutPad, splits, xcd_map
+int conv_grid_blocks(const ConvParams& q);
+int conv_xcd_map(const ConvParams& c, int tile, int splits);   // engine.cpp: 1 when the launch is laid out by XCD
+void conv_prefetch_of(ConvParams& p, const ConvParams& next, int next_tile, int next_splits, int next_cps);   // engine.cpp              // work blocks + padding + prefetch blocks
 int conv_tile_bm(int tile);
 int conv_tile_bn(int tile);
 
@@ -172,7 +200,7 @@ void launch_f32_to_bf16x3(const float* in, unsigned short* out_planes, long long
 void launch_f32_to_f16_staged(const float* in, unsigned short* out, int CoutPad, int Kpad, hipStream_t s);      // ... fp16 mode
 void launch_f32_to_bf16x3_staged(const float* in, unsigned short* out, int CoutPad, int Kpad, hipStream_t s);   // conv_kg.hip's layout
 void launch_probe_placement(int* d_out, int blocks, hipStream_t s);
-void launch_spin_ticks(long long ticks, hipStream_t s);   // one thread spinning until s_memtime has advanced by `ticks`
+void launch_spin_ticks(long long ticks, hipStream_t s);   // one thread spinning until bp_clock() has advanced by `ticks`
 
 // crop stage (dataloader.py:794-835 + img.py:242-262) on device.
 //  frames: BGR u8 [batch][H][W][3]; sel: [batch][8] select records (box in YOLO-input pixels) or boxes [batch][4];

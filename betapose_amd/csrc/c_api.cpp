@@ -393,6 +393,8 @@ int bp_calibrate_ticks(long long ticks, float* ms, void* stream) {
     return 0;
     BP_CATCH
 }
+int bp_yolo_set_prefetch(bp_yolo* y, int on) { y->net->set_prefetch(on != 0); return 0; }
+int bp_kpd_set_prefetch(bp_kpd* k, int on) { k->net->set_prefetch(on != 0); return 0; }
 int bp_yolo_set_stamps(bp_yolo* y, unsigned long long* d_buf, int slots) { y->net->set_stamps(d_buf, slots); return 0; }
 int bp_kpd_set_stamps(bp_kpd* k, unsigned long long* d_buf, int slots) { k->net->set_stamps(d_buf, slots); return 0; }
 static int op_name(const bp::Net& net, int i, char* out, int cap) {
@@ -541,6 +543,10 @@ int bp_conv2d_planes(const float* d_in, int N, int H, int W, int Cin, const floa
         p.tickets = (int*)net.arena_.alloc_bytes((size_t)tiles * sizeof(int));
         BP_HIP(hipMemset(p.tickets, 0, (size_t)tiles * sizeof(int)));
     }
+    if (std::getenv("BP_CONV_SELF_PREFETCH")) {   // (tests: the launch is laid out by XCD and carries prefetch blocks, for its own filters)
+        p.xcd_map = bp::conv_xcd_map(p, t, sp);
+        bp::conv_prefetch_of(p, p, t, sp, per);
+    }
     bp::launch_conv(p, t, s);
     BP_HIP(hipStreamSynchronize(s));
     if (const char* e = std::getenv("BP_CONV_STAMPS")) {   // debug: per-block s_memtime marks of one extra launch
@@ -572,7 +578,7 @@ int bp_conv2d_planes(const float* d_in, int N, int H, int W, int Cin, const floa
             std::fprintf(stderr, "[stage timing] cycles per stage: issue slots 0..UPW %.0f | slots ..SYNC %.0f | wait+barrier %.0f | SYNC..end %.0f\n",
                          sum[0] / stages, sum[1] / stages, sum[2] / stages, sum[3] / stages);
         }
-        std::fprintf(stderr, "[stamps] blocks=%d  mean cycles since the block's entry: index math done %.0f | chunk 0 in LDS %.0f | "
+        std::fprintf(stderr, "[stamps] blocks=%d  mean 10-ns ticks (s_memrealtime, 100 MHz) since the block's entry: index math done %.0f | chunk 0 in LDS %.0f | "
                      "K loop done %.0f | in-block sums (conv_kg) or cycles parked at the stage waits (conv_pl) %.0f | slab parked + ticket %.0f (%d blocks) | slices combined %.0f (%d) | stores done %.0f (%d) | "
                      "last mark of the grid %.0f after the first entry\n", nb, mean(1), mean(2), mean(3), mean(7), mean(5), cnt[5], mean(6),
                      cnt[6], mean(4), cnt[4], last);

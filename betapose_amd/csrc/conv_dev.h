@@ -69,19 +69,50 @@ __device__ __forceinline__ PlaneDesc make_plane_desc(const ConvParams& p) {
     return d;
 }
 // four consecutive channels of one pixel -> 8 B per plane at byte offset `off` (= element index * 2)
+// one LDS-DMA instruction: 64 lanes x 16 B, LDS destination lane-linear from `lds`
+typedef __attribute__((address_space(3))) void lds_void_t;
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds, unsigned voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)lds, 16, (int)voff, soff, 0, 0);
+}
+
+// A block past the work grid (ConvParams::pf_*): pull its share of the next layer's filters through the memory hierarchy.
+// The bytes are dropped into 1 KB of LDS per wave (LDS-DMA: no registers, nothing for the compiler to discard); the wave
+// ends when they have arrived.
+template <int NT>
+__device__ __forceinline__ void prefetch_block(const ConvParams& p, char* lds) {
+    const int e = (int)blockIdx.x - p.pf_first;
+    if (e < 0) return;                                   // padding between the work grid and the first prefetch block
+    const int q = (e >> 3) * 8 + ((int)blockIdx.x & 7);  // pf_first is a multiple of 8: this block sits on XCD q % 8
+    if (q >= p.pf_pairs) return;
+    const int tile_n = q / p.pf_splits, split = q - tile_n * p.pf_splits;
+    const int c0 = split * p.pf_cps, c1 = min(p.pf_nchunks, c0 + p.pf_cps);
+    if (c1 <= c0) return;
+    const long long beg = (long long)tile_n * p.pf_tile_stride + (long long)c0 * p.pf_chunk_bytes;
+    const unsigned n = (unsigned)min((long long)(c1 - c0) * p.pf_chunk_bytes, (long long)p.pf_cap);
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(static_cast<const char*>(p.pf_ptr)) + beg, 0, (int)n, 0x00020000);
+    char* const dst = lds + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6) * 1024;
+    for (unsigned off = threadIdx.x * 16u; off < n; off += NT * 16u) dma16(r, dst, off, 0);
+}
+
+// (write-through `sc1` epilogue stores -- lines leave the XCD's L2 instead of staying dirty until the kernel ends -- were
+// A/B-tested in rounds 2 and 3, per layer at batch 28 and in the pipeline in every mode: no difference beyond +-0.5 %)
+__device__ __forceinline__ void store_b64_wt(u32x2 v, __amdgpu_buffer_rsrc_t r, unsigned off, bool) {
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)off, 0, 0);
+}
 __device__ __forceinline__ void emit_planes4(const PlaneDesc& d, f32x4 v, unsigned off) {
     if (d.np == 1) {
         const f16x4 h = __builtin_convertvector(v, f16x4);
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h), d.r0, (int)off, 0, 0);
+        store_b64_wt(__builtin_bit_cast(u32x2, h), d.r0, off, false);
     } else if (d.np == 3) {
         const bf16x4 h1 = __builtin_convertvector(v, bf16x4);
         const f32x4 r1 = v - __builtin_convertvector(h1, f32x4);
         const bf16x4 h2 = __builtin_convertvector(r1, bf16x4);
         const f32x4 r2 = r1 - __builtin_convertvector(h2, f32x4);
         const bf16x4 h3 = __builtin_convertvector(r2, bf16x4);
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h1), d.r0, (int)off, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h2), d.r1, (int)off, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h3), d.r2, (int)off, 0, 0);
+        store_b64_wt(__builtin_bit_cast(u32x2, h1), d.r0, off, false);
+        store_b64_wt(__builtin_bit_cast(u32x2, h2), d.r1, off, false);
+        store_b64_wt(__builtin_bit_cast(u32x2, h3), d.r2, off, false);
     }
 }
 // one element (store modes / alignments the 16-B path does not cover); idx = element index inside the output view

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     constexpr int LDT = BN + 4;                 // row stride of the output tile staged through LDS in the epilogue
     static_assert(BM * LDT <= 2 * (BM + BN) * LDS_LD, "LDS too small for the staged epilogue");
 
-    const unsigned long long t_entry = p.stamps ? __builtin_readcyclecounter() : 0ull;
+    const unsigned long long t_entry = p.stamps ? bp_clock() : 0ull;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         BP_MF(fa1, fb1, w);                          BP_SB();                                          \
     }
 
-#define BP_STAMP(k_) if (p.stamps && tid == 0) p.stamps[(long long)blockIdx.x * 8 + (k_)] = __builtin_readcyclecounter();
+#define BP_STAMP(k_) if (p.stamps && tid == 0) p.stamps[(long long)blockIdx.x * 8 + (k_)] = bp_clock();
     if (p.stamps && tid == 0) p.stamps[(long long)blockIdx.x * 8 + 0] = t_entry;
     BP_STAMP(1);   // index math done
     if (c_begin < c_end) {
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     __shared__ int s_last;
 #define BP_NT 256
 #define BP_SLAST s_last
-#define BP_TAIL_STAMP(k_)
+#define BP_TAIL_STAMP(k_) BP_STAMP(k_)
 #include "conv_tail.inc"
 #undef BP_TAIL_STAMP
 #undef BP_NT
@@ -343,15 +343,28 @@ __global__ __launch_bounds__(256) void conv_igemm_h_kernel(const ConvParams p) {
 #define BH_AS(s_, pl_) (sh + (s_) * STAGE_HALFS + (pl_) * (BM * LDH))
 #define BH_BS(s_, pl_) (sh + (s_) * STAGE_HALFS + NP * (BM * LDH) + (pl_) * (BN * LDH))
 
+    if (p.work_blocks && (int)blockIdx.x >= p.work_blocks) { prefetch_block<256>(p, reinterpret_cast<char*>(smem)); return; }
+    const unsigned long long t_entry = p.stamps ? bp_clock() : 0ull;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int n_tiles_n = p.CoutPad / BN;
-    const int split = (int)blockIdx.x % p.splits;
-    const int tile_id = (int)blockIdx.x / p.splits;
-    const int tile_n = tile_id % n_tiles_n;
-    const int tile_m = tile_id / n_tiles_n;
+    int split, tile_n, tile_m;
+    if (p.xcd_map) {   // all M-tiles of a (N-tile, K-slice) pair on one XCD (ConvParams::xcd_map)
+        const int i = (int)blockIdx.x >> 3, ql = i / p.mtiles;
+        const int q = ql * 8 + ((int)blockIdx.x & 7);
+        if (q >= n_tiles_n * p.splits) return;           // padding of the last round of pairs
+        tile_m = i - ql * p.mtiles;
+        tile_n = q / p.splits;
+        split = q - tile_n * p.splits;
+    } else {
+        split = (int)blockIdx.x % p.splits;
+        const int t = (int)blockIdx.x / p.splits;
+        tile_n = t % n_tiles_n;
+        tile_m = t / n_tiles_n;
+    }
+    const int tile_id = tile_m * n_tiles_n + tile_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int c_begin = split * p.chunks_per_split;
 #ifdef BP_ABLATE_KLOOP   // timing experiment only (wrong results): one chunk per block, i.e. the fixed cost of the launch chain
@@ -562,18 +575,23 @@ __global__ __launch_bounds__(256) void conv_igemm_h_kernel(const ConvParams p) {
         if (nch & 1) BH_PHASE(0, ra1, rb1, ra0, rb0);
     }
     __syncthreads();
+#define BH_STAMP(k_) if (p.stamps && tid == 0) p.stamps[(long long)(tile_id * p.splits + split) * 8 + (k_)] = bp_clock();
+    if (p.stamps && tid == 0) p.stamps[(long long)(tile_id * p.splits + split) * 8 + 0] = t_entry;
+    BH_STAMP(3);   // K loop done
 
     const int w_row0 = wm * (BM / 2), w_col0 = wn * (BN / 2);
     __shared__ int s_last;
 #define BP_NT 256
 #define BP_SLAST s_last
 #define BP_EARLY_BIAS bias_early
-#define BP_TAIL_STAMP(k_)
+#define BP_TAIL_STAMP(k_) BH_STAMP(k_)
 #include "conv_tail.inc"
 #undef BP_EARLY_BIAS
 #undef BP_TAIL_STAMP
 #undef BP_NT
 #undef BP_SLAST
+    if (p.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); BH_STAMP(4); }
+#undef BH_STAMP
 #undef BH_AS
 #undef BH_BS
 #undef BH_ADDR
@@ -586,16 +604,27 @@ __global__ __launch_bounds__(256) void conv_igemm_h_kernel(const ConvParams p) {
 
 thread_local ConvProfHook* g_conv_prof = nullptr;
 
+// the 1-D launch grid of the kernels that take ConvParams::xcd_map / pf_*: [work blocks | padding to 8 | prefetch blocks]
+void conv_grid_setup(ConvParams& q, int bm, int bn) {
+    q.mtiles = (q.M + bm - 1) / bm;
+    const int ntn = (q.CoutPad + bn - 1) / bn;
+    q.n_tiles = q.mtiles * ntn;
+    const int pairs = ntn * q.splits;
+    q.work_blocks = q.xcd_map ? ((pairs + 7) / 8) * 8 * q.mtiles : q.n_tiles * q.splits;
+    q.pf_first = (q.work_blocks + 7) & ~7;
+}
+int conv_grid_blocks(const ConvParams& q) { return q.pf_ptr ? q.pf_first + ((q.pf_pairs + 7) / 8) * 8 : q.work_blocks; }
+
 int conv_tile_bm(int tile) {
     switch (tile) {
-        case TILE_128x64: case TILE_W64_2x1: case TILE_W64_2x2: case TILE_PL128: case TILE_PL128x64: return 128;
+        case TILE_128x64: case TILE_W64_2x1: case TILE_W64_2x2: case TILE_PL128: case TILE_PL128x64: case TILE_PL128S: return 128;
         case TILE_PL256x128: return 256;
         default: return 64;
     }
 }
 int conv_tile_bn(int tile) {
     switch (tile) {
-        case TILE_W64_1x2: case TILE_W64_2x2: case TILE_PL128: case TILE_PL256x128: return 128;
+        case TILE_W64_1x2: case TILE_W64_2x2: case TILE_PL128: case TILE_PL256x128: case TILE_PL128S: return 128;
         default: return 64;
     }
 }
@@ -627,11 +656,13 @@ static void launch_t(const ConvParams& p, hipStream_t s) {
 template <int TM, int TN, int NP, bool BD = false>
 static void launch_h_t(const ConvParams& p, hipStream_t s) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
-    dim3 grid(((p.M + BM - 1) / BM) * (p.CoutPad / BN) * p.splits);
+    ConvParams q = p;
+    conv_grid_setup(q, BM, BN);
+    dim3 grid(conv_grid_blocks(q));
     if (g_conv_prof)
-        hipExtLaunchKernelGGL((conv_igemm_h_kernel<TM, TN, NP, BD>), grid, dim3(256), 0, s, g_conv_prof->e0, g_conv_prof->e1, 0, p);
+        hipExtLaunchKernelGGL((conv_igemm_h_kernel<TM, TN, NP, BD>), grid, dim3(256), 0, s, g_conv_prof->e0, g_conv_prof->e1, 0, q);
     else
-        hipLaunchKernelGGL((conv_igemm_h_kernel<TM, TN, NP, BD>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((conv_igemm_h_kernel<TM, TN, NP, BD>), grid, dim3(256), 0, s, q);
 }
 
 int conv_vec_mode(const ConvParams& p) {

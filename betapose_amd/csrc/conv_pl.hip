@@ -35,18 +35,28 @@
 
 namespace bp {
 
-typedef __attribute__((address_space(3))) void lds_void_t;
+// (dma16, conv_dev.h: operands come in as plain locals -- array elements written straight into the builtin's argument list
+// made hipcc (ROCm 7.2) drop the kernel's host stub)
 
-// one LDS-DMA instruction: 64 lanes x 16 B, LDS destination lane-linear from `lds`.  Operands come in as plain locals:
-// array elements written straight into the builtin's argument list made hipcc (ROCm 7.2) drop the kernel's host stub.
-__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds, unsigned voff, int soff) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)lds, 16, (int)voff, soff, 0, 0);
-}
-
-// WM x WN waves, each a (32 TM) x (32 TN) accumulator tile; NST LDS stages of CPS 32-k chunks each.
-template <int NP, int WM, int WN, int TM, int TN, int NST, int CPS>
-__global__ __launch_bounds__(64 * WM * WN) void conv_pl_kernel(const ConvParams p) {
-    constexpr int NW = WM * WN, NT = 64 * NW;
+// WM x WN compute waves, each a (32 TM) x (32 TN) accumulator tile; NST LDS stages of CPS 32-k chunks each.
+// LW > 0: LW further waves do nothing but issue the DMAs (wave specialisation).  An LDS-DMA instruction parks the issuing
+// wave for 60-180 cycles, and a fp16 128x128 stage is 16 of them against 256 MFMA cycles per SIMD: with every wave doing both,
+// the matrix pipe idles while its wave is stuck in the memory pipeline's queue (22 % MFMA-busy, profiles/
+// r03_pmc_mfma_busy_f16_batch28.json).  A loader wave per SIMD takes that wait; the compute waves only read fragments and
+// multiply.  (K slices are not supported by the specialised form: its tiles run where the grid fills the chip anyway.)
+//
+// KG > 1: KG wave groups of WM x WN waves per block, each with its OWN ring, walking its own contiguous part of the block's K
+// range into its own accumulators; group 0 collects the partial sums through LDS behind the K loop.  For launches that
+// cannot put more than one 4-wave block on a CU (the M <= 1 280 layers of the batch-1 frame): a wave issues in order and an
+// LDS-DMA instruction holds it for 60+ cycles, so with one wave per SIMD the matrix pipe idles through every DMA issue
+// (measured 860 cycles per 384-cycle bf16x3 chunk); a second wave on the SIMD multiplies meanwhile -- K parallelism without
+// the slab hand-off of the K slices between blocks (3-5 us per launch, tools/bench_pl.py with BP_CONV_STAMPS).
+template <int NP, int WM, int WN, int TM, int TN, int NST, int CPS, int LW = 0, int KG = 1>
+__global__ __launch_bounds__(64 * (WM * WN * KG + LW)) void conv_pl_kernel(const ConvParams p) {
+    static_assert(LW == 0 || KG == 1, "loader waves and K groups are alternatives");
+    constexpr int NWC = WM * WN;                  // compute waves (per K group)
+    constexpr int NW = LW ? LW : NWC;             // waves (of a group) that issue DMAs
+    constexpr int NT = 64 * (NWC * KG + LW);
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int LDT = BN + 4;
     constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64;        // bytes per plane and chunk
@@ -54,20 +64,36 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_pl_kernel(const ConvParams 
     constexpr int STAGE = CPS * CHUNK;
     constexpr int EP_SLABS_ = BM > 128 ? BM / 64 : 1;       // epilogue staging in 64-row slabs on the big tiles (conv_tail.inc)
     constexpr int EPI_BYTES = (BM / EP_SLABS_) * LDT * 4;
-    constexpr int SMEM_BYTES = (NST * STAGE > EPI_BYTES ? NST * STAGE : EPI_BYTES) + 16;
+    constexpr int RING = NST * STAGE;
+    constexpr int KGSUM_BYTES = (KG - 1) * NWC * TM * TN * 4096;      // the other groups' accumulators, fragment order
+    static_assert(KGSUM_BYTES <= KG * RING, "");
+    constexpr int SMEM_BYTES = (KG * RING > EPI_BYTES ? KG * RING : EPI_BYTES) + 16;
     // the ONE LDS object of the kernel (a second one makes hipcc drain vmcnt before every fragment read)
     __shared__ __attribute__((aligned(16))) float smem[SMEM_BYTES / 4];
-    char* const sb = reinterpret_cast<char*>(smem);
     typedef typename HalfOps<NP>::frag frag_t;
 
-    const unsigned long long t_entry = p.stamps ? __builtin_readcyclecounter() : 0ull;
+    if (p.work_blocks && (int)blockIdx.x >= p.work_blocks) { prefetch_block<NT>(p, reinterpret_cast<char*>(smem)); return; }
+    const unsigned long long t_entry = p.stamps ? bp_clock() : 0ull;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
+    const int wave_id = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kgrp = KG > 1 ? wave_id / NWC : 0;             // K group of the wave
+    const int wv = wave_id - kgrp * NWC;                     // wave inside its group
+    char* const sb = reinterpret_cast<char*>(smem) + kgrp * RING;     // the group's ring
+    const bool is_loader = LW ? wave_id >= NWC : true;      // issues DMAs
+    const bool has_acc = LW ? wave_id < NWC : kgrp == 0;     // owns the block's accumulators in the tail (conv_tail.inc)
+    const int wave = LW ? (is_loader ? wave_id - NWC : 0) : wv;        // index among the DMA-issuing waves of the group
+    const int wm = (LW ? (wave_id < NWC ? wave_id : 0) : wv) / WN, wn = (LW ? (wave_id < NWC ? wave_id : 0) : wv) % WN;
     const int n_tiles_n = (p.CoutPad + BN - 1) / BN;
     int split, tile_id;
-    if (p.splits > 1) {
+    if (p.xcd_map) {   // all M-tiles of a (N-tile, K-slice) pair on one XCD (ConvParams::xcd_map)
+        const int i = (int)blockIdx.x >> 3, ql = i / p.mtiles;
+        const int q = ql * 8 + ((int)blockIdx.x & 7);
+        if (q >= n_tiles_n * p.splits) return;           // padding of the last round of pairs
+        const int tn = q / p.splits;
+        split = q - tn * p.splits;
+        tile_id = (i - ql * p.mtiles) * n_tiles_n + tn;
+    } else if (p.splits > 1) {
         // K-slice fastest: consecutive block ids (= consecutive XCDs) take different K ranges of one output tile, so every
         // XCD streams its own share of the filters through its private L2
         split = (int)blockIdx.x % p.splits;
@@ -75,7 +101,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_pl_kernel(const ConvParams 
     } else {
         // block b runs on XCD b % 8: give every XCD a CONTIGUOUS range of tiles (N-tiles of one M-tile next to each other,
         // neighbouring M-tiles share their halo rows), so the re-reads of an activation tile hit that XCD's L2
-        const int nblk = (int)gridDim.x, q = nblk >> 3, r = nblk & 7;
+        const int nblk = p.n_tiles ? p.n_tiles : (int)gridDim.x, q = nblk >> 3, r = nblk & 7;
         const int xcd = (int)blockIdx.x & 7, i = (int)blockIdx.x >> 3;
         split = 0;
         tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
@@ -83,8 +109,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_pl_kernel(const ConvParams 
     const int tile_n = tile_id % n_tiles_n;
     const int tile_m = tile_id / n_tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int c_begin = split * p.chunks_per_split;
-    const int c_end = min(p.nchunks, c_begin + p.chunks_per_split);
+    const int cb_blk = split * p.chunks_per_split, ce_blk = min(p.nchunks, cb_blk + p.chunks_per_split);
+    const int c_per = (ce_blk - cb_blk + KG - 1) / KG;                // chunks per K group (the last may get fewer, or none)
+    const int c_begin = KG > 1 ? min(cb_blk + kgrp * c_per, ce_blk) : cb_blk;
+    const int c_end = KG > 1 ? min(c_begin + c_per, ce_blk) : ce_blk;
+    const int n_it = (c_per + CPS - 1) / CPS;                         // stages: the same for every group (they share the barriers)
 #ifdef BP_EXPERIMENTAL   // timing ablations (wrong results): 1 no activation DMA, 2 no filter DMA, 4 no MFMA, 8 no fragment reads
     const int abl = p.abl;
 #else
@@ -264,9 +293,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_pl_kernel(const ConvParams 
         acc[i][jn] = HalfOps<NP>::mfma(fa[fs][NP == 1 ? 0 : PA[q]][i], fb[fs][NP == 1 ? 0 : PB[q]][jn], acc[i][jn]);
     };
 
-#define PL_STAMP(k_) if (p.stamps && tid == 0) p.stamps[(long long)blockIdx.x * 8 + (k_)] = __builtin_readcyclecounter();
+#define PL_STAMP(k_) if (p.stamps && tid == 0) p.stamps[(long long)(tile_id * p.splits + split) * 8 + (k_)] = bp_clock();
 #define PL_SB() __builtin_amdgcn_sched_barrier(0)
-    if (p.stamps && tid == 0) p.stamps[(long long)blockIdx.x * 8 + 0] = t_entry;
+    if (p.stamps && tid == 0) p.stamps[(long long)(tile_id * p.splits + split) * 8 + 0] = t_entry;
     PL_STAMP(1);   // index math done
     unsigned long long t_wait = 0;     // debug (p.stamps): cycles parked at the stage waits
     // One stage = NSTEP x NMF MFMA slots.  An LDS-DMA instruction costs the issuing wave 60-180 cycles and a wave issues in
@@ -283,49 +312,88 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_pl_kernel(const ConvParams 
         // prologue: NST - 1 stages in flight
         static_for<NST - 1>([&](auto sc) __attribute__((always_inline)) {
             stage_addr();
-            static_for<IPW>([&](auto dc) __attribute__((always_inline)) { dma_piece(decltype(sc)::value * STAGE, dc); });
+            if (LW == 0 || is_loader)
+                static_for<IPW>([&](auto dc) __attribute__((always_inline)) { dma_piece(decltype(sc)::value * STAGE, dc); });
         });
         int rd_off = 0, wr_off = (NST - 1) * STAGE;
-        int c = c_begin;
+        int it = 0;
         do {
             stage_addr();
             // this wave's DMAs of the oldest stage have landed (NST - 2 younger stages stay in flight); behind the barrier
             // everybody's have, and everybody is done reading the slot the next issue overwrites
 #ifdef BP_EXPERIMENTAL
-            const unsigned long long tw0 = p.stamps ? __builtin_readcyclecounter() : 0ull;
+            const unsigned long long tw0 = p.stamps ? bp_clock() : 0ull;
 #endif
             asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"((NST - 2) * IPW) : "memory");
 #ifdef BP_EXPERIMENTAL
-            if (p.stamps) t_wait += __builtin_readcyclecounter() - tw0;
+            if (p.stamps) t_wait += bp_clock() - tw0;
 #endif
-            static_for<NRD>([&](auto rc) __attribute__((always_inline)) { read_frag(rd_off, std::integral_constant<int, 0>{}, rc); });
-            PL_SB();
-            static_for<N0>([&](auto dc) __attribute__((always_inline)) { dma_piece(wr_off, dc); });
-            PL_SB();
-            static_for<SLOTS>([&](auto gc) __attribute__((always_inline)) {
-                constexpr int g = decltype(gc)::value, s = g / NMF, m = g % NMF;
-                mfma_one(std::integral_constant<int, s>{}, std::integral_constant<int, m>{});
-                constexpr int d_lo = N0 + (g * DREM + SLOTS - 1) / SLOTS, d_hi = N0 + ((g + 1) * DREM + SLOTS - 1) / SLOTS;
-                static_for<d_hi - d_lo>([&](auto k) __attribute__((always_inline)) {
-                    dma_piece(wr_off, std::integral_constant<int, d_lo + decltype(k)::value>{});
-                });
-                if constexpr (s + 1 < NSTEP && m < HALF) {
-                    constexpr int r_lo = (m * NRD + HALF - 1) / HALF, r_hi = ((m + 1) * NRD + HALF - 1) / HALF;
-                    static_for<r_hi - r_lo>([&](auto k) __attribute__((always_inline)) {
-                        read_frag(rd_off, std::integral_constant<int, s + 1>{}, std::integral_constant<int, r_lo + decltype(k)::value>{});
-                    });
-                }
+            if constexpr (LW == 0) {
+                static_for<NRD>([&](auto rc) __attribute__((always_inline)) { read_frag(rd_off, std::integral_constant<int, 0>{}, rc); });
                 PL_SB();
-            });
+                static_for<N0>([&](auto dc) __attribute__((always_inline)) { dma_piece(wr_off, dc); });
+                PL_SB();
+                static_for<SLOTS>([&](auto gc) __attribute__((always_inline)) {
+                    constexpr int g = decltype(gc)::value, s = g / NMF, m = g % NMF;
+                    mfma_one(std::integral_constant<int, s>{}, std::integral_constant<int, m>{});
+                    constexpr int d_lo = N0 + (g * DREM + SLOTS - 1) / SLOTS, d_hi = N0 + ((g + 1) * DREM + SLOTS - 1) / SLOTS;
+                    static_for<d_hi - d_lo>([&](auto k) __attribute__((always_inline)) {
+                        dma_piece(wr_off, std::integral_constant<int, d_lo + decltype(k)::value>{});
+                    });
+                    if constexpr (s + 1 < NSTEP && m < HALF) {
+                        constexpr int r_lo = (m * NRD + HALF - 1) / HALF, r_hi = ((m + 1) * NRD + HALF - 1) / HALF;
+                        static_for<r_hi - r_lo>([&](auto k) __attribute__((always_inline)) {
+                            read_frag(rd_off, std::integral_constant<int, s + 1>{}, std::integral_constant<int, r_lo + decltype(k)::value>{});
+                        });
+                    }
+                    PL_SB();
+                });
+            } else if (is_loader) {      // (wave-uniform) loader waves: the whole stage's DMAs, nothing else
+                static_for<IPW>([&](auto dc) __attribute__((always_inline)) { dma_piece(wr_off, dc); });
+            } else {                     // compute waves: fragment reads pinned into the MFMA slots, no memory instruction
+                static_for<NRD>([&](auto rc) __attribute__((always_inline)) { read_frag(rd_off, std::integral_constant<int, 0>{}, rc); });
+                PL_SB();
+                static_for<SLOTS>([&](auto gc) __attribute__((always_inline)) {
+                    constexpr int g = decltype(gc)::value, s = g / NMF, m = g % NMF;
+                    mfma_one(std::integral_constant<int, s>{}, std::integral_constant<int, m>{});
+                    if constexpr (s + 1 < NSTEP && m < HALF) {
+                        constexpr int r_lo = (m * NRD + HALF - 1) / HALF, r_hi = ((m + 1) * NRD + HALF - 1) / HALF;
+                        static_for<r_hi - r_lo>([&](auto k) __attribute__((always_inline)) {
+                            read_frag(rd_off, std::integral_constant<int, s + 1>{}, std::integral_constant<int, r_lo + decltype(k)::value>{});
+                        });
+                    }
+                    PL_SB();
+                });
+            }
             wr_off = (wr_off + STAGE == NST * STAGE) ? 0 : wr_off + STAGE;
             rd_off = (rd_off + STAGE == NST * STAGE) ? 0 : rd_off + STAGE;
-            c += CPS;
-        } while (c < c_end);
+            ++it;
+        } while (it < n_it);
     }
     // the ring (still receiving the out-of-range tail issues) becomes the epilogue's staging tile
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     PL_STAMP(3);   // K loop done
-    if (p.stamps && tid == 0) p.stamps[(long long)blockIdx.x * 8 + 7] = t_entry + t_wait;   // (read as a duration)
+    if constexpr (KG > 1) {
+        // groups 1 .. KG-1 park their accumulators in LDS (fragment order: 16 B per lane and instruction), group 0 adds them
+        // in group order -- the same sum chain whichever group finished first
+        char* const kb = reinterpret_cast<char*>(smem) + (wv * (TM * TN * 4)) * 1024 + lane * 16;
+        if (kgrp > 0)
+            static_for<TM * TN * 4>([&](auto ec) __attribute__((always_inline)) {
+                constexpr int t = decltype(ec)::value / 4, q = decltype(ec)::value % 4;
+                f32x4 v;
+                v.x = acc[t / TN][t % TN][4 * q]; v.y = acc[t / TN][t % TN][4 * q + 1]; v.z = acc[t / TN][t % TN][4 * q + 2]; v.w = acc[t / TN][t % TN][4 * q + 3];
+                *reinterpret_cast<f32x4*>(kb + ((kgrp - 1) * NWC * TM * TN * 4 + t * 4 + q) * 1024) = v;
+            });
+        __syncthreads();
+        if (kgrp == 0)
+            static_for<(KG - 1) * TM * TN * 4>([&](auto ec) __attribute__((always_inline)) {
+                constexpr int g = decltype(ec)::value / (TM * TN * 4), t = (decltype(ec)::value / 4) % (TM * TN), q = decltype(ec)::value % 4;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(kb + (g * NWC * TM * TN * 4 + t * 4 + q) * 1024);
+                acc[t / TN][t % TN][4 * q] += v.x; acc[t / TN][t % TN][4 * q + 1] += v.y; acc[t / TN][t % TN][4 * q + 2] += v.z; acc[t / TN][t % TN][4 * q + 3] += v.w;
+            });
+        __syncthreads();
+    }
+    if (p.stamps && tid == 0) p.stamps[(long long)(tile_id * p.splits + split) * 8 + 7] = t_entry + t_wait;   // (read as a duration)
 
     const int w_row0 = wm * (32 * TM), w_col0 = wn * (32 * TN);
 #define BP_NT NT
@@ -333,7 +401,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_pl_kernel(const ConvParams 
 #define BP_EARLY_BIAS bias_early
 #define BP_TAIL_STAMP(k_) PL_STAMP(k_)
 #define BP_EP_SLABS EP_SLABS_
+#define BP_HAS_ACC has_acc
 #include "conv_tail.inc"
+#undef BP_HAS_ACC
 #undef BP_EP_SLABS
 #undef BP_NT
 #undef BP_SLAST
@@ -344,21 +414,29 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_pl_kernel(const ConvParams 
 #undef PL_SB
 }
 
-bool conv_tile_is_pl(int tile) { return tile == TILE_PL64 || tile == TILE_PL128 || tile == TILE_PL128x64 || tile == TILE_PL256x128; }
+bool conv_tile_is_pl(int tile) {
+#ifdef BP_EXPERIMENTAL
+    if (tile == TILE_PL128S || tile == TILE_PL64K2) return true;
+#endif
+    return tile == TILE_PL64 || tile == TILE_PL128 || tile == TILE_PL128x64 || tile == TILE_PL256x128;
+}
 
 bool conv_pl_eligible(const ConvParams& p) {
     return p.in16 != nullptr && p.wpl != nullptr && (p.Cin % 32 == 0) && (p.in_ld % 8 == 0) && p.ksize * p.ksize <= 32 &&
            ((reinterpret_cast<uintptr_t>(p.in16) & 15) == 0) && (p.in16_plane % 8 == 0);
 }
 
-template <int NP, int WM, int WN, int TM, int TN, int NST, int CPS>
+template <int NP, int WM, int WN, int TM, int TN, int NST, int CPS, int LW = 0, int KG = 1>
 static void launch_pl_t(const ConvParams& p, hipStream_t s) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-    dim3 grid(((p.M + BM - 1) / BM) * ((p.CoutPad + BN - 1) / BN) * p.splits);
+    BP_CHECK(LW == 0 || p.splits == 1, "the wave-specialised operand-plane tiles do not take K slices");
+    ConvParams q = p;
+    conv_grid_setup(q, BM, BN);
+    dim3 grid(conv_grid_blocks(q));
     if (g_conv_prof)
-        hipExtLaunchKernelGGL((conv_pl_kernel<NP, WM, WN, TM, TN, NST, CPS>), grid, dim3(64 * WM * WN), 0, s, g_conv_prof->e0, g_conv_prof->e1, 0, p);
+        hipExtLaunchKernelGGL((conv_pl_kernel<NP, WM, WN, TM, TN, NST, CPS, LW, KG>), grid, dim3(64 * (WM * WN * KG + LW)), 0, s, g_conv_prof->e0, g_conv_prof->e1, 0, q);
     else
-        hipLaunchKernelGGL((conv_pl_kernel<NP, WM, WN, TM, TN, NST, CPS>), grid, dim3(64 * WM * WN), 0, s, p);
+        hipLaunchKernelGGL((conv_pl_kernel<NP, WM, WN, TM, TN, NST, CPS, LW, KG>), grid, dim3(64 * (WM * WN * KG + LW)), 0, s, q);
 }
 
 template <int NP>
@@ -368,6 +446,12 @@ static void launch_pl_np(const ConvParams& p, int tile, hipStream_t s) {
         case TILE_PL128: launch_pl_t<NP, 2, 2, 2, 2, NP == 1 ? 4 : 3, 1>(p, s); break;
         case TILE_PL128x64: launch_pl_t<NP, 2, 2, 2, 1, 3, NP == 1 ? 2 : 1>(p, s); break;
         case TILE_PL256x128: launch_pl_t<NP, 4, 2, 2, 2, NP == 1 ? 3 : 2, 1>(p, s); break;
+#ifdef BP_EXPERIMENTAL   // two round-3 forms that are parity-green and bring nothing:
+        // K groups inside the block (8 waves, two rings): the M <= 1 280 layers at 7.8-24.2 us against 7.7-25.0 us
+        case TILE_PL64K2: launch_pl_t<NP, 2, 2, 1, 1, 3, NP == 1 ? 2 : 1, 0, 2>(p, s); break;
+        // wave specialisation (4 loader waves): fp16 batch-28 3x3 115 us against 76 us
+        case TILE_PL128S: launch_pl_t<NP, 2, 2, 2, 2, NP == 1 ? 4 : 3, NP == 1 ? 2 : 1, 4>(p, s); break;
+#endif
         default: throw Error("not a conv_pl tile");
     }
 }

@@ -331,6 +331,46 @@ static const PlanEntry kPlanPL1[] = {
     { 10816,   128,   18, TILE_PL64,  1},
     { 43264,    64,    2, TILE_PL64,  1},
     { 43264,    64,    9, TILE_PL64,  1},
+    // batch 28 (BASELINE configs[2]; tools/tune_conv.py --pl --f16 --big --batch 28, profiles/r03_tune_pl_f16_batch28.txt)
+    {   2240,   512,   64, TILE_PL64,  1},
+    {   2240,   512,  144, TILE_PL64,  1},
+    {   2240,  2048,   16, TILE_PL64,  1},
+    {   2240,  2048,   32, TILE_PL128,  1},
+    {   4732,    64,   32, TILE_PL64,  1},
+    {   4732,   256,   16, TILE_PL128x64,  1},
+    {   4732,   512,   32, TILE_PL64,  1},
+    {   4732,  1024,  144, TILE_PL128,  1},
+    {   8960,   256,   32, TILE_PL64,  1},
+    {   8960,   256,   72, TILE_PL64,  1},
+    {   8960,   512,   32, TILE_PL64,  1},
+    {   8960,  1024,    8, TILE_PL64,  1},
+    {   8960,  1024,   16, TILE_PL64,  1},
+    {   8960,  1024,  144, TILE_PL256x128,  1},
+    {  18928,    64,   16, TILE_PL64,  1},
+    {  18928,   128,    8, TILE_PL64,  1},
+    {  18928,   256,   16, TILE_PL64,  1},
+    {  18928,   256,   24, TILE_PL64,  1},
+    {  18928,   512,   72, TILE_PL256x128,  1},
+    {  35840,   128,   16, TILE_PL64,  1},
+    {  35840,   128,   36, TILE_PL64,  1},
+    {  35840,   256,   16, TILE_PL64,  1},
+    {  35840,   512,    4, TILE_PL64,  1},
+    {  35840,   512,    8, TILE_PL64,  1},
+    {  35840,   512,   72, TILE_PL256x128,  1},
+    {  75712,    64,    8, TILE_PL64,  1},
+    {  75712,   128,    8, TILE_PL64,  1},
+    {  75712,   128,   12, TILE_PL256x128,  1},
+    {  75712,   256,   36, TILE_PL128,  1},
+    { 143360,    64,    2, TILE_PL64,  1},
+    { 143360,    64,    8, TILE_PL64,  1},
+    { 143360,    64,   18, TILE_PL64,  1},
+    { 143360,    64,   36, TILE_PL64,  1},
+    { 143360,   128,    8, TILE_PL64,  1},
+    { 143360,   256,    2, TILE_PL64,  1},
+    { 302848,    64,    4, TILE_PL64,  1},
+    { 302848,   128,   18, TILE_PL256x128,  1},
+    {1211392,    64,    2, TILE_PL64,  1},
+    {1211392,    64,    9, TILE_PL64,  1},
     {0, 0, 0, 0, 0},
 };
 
@@ -342,8 +382,10 @@ static void choose_pl(const ConvParams& c, long long M, int mode, int sk_max, in
         if (e->M == (int)M && e->CoutPad == c.CoutPad && e->nchunks == c.nchunks) { *tile = e->tile; *splits = e->splits; return; }
     // other shapes (batched runs): the 128x128 block once its grid covers the chip (half the operand bytes per FLOP of the
     // 64x64 block: profiles/r03_bench_pl_batch28.txt), else the 64x64 block with enough K slices to fill it
+    // (short K loops -- the 1x1 layers of the bottlenecks -- stay on the 64x64 block even then: a 128x128 block runs one per
+    // CU and its prologue / epilogue are not covered by a neighbour's K loop; profiles/r03_tune_pl_f16_batch28.txt)
     const long long tiles128 = ((M + 127) / 128) * ((c.CoutPad + 127) / 128);
-    int t = (c.CoutPad >= 128 && tiles128 >= 192) ? TILE_PL128 : TILE_PL64;
+    int t = (c.CoutPad >= 128 && tiles128 >= 192 && c.nchunks >= 32) ? TILE_PL128 : TILE_PL64;
     int s = 1;
     if (t == TILE_PL64) {
         const long long blocks = ((M + 63) / 64) * (c.CoutPad / 64);
@@ -482,6 +524,8 @@ int Net::add_conv(const std::string& name, const Tensor& in, const Tensor& out_v
     c.stamps = nullptr;
     c.w16 = nullptr; c.w16s = nullptr;
     c.in16 = nullptr; c.out16 = nullptr; c.wpl = nullptr; c.in16_plane = c.out16_plane = 0; c.out_np = 0; c.abl = 0; c.skip_f32 = 0;
+    c.pf_ptr = nullptr; c.xcd_map = 0; c.mtiles = c.n_tiles = c.work_blocks = c.pf_first = 0;
+    c.pf_pairs = c.pf_splits = c.pf_cps = c.pf_nchunks = c.pf_tile_stride = c.pf_chunk_bytes = c.pf_cap = 0;
     c.CoutPad = CoutPad;
     const double Kalg = (double)k * k * Cin;   // algorithmic K (the packing pad is not work)
     op.flops = 2.0 * OH * OW * (double)Cout * Kalg;
@@ -581,6 +625,15 @@ void Net::set_precision(int prec) {
             BP_HIP(hipDeviceSynchronize());
         }
     }
+#ifdef BP_EXPERIMENTAL   // timing experiment (wrong results): every layer reads ONE filter buffer, so the filters are always cache-resident
+    if (std::getenv("BP_ALIAS_WEIGHTS")) {
+        const unsigned short* big = nullptr; size_t big_n = 0;
+        for (Op& op : ops_)
+            if (op.type == OP_CONV && op.conv.w16s && (size_t)op.conv.CoutPad * op.conv.Kpad > big_n) { big_n = (size_t)op.conv.CoutPad * op.conv.Kpad; big = op.conv.w16s; }
+        for (Op& op : ops_)
+            if (op.type == OP_CONV && op.conv.w16s) op.conv.w16s = big;
+    }
+#endif
     plan_planes(plane_path ? prec : PREC_F32);
     for (Op& op : ops_)
         if (op.type == OP_CONV) op.conv.mfma_mode = (prec != PREC_F32 && (conv_h16_eligible(op.conv) || conv_pl_eligible(op.conv))) ? prec : PREC_F32;
@@ -684,6 +737,32 @@ void Net::plan_planes(int prec) {
 
 static int planes_np(int prec) { return prec == PREC_F16 ? 1 : 3; }
 
+// filter prefetch (ConvParams::pf_*): one extra block per (N-tile, K-slice) pair of the next launch pulls at most this much
+static int env_int(const char* name, int dflt) { const char* v = std::getenv(name); return v ? std::atoi(v) : dflt; }
+static const int kPrefetchCap = env_int("BP_PF_CAP_KB", 128) * 1024;
+// the XCD-matched block layout pays when the filters of a pair are worth sharing and there are pairs for all 8 XCDs
+int conv_xcd_map(const ConvParams& c, int tile, int splits) {
+    if (!(tile == TILE_64x64_BD || tile == TILE_PL64)) return 0;
+    if (conv_tile_is_pl(tile) && splits == 1) return 0;          // conv_pl's one-slice layout keeps neighbouring M-tiles on an XCD
+    return ((c.CoutPad + 63) / 64) * splits >= 8 ? 1 : 0;
+}
+
+// p's launch carries the prefetch blocks for `next` (launched with tile nt, ns K slices of nc chunks), when next's blocks
+// will be laid out by XCD (conv_xcd_map) and read a per-pair contiguous filter image
+void conv_prefetch_of(ConvParams& p, const ConvParams& next, int nt, int ns, int nc) {
+    p.pf_ptr = nullptr;
+    const bool pl = next.mfma_mode != PREC_F32 && conv_tile_is_pl(nt) && next.wpl;
+    const bool bd = nt == TILE_64x64_BD && next.mfma_mode == PREC_BF16X3 && next.w16s;
+    if (!(pl || bd) || !conv_xcd_map(next, nt, ns)) return;
+    const int np = planes_np(next.mfma_mode);
+    p.pf_ptr = pl ? (const void*)next.wpl : (const void*)next.w16s;
+    p.pf_splits = ns; p.pf_cps = nc; p.pf_nchunks = next.nchunks;
+    p.pf_pairs = ((next.CoutPad + 63) / 64) * ns;
+    p.pf_chunk_bytes = np * 4096;                  // 64 filter rows x 32 k x 2 B per plane
+    p.pf_tile_stride = next.nchunks * p.pf_chunk_bytes;
+    p.pf_cap = kPrefetchCap;
+}
+
 void Net::run_op(const Op& op, int batch, hipStream_t s) {
     switch (op.type) {
         case OP_CONV: {
@@ -703,6 +782,21 @@ void Net::run_op(const Op& op, int batch, hipStream_t s) {
                 int ord = 0;
                 for (const Op* q = ops_.data(); q != &op; ++q) ord += q->type == OP_CONV;
                 if ((long long)conv_tiles(p, tile) * splits <= stamp_slots_) p.stamps = stamps_ + ((size_t)ord * stamp_slots_) * 8;
+            }
+            // XCD-matched layout + prefetch of the next convolution's filters (set_prefetch; ConvParams::xcd_map / pf_*; a
+            // hint: a wrong guess about the next launch costs bandwidth, not correctness)
+            p.xcd_map = prefetch_ ? conv_xcd_map(p, tile, splits) : 0;
+            p.pf_ptr = nullptr;
+            if (prefetch_ && (tile == TILE_64x64_BD || conv_tile_is_pl(tile))) {
+                for (const Op* q = &op + 1; q != ops_.data() + ops_.size(); ++q) {
+                    if (q->type != OP_CONV) continue;
+                    ConvParams n = q->conv;
+                    n.N = batch; n.M = batch * n.OH * n.OW;
+                    int nt, ns, nc;
+                    choose_launch(*q, batch, force_tile_, sk_target_, sk_min_chunks_, sk_max_splits_, &nt, &ns, &nc);
+                    conv_prefetch_of(p, n, nt, ns, nc);
+                    break;
+                }
             }
             launch_conv(p, tile, s);
         } break;

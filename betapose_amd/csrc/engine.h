@@ -93,10 +93,14 @@ public:
     void set_precision(int prec);
     int precision() const { return precision_; }
     unsigned plan_version() const { return plan_version_; }
-    // in-situ timing: every convolution launch whose grid has at most `slots` blocks writes 8 u64 s_memtime marks per block
+    // in-situ timing: every convolution launch whose grid has at most `slots` blocks writes 8 u64 s_memrealtime (100 MHz) marks per block
     // (entry, index math done, -, K loop done, stores done, slab parked, slices combined, -) at d_buf + (conv ordinal * slots +
     // block) * 8; null switches it off.  Graphs must be re-captured (plan_version).
     void set_stamps(unsigned long long* d_buf, int slots) { stamps_ = d_buf; stamp_slots_ = slots; ++plan_version_; }
+    // XCD-matched block layout + prefetch of the next layer's filters (bp_common.h ConvParams::xcd_map / pf_*).  Off by
+    // default: it is a lone-frame latency feature (+3.4 % one frame at a time, -1 .. -2 % with two to four in flight)
+    void set_prefetch(bool on) { prefetch_ = on; ++plan_version_; }
+    bool prefetch() const { return prefetch_; }
     const char* op_name(int i) const { return ops_[i].name.c_str(); }
 
 protected:
@@ -135,6 +139,7 @@ protected:
     int precision_ = PREC_F32;
     unsigned long long* stamps_ = nullptr;
     int stamp_slots_ = 0;
+    bool prefetch_ = false;
     unsigned plan_version_ = 0;   // bumped whenever launches would change (captured graphs must be rebuilt)
 };
 

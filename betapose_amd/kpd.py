@@ -171,6 +171,11 @@ class FastPoseHIP:
             _lib.check(rc)
         return np.array(ms, dtype=np.float64), np.array(info, dtype=np.int64).reshape(n, 4)
 
+    def set_prefetch(self, on: bool = True):
+        """Lone-frame latency mode (include/betapose_hip.h bp_*_set_prefetch), see Darknet.set_prefetch."""
+        self._ensure()
+        _lib.check(_lib.lib().bp_kpd_set_prefetch(self._h, int(bool(on))))
+
     def set_stamps(self, buf=None, slots: int = 0):
         """In-situ conv timing (include/betapose_hip.h bp_*_set_stamps): ``buf`` a cuda int64 tensor of
         n_convs * slots * 8 elements, or None to switch it off."""

@@ -71,17 +71,50 @@ def results_to_json_list(all_results, for_eval=False):
     return out
 
 
+# The 'cmu' / 'open' layouts of the reference's write_json (pPose_nms.py:316-347): per image a dict with a version string and
+# a list of bodies / people, each a flat (x, y, score) list of 18 joints picked from the result's key-point list after
+# three derived values have been appended to it.  The picks are positions in the FLAT list (3 per key point): written for
+# 17 COCO joints (position 51 = the first appended value = a neck), they run unchanged on whatever key points there are.
+_BODY_LAYOUTS = {"cmu": ("Betapose v1.0", "bodies", "joints"), "open": ("Betapose v0.2", "people", "pose_keypoints_2d")}
+_BODY_PICKS = (0, 51, 18, 24, 30, 15, 21, 27, 36, 42, 48, 33, 39, 45, 6, 3, 12, 9)
+_BODY_MEANS = ((15, 18), (16, 19), (50, 20))       # appended values: means of these flat positions, in this order
+
+
+def body_layout_results(all_results, form, for_eval=False):
+    """{image_id: {"version": ..., "bodies" | "people": [{"joints" | "pose_keypoints_2d": [54 floats]}, ...]}}."""
+    version, list_key, joints_key = _BODY_LAYOUTS[form]
+    per_image = {}
+    for r in results_to_json_list(all_results, for_eval):
+        flat = list(r["keypoints"])
+        for a, b in _BODY_MEANS:          # each mean is appended before the next is taken, as the reference does
+            flat.append((flat[a] + flat[b]) / 2)
+        joints = [flat[i + d] for i in _BODY_PICKS for d in (0, 1, 2)]
+        entry = per_image.setdefault(r["image_id"], {"version": version, list_key: []})
+        entry[list_key].append({joints_key: joints})
+    return per_image
+
+
 def write_json(all_results, outputpath, for_eval=False, form=None):
-    """Default ('coco'-like list) format of the reference's write_json; the 'cmu'/'open' body-pose
-    re-mappings (pPose_nms.py:316-347) index 17/18 human joints and do not apply to 50 object key points."""
+    """pPose_nms.py:284-371: ``Betapose-results.json`` in the default list layout, or -- opt.format 'cmu' / 'open' -- the
+    per-image body layouts plus one file per image under ``sep-json/``."""
     if form is None:   # the reference reads opt.format (pPose_nms.py:287)
         from .opt import opt as _opt
         form = getattr(_opt, "format", None)
-    if form in ("cmu", "open"):
-        raise NotImplementedError("cmu/open formats are human-pose layouts; not used on the 6D path")
-    text = json.dumps(results_to_json_list(all_results, for_eval))
     path = os.path.join(outputpath, "Betapose-results.json")
-    with open(path, "w") as f:
-        f.write(text)
+    if form in _BODY_LAYOUTS:
+        if for_eval:   # the reference fails here too (pPose_nms.py:358: int image ids have no .split) -- same outcome, said clearly
+            raise AttributeError("write_json: the 'cmu' / 'open' layouts name their per-image files after the image name; "
+                                 "for_eval=True turns it into an int (the reference raises at pPose_nms.py:358)")
+        per_image = body_layout_results(all_results, form, for_eval)
+        with open(path, "w") as f:
+            f.write(json.dumps(per_image))
+        sep = os.path.join(outputpath, "sep-json")
+        os.makedirs(sep, exist_ok=True)
+        for name, entry in per_image.items():
+            with open(os.path.join(sep, str(name).split('.')[0] + ".json"), "w") as f:
+                f.write(json.dumps(entry))
+    else:
+        with open(path, "w") as f:
+            f.write(json.dumps(results_to_json_list(all_results, for_eval)))
     print("Results have been written to", path)
     return path

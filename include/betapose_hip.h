@@ -122,11 +122,17 @@ int bp_kpd_op_stats(const bp_kpd* k, double* flops, double* bytes, int cap);
  * Returns the number of ops (arrays may be NULL to query). */
 int bp_yolo_profile(bp_yolo* y, int batch, int iters, float* ms, int* info, int cap, void* stream);
 /* in-situ timing of the convolutions WHILE the pipeline runs (several frames in flight, graph replay): every conv launch
- * whose grid has at most `slots` blocks writes 8 u64 shader-clock marks per block (entry, index math done, -, K loop done,
+ * whose grid has at most `slots` blocks writes 8 u64 marks of the device-wide 100 MHz reference clock (s_memrealtime) per block (entry, index math done, -, K loop done,
  * stores done, slab parked, slices combined, -) at d_buf + (conv ordinal * slots + block) * 8.  NULL switches it off; a
  * captured pipeline graph is rebuilt on the next run.  op_name: the layer behind op i of bp_*_op_stats / bp_*_profile; returns 1 for a convolution, 0 for any other op, -1 on error. */
 /* how long `ticks` marks of the clock those stamps read take (one thread spinning on s_memtime between two events) */
 int bp_calibrate_ticks(long long ticks, float* ms, void* stream);
+/* lone-frame latency mode (off by default): lay the launches with >= 8 (N-tile, K-slice) pairs out by XCD and let every
+ * convolution launch carry blocks that pull the NEXT convolution's filters into the L2 of the XCD that will read them.
+ * +3.4 % frames/s with one frame at a time, a loss with two or more frames in flight (no idle CUs to spare);
+ * results are bit-identical either way.  A captured pipeline graph is rebuilt on the next run. */
+int bp_yolo_set_prefetch(bp_yolo* y, int on);
+int bp_kpd_set_prefetch(bp_kpd* k, int on);
 int bp_yolo_set_stamps(bp_yolo* y, unsigned long long* d_buf, int slots);
 int bp_kpd_set_stamps(bp_kpd* k, unsigned long long* d_buf, int slots);
 int bp_yolo_op_name(const bp_yolo* y, int i, char* out, int cap);

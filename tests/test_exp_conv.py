@@ -240,3 +240,20 @@ def test_conv_filters_direct_is_bit_identical_to_the_staged_kernel(cuda, case, s
     assert torch.equal(a1, a2)
 
 
+
+
+# ---- two round-3 forms of conv_pl.hip that were measured and left out of the product: K groups inside the
+# block (pl64k2: 8 waves, a ring per group, partial sums combined through LDS) and wave specialisation (pl128s: 4 loader waves)
+@pytest.mark.parametrize("tile,splits", [("pl64k2_b3", 1), ("pl64k2_b3", 3), ("pl64k2_f16", 1), ("pl64k2_f16", 2), ("pl128s_b3", 1), ("pl128s_f16", 1)])
+@pytest.mark.parametrize("shape", [(20, 16, 256, 256, 3), (26, 26, 128, 192, 1), (13, 13, 96, 128, 3)])
+def test_conv_pl_round3_experiments(cuda, tile, splits, shape):
+    H, W, Cin, Cout, k = shape
+    g = torch.Generator().manual_seed(5200 + H + Cout + splits)
+    x = torch.randn(1, H, W, Cin, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g)
+    out = ops.conv2d_nhwc(x.to(cuda), w, b, pad=k // 2, act="relu", tile=tile, splits=splits).cpu().permute(0, 3, 1, 2)
+    if tile.endswith("f16"):
+        _check(out, _ref(x.half().float(), w.half().float(), b, 1, k // 2, "relu", None, False))
+    else:
+        _check(out, _ref(x, w, b, 1, k // 2, "relu", None, False))

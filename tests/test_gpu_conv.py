@@ -159,8 +159,8 @@ def test_conv_pl_bf16x3_is_fp32_accurate(cuda, case, tile, splits):
     x = torch.randn(N, H, W, Cin, generator=g) * torch.exp(2 * torch.randn(N, H, W, 1, generator=g))   # wide dynamic range
     w = torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k)
     b = torch.randn(Cout, generator=g)
-    if splits > 1 and Cin * k * k // 32 < 2 * splits:
-        pytest.skip("too few K-chunks to split")
+    if splits > 1 and (Cin * k * k // 32 < 2 * splits):
+        pytest.skip("too few K-chunks to split / tile without K slices")
     OH, OW = (H + 2 * pad - k) // st + 1, (W + 2 * pad - k) // st + 1
     res = torch.randn(N, OH, OW, Cout, generator=g)
     for after in (False, True):
@@ -190,8 +190,8 @@ def test_conv_pl_f16_operands(cuda, case, tile, splits):
     x = torch.randn(N, H, W, Cin, generator=g)
     w = torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k)
     b = torch.randn(Cout, generator=g)
-    if splits > 1 and Cin * k * k // 32 < 2 * splits:
-        pytest.skip("too few K-chunks to split")
+    if splits > 1 and (Cin * k * k // 32 < 2 * splits):
+        pytest.skip("too few K-chunks to split / tile without K slices")
     OH, OW = (H + 2 * pad - k) // st + 1, (W + 2 * pad - k) // st + 1
     res = torch.randn(N, OH, OW, Cout, generator=g)
     ref16 = _ref(x.half().float(), w.half().float(), b, st, pad, act, res, False)
@@ -319,3 +319,24 @@ def test_conv_filters_direct_store_modes(cuda):
     b18 = torch.randn(18, generator=g)
     hd = ops.conv2d_nhwc(xd, w18, b18, tile="bd_b3").cpu().permute(0, 3, 1, 2)
     _check(hd, _ref(x, w18, b18, 1, 0, "linear", None, False))
+
+
+@pytest.mark.parametrize("tile", ["bd_b3", "pl64_b3", "pl64_f16"])
+@pytest.mark.parametrize("shape", [(20, 16, 256, 512, 1, 3), (13, 13, 128, 256, 3, 5), (10, 8, 512, 1024, 1, 1), (26, 26, 64, 192, 3, 4)])
+def test_conv_xcd_layout_and_prefetch_blocks(cuda, monkeypatch, tile, shape):
+    """Launches laid out by XCD (>= 8 (N-tile, K-slice) pairs: ConvParams::xcd_map, padded work grid) that also carry
+    prefetch blocks (here for their own filters): same bits as the plain launch of the same kernel."""
+    H, W, Cin, Cout, k, splits = shape
+    g = torch.Generator().manual_seed(4100 + H + Cout + splits)
+    x = torch.randn(1, H, W, Cin, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g)
+    kw = dict(pad=k // 2, act="leaky", tile=tile, splits=splits)
+    monkeypatch.delenv("BP_CONV_SELF_PREFETCH", raising=False)
+    plain = ops.conv2d_nhwc(x.to(cuda), w, b, **kw)
+    monkeypatch.setenv("BP_CONV_SELF_PREFETCH", "1")
+    with_pf = ops.conv2d_nhwc(x.to(cuda), w, b, **kw)
+    assert torch.equal(plain, with_pf)
+    ref = _ref(x, w, b, 1, k // 2, "leaky", None, False)
+    tol = 2e-2 if tile.endswith("f16") else 2e-5
+    _check(plain.cpu().permute(0, 3, 1, 2), ref, tol=tol * max(1.0, float(ref.abs().mean())))

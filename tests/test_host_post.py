@@ -107,15 +107,41 @@ def test_pose_nms_seeded_candidate_sets_match_reference():
     assert min(counts) == 1 and max(counts) >= 4
 
 
-def test_write_json_honours_opt_format(tmp_path):
-    """pPose_nms.py:287 reads opt.format; the human-pose layouts must fail loudly, not fall back to the default."""
+def test_write_json_layouts_equal_the_reference(tmp_path, golden_dir):
+    """pPose_nms.py:284-371 reads opt.format: the default list and the 'cmu' / 'open' per-image layouts (+ sep-json files)
+    against the files the reference's own write_json wrote for the same seeded results (tools/make_golden_json.py), text
+    for text; for_eval=True with a body layout fails, as in the reference."""
+    import os
+    import torch
     from betapose_amd import pPose_nms
     from betapose_amd.opt import opt
+    g = np.load(os.path.join(golden_dir, "json_formats.npz"))
+    results, n = [], 0
+    for i, name in enumerate(g["names"]):
+        humans = []
+        for _ in range(int(g["per_image"][i])):
+            humans.append({"keypoints": torch.from_numpy(g["kp"][n]), "kp_score": torch.from_numpy(g["sc"][n]),
+                           "proposal_score": torch.tensor([float(g["prop"][n])])})
+            n += 1
+        results.append({"imgname": "some/dir/" + str(name), "result": humans, "cam_R": g["R"][i] if i != 1 else [],
+                        "cam_t": g["t"][i] if i != 1 else []})
     old = getattr(opt, "format", None)
     try:
+        for form in (None, "cmu", "open"):
+            for for_eval in ((False, True) if form is None else (False,)):
+                opt.format = form
+                d = tmp_path / ("%s_%d" % (form, for_eval))
+                d.mkdir()
+                pPose_nms.write_json(results, str(d), for_eval=for_eval)
+                key = "%s_%d" % (form or "default", int(for_eval))
+                assert (d / "Betapose-results.json").read_text() == str(g["main_" + key])
+                if form:
+                    assert sorted(os.listdir(d / "sep-json")) == list(g["sepnames_" + key])
+                    for nm, txt in zip(g["sepnames_" + key], g["sep_" + key]):
+                        assert (d / "sep-json" / str(nm)).read_text() == str(txt)
         opt.format = "cmu"
-        with pytest.raises(NotImplementedError):
-            pPose_nms.write_json([], str(tmp_path))
+        with pytest.raises(AttributeError):
+            pPose_nms.write_json(results, str(tmp_path), for_eval=True)
         opt.format = old
         pPose_nms.write_json([], str(tmp_path))
         assert (tmp_path / "Betapose-results.json").read_text() == "[]"

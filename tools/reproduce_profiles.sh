@@ -1,54 +1,94 @@
 #!/bin/bash
 # Regenerates everything under profiles/ for one round on an MI355X box (writes into gpurun_out/, copy what you keep).
-#   tools/reproduce_profiles.sh [round tag, default r02]
-# Each block is independent; PMC passes are separate rocprofv3 runs with --kernel-trace only.
+#   tools/reproduce_profiles.sh [round tag, default r03] [blocks, default "1 2 3 4 5 6"]
+# Each block is independent; PMC passes are separate rocprofv3 runs with --kernel-trace only.  The experimental library
+# (python -m betapose_amd.build --experimental) is needed by block 5 (A/B against the round-2 data path).
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
+BLOCKS=${2:-"1 2 3 4 5 6"}
 REPO="$(cd "$(dirname "$0")/.." && pwd)"
 OUT=$REPO/gpurun_out
+EXP=$REPO/betapose_amd/libbetapose_hip_exp.so
 mkdir -p "$OUT"
 cd $REPO
+has() { [[ " $BLOCKS " == *" $1 "* ]]; }
+line() { python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(sys.argv[1], "frames/s", d["value"], "ms/step", d["ms_per_step"])' "$1"; }
+quick() { tag=$1; shift; python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-roofline --other-modes , --no-side-runs --repeats 1 "$@" 2>/dev/null | tail -1 | line "$tag"; }
 
-# 1. headline bench line (+ other_precisions, roofline, latency, h2d_inclusive, cpu_baseline) and the other modes alone
-python bench.py                                   > $OUT/${TAG}_bench_default.json 2>/dev/null
-python bench.py --precision f32 --no-cpu-baseline --other-modes "" > $OUT/${TAG}_bench_f32.json 2>/dev/null
-python bench.py --precision f16 --no-cpu-baseline --other-modes "" > $OUT/${TAG}_bench_f16.json 2>/dev/null
+if has 1; then
+# 1. headline bench line (+ repeats, other_precisions, roofline with hbm / layer classes / in-situ layer table, latency,
+#    h2d_inclusive, cpu_baseline) and the other modes alone; batched and stream-count sweeps
+python bench.py --insitu $OUT/${TAG}_insitu_layer_times.txt > $OUT/${TAG}_bench_default.json 2>/dev/null
+python bench.py --precision f32 --no-cpu-baseline --other-modes , > $OUT/${TAG}_bench_f32.json 2>/dev/null
+python bench.py --precision f16 --no-cpu-baseline --other-modes , --insitu $OUT/${TAG}_insitu_layer_times_f16.txt > $OUT/${TAG}_bench_f16.json 2>/dev/null
 for cfg in "bf16x3 28 2" "f16 28 3" "f32 28 2" "bf16x3 2 4" "bf16x3 4 3"; do set -- $cfg
-  python bench.py --precision $1 --batch $2 --streams $3 --steps 60 --warmup 6 --no-cpu-baseline --other-modes "" --no-roofline --no-side-runs 2>/dev/null
+  python bench.py --precision $1 --batch $2 --streams $3 --steps 60 --warmup 6 --no-cpu-baseline --other-modes , --no-roofline --no-side-runs --repeats 3 2>/dev/null
 done > $OUT/${TAG}_bench_batched.jsonl
 for st in 1 2 3 4 5 6 8; do
-  python bench.py --streams $st --steps 300 --warmup 20 --no-cpu-baseline --other-modes "" --no-roofline --no-side-runs 2>/dev/null
+  python bench.py --streams $st --steps 300 --warmup 20 --no-cpu-baseline --other-modes , --no-roofline --no-side-runs --repeats 1 2>/dev/null
 done > $OUT/${TAG}_bench_streams.jsonl
+fi
 
-# 2. rocprofv3 kernel statistics of the default command (kernels are serialised under the profiler: compare AverageNs
-#    of the dominant conv kernel with roofline.isolated.avg_launch_us, not the frames/s)
+if has 2; then
+# 2. rocprofv3 kernel statistics of the default command (the tracer serialises the streams: AverageNs of the dominant conv
+#    kernel = its isolated duration, compare with roofline.isolated.avg_launch_us, not the frames/s)
 tools/trace_headline.sh $TAG > /dev/null
+fi
 
-# 3. HBM-side traffic: the dominant kernel per launch, and one whole frame (FETCH_SIZE / WRITE_SIZE, two passes each)
+if has 3; then
+# 3. HBM-side traffic (FETCH_SIZE / WRITE_SIZE, two passes each): the dominant kernel per launch in the bf16x3 and fp16
+#    modes, one whole frame; matrix-pipe occupancy; wave stall breakdown
 tools/pmc_traffic.sh && cp $OUT/pmc_traffic.json $OUT/${TAG}_pmc_traffic.json
+BP_PMC_KERNEL=conv_pl tools/pmc_traffic.sh --precision f16 && cp $OUT/pmc_traffic.json $OUT/${TAG}_pmc_traffic_f16.json
 tools/pmc_traffic.sh --precision f32 && cp $OUT/pmc_traffic.json $OUT/${TAG}_pmc_traffic_f32.json
 tools/pmc_frame_traffic.sh 1 > $OUT/${TAG}_pmc_frame_traffic.json
+tools/pmc_frame_traffic.sh 1 --precision f16 > $OUT/${TAG}_pmc_frame_traffic_f16.json
 tools/pmc_mfma_busy.sh > /dev/null && cp $OUT/pmc_mfma_busy.json $OUT/${TAG}_pmc_mfma_busy.json
+tools/pmc_mfma_busy.sh --precision f16 --batch 28 --steps 3 --warmup 1 > /dev/null && cp $OUT/pmc_mfma_busy.json $OUT/${TAG}_pmc_mfma_busy_f16_batch28.json
 tools/pmc_wave_stalls.sh > /dev/null && cp $OUT/pmc_wave_stalls.json $OUT/${TAG}_pmc_wave_stalls.json
+fi
 
-# 4. per-shape kernel / slice tuning tables (engine.cpp embeds the winners), per-op times
-python tools/tune_conv.py            > $OUT/${TAG}_tune_b3.txt          2>&1
-python tools/tune_conv.py --kg       > $OUT/${TAG}_tune_b3_kernels.txt  2>&1   # 64x64 / filters-direct / K-group / register-direct
-python tools/tune_conv.py --f16      > $OUT/${TAG}_tune_f16.txt         2>&1
-python tools/tune_conv.py --fp32     > $OUT/${TAG}_tune_f32.txt         2>&1
-python tools/tune_conv.py --batch 4  > $OUT/${TAG}_tune_b3_batch4.txt   2>&1
-python tools/tune_conv.py --batch 28 > $OUT/${TAG}_tune_b3_batch28.txt  2>&1
-python tools/tune_conv.py --f16 --batch 28 > $OUT/${TAG}_tune_f16_batch28.txt 2>&1
+if has 4; then
+# 4. per-shape kernel / slice tuning tables (engine.cpp embeds the winners), kernel-against-kernel timings, per-op times
+python tools/tune_conv.py --pl              > $OUT/${TAG}_tune_pl_b3.txt          2>&1   # plane path, bf16x3 (BP_B3_PLANES)
+python tools/tune_conv.py --pl --f16        > $OUT/${TAG}_tune_pl_f16.txt         2>&1
+python tools/tune_conv.py --pl --f16 --big --batch 28 > $OUT/${TAG}_tune_pl_f16_batch28.txt 2>&1
+for m in f16 b3; do
+  python tools/bench_pl.py --batch 28 --mode $m --splits 1 --only y3x3 --tiles pl64,pl128x64,pl128,pl256x128 --engine-like 2>&1 | grep -v amdgpu.ids
+done > $OUT/${TAG}_bench_pl_batch28.txt
+python tools/bench_pl.py --batch 1 --mode b3 --tiles bd,pl64 --engine-like 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_bench_pl_batch1.txt
 python tools/profile_ops.py                 > $OUT/${TAG}_per_op_times.txt     2>/dev/null
-python tools/profile_ops.py --precision f32 > $OUT/${TAG}_per_op_times_f32.txt 2>/dev/null
+python tools/profile_ops.py --precision f16 > $OUT/${TAG}_per_op_times_f16.txt 2>/dev/null
+python tools/profile_ops.py --precision f16 --batch 28 > $OUT/${TAG}_per_op_times_f16_batch28.txt 2>/dev/null
+tools/micro/run_dma_bw.sh 2>/dev/null | grep "B/clk" > $OUT/${TAG}_dma_bw.txt
+fi
 
-# 5. determinism soak (bit-identical records over 4000 frames under 4-stream load, every precision)
+if has 5; then
+# 5. A/B of the whole pipeline on ONE box: the product, the bf16x3 mode forced onto the operand-plane path, and the round-2
+#    data path in every mode (experimental library, BP_LEGACY=1)
+{
+for r in 1 2 3; do
+  quick "product bf16x3 (fp32 activations, filters-direct kernel)"
+  BP_B3_PLANES=1 quick "bf16x3 on the operand-plane path (BP_B3_PLANES=1)"
+  [ -f $EXP ] && BP_LIB=$EXP BP_LEGACY=1 quick "round-2 kernels, bf16x3 (experimental library)"
+done
+quick "product fp16 (operand-plane path)" --precision f16
+[ -f $EXP ] && BP_LIB=$EXP BP_LEGACY=1 quick "round-2 kernels, fp16" --precision f16
+quick "product fp16, batch 28 x 3 streams" --precision f16 --batch 28 --streams 3 --steps 30
+[ -f $EXP ] && BP_LIB=$EXP BP_LEGACY=1 quick "round-2 kernels, fp16, batch 28 x 3 streams" --precision f16 --batch 28 --streams 3 --steps 30
+quick "product bf16x3, batch 28 x 2 streams" --batch 28 --streams 2 --steps 30
+BP_B3_PLANES=1 quick "bf16x3 on the plane path, batch 28 x 2 streams" --batch 28 --streams 2 --steps 30
+quick "product bf16x3, one frame at a time" --streams 1
+BP_B3_PLANES=1 quick "bf16x3 on the plane path, one frame at a time" --streams 1
+BP_KEEP_F32=1 quick "product fp16, fp32 stores kept everywhere (BP_KEEP_F32=1)" --precision f16
+} > $OUT/${TAG}_ab_pipeline.txt
+fi
+
+if has 6; then
+# 6. determinism soak (bit-identical records over 4000 frames under 4-stream load, every precision), BASELINE configs[4]
+#    (eight resident objects, (frame, object) units), files-on-disk harness
 for pr in bf16x3 f32 f16; do python tools/soak_determinism.py --iters 4000 --precision $pr; done > $OUT/${TAG}_soak.txt 2>/dev/null
-
-# 6. what bounds the batch-1 pipeline: parts of the conv kernels compiled out (timing only), the launch-chain floor,
-#    BASELINE configs[4] (eight resident objects, (frame, object) units) against eight single-object runs
-bash tools/ablate_pipeline.sh > /dev/null && cp $OUT/ablate_pipeline.txt $OUT/${TAG}_ablate_pipeline.txt
-python tools/launch_floor.py 202 > $OUT/${TAG}_launch_floor.txt 2>/dev/null
 python tools/occlusion_scale.py --frames 384 > $OUT/${TAG}_occlusion_8obj.txt 2>&1
 for b in 1 2 4; do python evaluate.py --synthetic 768 --outdir /tmp/ev --fused --streams 4 --detbatch $b 2>&1 | grep frames/sec; done > $OUT/${TAG}_evaluate_fused.txt
+fi
 ls -la $OUT | tail -40

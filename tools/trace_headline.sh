@@ -1,6 +1,8 @@
 #!/bin/bash
-# rocprofv3 kernel trace (+ stats) of the HEADLINE configuration (default bench: bf16x3, 4 frames in flight), not
-# serialised: per-kernel durations as they are with four graphs overlapping, and how busy the device is.
+# rocprofv3 kernel trace (+ stats) of the HEADLINE configuration (default bench: bf16x3, 4 frames in flight).  The tracer
+# SERIALISES the four streams (mean concurrency ~1, frames/s roughly halved): read the per-kernel AverageNs as ISOLATED
+# durations (they agree with roofline.isolated of bench.py); durations with the frames overlapping come from the kernels' own
+# s_memtime stamps (bench.py --insitu -> profiles/r03_insitu_layer_times.txt).
 #   tools/trace_headline.sh [round tag]   -> gpurun_out/<tag>_bench_kernel_stats.csv, <tag>_bench_trace_summary.json
 TAG=${1:-r02}
 REPO="$(cd "$(dirname "$0")/.." && pwd)"
@@ -8,7 +10,7 @@ OUT=$REPO/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/trace_headline
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_headline -o p -- \
-    python $REPO/bench.py --steps 200 --warmup 20 --no-cpu-baseline --other-modes "" --no-roofline --no-side-runs > $OUT/${TAG}_bench_under_rocprof.json 2>/dev/null
+    python $REPO/bench.py --steps 200 --warmup 20 --no-cpu-baseline --other-modes "" --no-roofline --no-side-runs --repeats 1 > $OUT/${TAG}_bench_under_rocprof.json 2>/dev/null
 cp $OUT/trace_headline/p_kernel_stats.csv $OUT/${TAG}_bench_kernel_stats.csv
 python - <<PY
 import csv, json

@@ -53,10 +53,10 @@ if "--kg" in sys.argv:             # batch-1 candidates only: the 64x64-block ke
     TILES = ["64x64_b3", "bd_b3", "kg2_b3", "rd4_b3"]
 PL = "--pl" in sys.argv            # the operand-plane kernels (conv_pl.hip), the product's 16-bit kernels
 if PL:
-    TILES = [t + SUF for t in (["pl64", "pl128x64"] + (["pl128", "pl256x128"] if "--big" in sys.argv else []))]
+    TILES = [t + SUF for t in (["pl64", "pl128x64"] + (["pl128", "pl256x128", "pl128s"] if "--big" in sys.argv else []))]
 ENGINE_LIKE = PL                   # residual after the activation + operand planes emitted, as most layers of the networks run
-TILE_ID = {"pl64": 13, "pl128": 14, "pl128x64": 15, "pl256x128": 16, "64x64": 0, "128x64": 1, "w1x1": 2, "w1x2": 3, "w2x1": 5, "w2x2": 6, "kg1": 7, "kg2": 8, "kg4": 9, "rd4": 10, "rd8": 11, "bd": 12}
-BMN = {"pl64": (64, 64), "pl128": (128, 128), "pl128x64": (128, 64), "pl256x128": (256, 128), "64x64": (64, 64), "128x64": (128, 64), "w1x1": (64, 64), "w1x2": (64, 128), "w2x1": (128, 64), "w2x2": (128, 128),
+TILE_ID = {"pl64": 13, "pl128": 14, "pl128x64": 15, "pl256x128": 16, "pl128s": 17, "pl64k2": 18, "64x64": 0, "128x64": 1, "w1x1": 2, "w1x2": 3, "w2x1": 5, "w2x2": 6, "kg1": 7, "kg2": 8, "kg4": 9, "rd4": 10, "rd8": 11, "bd": 12}
+BMN = {"pl64": (64, 64), "pl128": (128, 128), "pl128x64": (128, 64), "pl256x128": (256, 128), "pl128s": (128, 128), "pl64k2": (64, 64), "64x64": (64, 64), "128x64": (128, 64), "w1x1": (64, 64), "w1x2": (64, 128), "w2x1": (128, 64), "w2x2": (128, 128),
        "kg1": (64, 64), "kg2": (64, 64), "kg4": (64, 64), "rd4": (64, 64), "rd8": (64, 64), "bd": (64, 64)}
 BATCH = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else 1
 dev = torch.device("cuda:0")
@@ -80,6 +80,8 @@ for (h, w_, cin, co, k, st), cnt in sorted(shapes.items()):
         tiles = -(-M // bm) * -(-cpad // bn)
         tb = (1e9, None)
         for sp in (1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 24):
+            if sp > 1 and base == "pl128s":
+                continue                   # (the wave-specialised tile takes no K slices)
             if sp > 1 and (nch // sp < 2 or tiles * sp > 1400 or BATCH > 4):
                 continue
             kw = dict(res=res, res_after_act=True, planes=True) if ENGINE_LIKE else {}
