@@ -182,6 +182,47 @@ def reference_darknet_c(frames, blocks, threads):
             "sample": "%d frames, network_predict_image + get_network_boxes of the reference's Darknet-C (AVX2, OpenMP)" % len(xs)}
 
 
+class ClockSampler:
+    """Shader clock and package power WHILE the timed regions run (a thread polling `rocm-smi --showclocks --showpower`):
+    with several frames in flight this pipeline runs into the package power limit and the shader clock drops below its
+    2.4 GHz ceiling -- frames/s then follow the clock, not the kernels' latency."""
+
+    def __init__(self, period=0.5):
+        import threading
+        self.period, self.samples, self._stop = period, [], threading.Event()
+        self._t = threading.Thread(target=self._loop, daemon=True)
+
+    def _loop(self):
+        import re
+        import subprocess
+        while not self._stop.is_set():
+            try:
+                out = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=5).stdout
+                m1 = re.search(r"GPU\[0\]\s*:\s*sclk clock level[^(]*\((\d+)Mhz\)", out)
+                m2 = re.search(r"GPU\[0\]\s*:[^\n]*Power \(W\):\s*([0-9.]+)", out)
+                if m1 and m2:
+                    self.samples.append((int(m1.group(1)), float(m2.group(1))))
+            except Exception:
+                pass
+            self._stop.wait(self.period)
+
+    def __enter__(self):
+        self._t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._t.join(timeout=6)
+
+    def summary(self):
+        busy = [x for x in self.samples if x[1] > 400.0] or self.samples       # samples taken while the pipeline was loaded
+        if not busy:
+            return None
+        clk, pw = sorted(x[0] for x in busy), sorted(x[1] for x in busy)
+        return {"sclk_MHz_p50": clk[len(clk) // 2], "sclk_MHz_min": clk[0], "package_W_p50": pw[len(pw) // 2], "package_W_max": pw[-1],
+                "samples": len(busy), "source": "rocm-smi --showclocks --showpower, polled during the timed regions (GPU 0)"}
+
+
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -378,6 +419,14 @@ def insitu_layers(dets, poses, run, S, batch, path, precision):
             spans.append((int(entry.min()), int(last.max())))
         net.set_stamps(None, 0)
     us = lambda t: t / ghz / 1e3
+    # where every stream's last frame was in time: first stamped entry of its YOLO and the last mark of its KPD
+    phase = {}
+    for k, tag, c, nm, nb, r in rows:
+        if r is not None:
+            ph = phase.setdefault(k, [r[0], r[1]])
+            ph[0], ph[1] = min(ph[0], r[0]), max(ph[1], r[1])
+    t_first = min(v[0] for v in phase.values()) if phase else 0
+    stream_phase = {str(k): {"start_us": round(us(v[0] - t_first), 1), "frame_us": round(us(v[1] - v[0]), 1)} for k, v in sorted(phase.items())}
     # layers in flight at once over the stamped window (the last frame of each stream): sum of spans / union of spans
     ev = sorted([(s0, 1) for s0, _ in spans] + [(s1, -1) for _, s1 in spans])
     busy = depth = 0
@@ -405,7 +454,7 @@ def insitu_layers(dets, poses, run, S, batch, path, precision):
         v["span_us"] = round(v["span_us"] / S, 1)
         v["kloop_us"] = round(v["kloop_us"] / S, 1)
     summary = {"frames_in_flight": S, "stamp_clock_GHz": round(ghz, 3), "mean_layers_in_flight": round(conc, 2),
-               "per_class_us_per_frame": per_class, "table": os.path.relpath(path, ROOT) if path.startswith(ROOT) else path,
+               "per_class_us_per_frame": per_class, "last_frame_of_each_stream": stream_phase, "table": os.path.relpath(path, ROOT) if path.startswith(ROOT) else path,
                "fps_while_stamping": round(n * batch / (wall_ms * 1e-3), 1)}
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     with open(path, "w") as f:
@@ -584,6 +633,17 @@ def main():
         side["single"]["without_filter_prefetch"] = one_at_a_time(a.prefetch)
         if a.prefetch:
             side["single"].pop("without_filter_prefetch")
+        # shader clock and package power under this pipeline's load: ~4 s of the same multi-frame run, sampled
+        with ClockSampler() as cs:
+            t_c = time.perf_counter()
+            n_c = 0
+            while time.perf_counter() - t_c < 4.0:
+                run(max(4 * S, 50), False)
+                n_c += max(4 * S, 50)
+            torch.cuda.synchronize()
+            t_c = time.perf_counter() - t_c
+        if cs.summary():
+            side["clocks"] = dict(cs.summary(), frames_per_sec_meanwhile=round(n_c * a.batch / t_c, 1))
         src["pool"] = pool_host
         n2 = min(a.steps, 200)
         run(2 * S, False)
@@ -621,6 +681,7 @@ def main():
                            "p95": round(float(np.percentile(lat_flight, 95)), 4),
                            "definition": "frame handed to the stream -> its record (post-processing input) on the host",
                            **({"one_frame_at_a_time": side["single"]} if "single" in side else {})},
+            **({"clocks_under_load": side["clocks"]} if "clocks" in side else {}),
             "repeats": {"regions": len(region_fps), "steps_each": a.steps, "fps": [round(v, 2) for v in region_fps],
                         "p50": round(float(np.percentile(region_fps, 50)), 2), "min": round(min(region_fps), 2),
                         "max": round(max(region_fps), 2), "note": "`value` is region 0"},

@@ -86,23 +86,29 @@ struct ConvParams {
     int skip_f32;                 // 1: every reader of `out` takes the planes -- the fp32 store is dropped (engine.cpp plan_planes)
     int abl;                      // timing ablations, experimental builds only (-DBP_EXPERIMENTAL; tools/abl_pl.sh): 0 in the product
     const unsigned short* wpl;    // filters as conv_pl.hip's LDS image: [CoutPad/64][nchunks][plane][64 rows][64 B swizzled]
-    // Filter prefetch for the NEXT convolution on the stream (engine.cpp run_op; conv_dev.h prefetch_block): the launch carries
-    // pf_blocks extra blocks past its work grid that pull pf_bytes of the next layer's filters toward the caches while this
-    // layer computes.  At batch 1 every layer's filters come cold from HBM (730 MB per frame do not stay in the 256 MB MALL),
-    // pulled by the few blocks that need them at 17-22 B/clk/CU where a cache hit delivers 27-60 (tools/micro/cold_fetch.hip).
-    // Both follow the XCD the hardware puts a block on (block b -> XCD b % 8, each XCD with its own 4 MB L2):
-    //  * xcd_map: the work grid is laid out so that ALL M-tiles of a (N-tile, K-slice) pair q run on XCD q % 8 -- its
-    //    filters are fetched into ONE L2, once, instead of by MT blocks on MT XCDs (used when there are >= 8 pairs);
-    //  * the prefetch block for pair q of the next layer runs on XCD q % 8 as well and pulls the head of that pair's filter
-    //    range, so the work blocks find it in their own L2 (46-60 B/clk/CU against 17-22 cold: tools/micro/cold_fetch.hip).
-    int xcd_map;                  // 1: block b -> XCD x = b % 8, i = b / 8: pair (i / mtiles) * 8 + x, M-tile i % mtiles
+    // ---- launch layout by XCD (the hardware puts block b of a 1-D grid on XCD (b + c) % 8, every XCD with its own 4 MB L2;
+    // tools/micro/xcc_map.hip: one c per queue, also with four streams in flight)
+    //  * xcd_home (split-K launches): ALL K slices of an output tile run on ONE XCD (tile t on the XCD of block residue
+    //    t % 8), so the slab hand-off never leaves that XCD's L2: workgroup-scope (sc0) slab stores and loads, an L2-local
+    //    ticket -- instead of write-through to the memory side and back (conv_tail.inc).  Correctness then rests on the
+    //    round-robin dispatch.  It is CHECKED in every launch: each slice publishes its XCC_ID (agent scope, xcc_of), the
+    //    reducing block compares them with its own before it stores anything and TRAPS on a mismatch (the stream fails).
+    //  * filter prefetch for the NEXT convolution on the stream (lone-frame latency mode, Net::set_prefetch): the launch
+    //    carries extra blocks past its work grid that pull the head of the next layer's filters into the L2 of the XCD whose
+    //    blocks will read them, while this layer computes.  At batch 1 every layer's filters come cold from HBM (730 MB per
+    //    frame do not stay in the 256 MB MALL), pulled by the few blocks that need them at 17-22 B/clk/CU where an L2 hit
+    //    delivers 46-60 (tools/micro/cold_fetch.hip).  Under both layouts used here (xcd_home, and the plain one-slice grid
+    //    of the 64x64 filters-direct kernel) the blocks of residue x read the N-tiles n == x (mod g), g = min(N-tiles, 8).
+    int xcd_home;                 // 1: block b -> x = b % 8, i = b / 8: tile (i / splits) * 8 + x, K slice i % splits
+    int* xcc_of;                  // [tiles][64] XCC_ID of every K slice of the running launch
+    int* tickets_local;           // [tiles] arrival counters of the xcd_home launches (touched by L2-local atomics only)
     int mtiles, n_tiles;          // M-tiles, output tiles of the launch (set by the launchers)
     int work_blocks;              // blocks of the work grid incl. padding (set by the launchers; 0 = the whole grid)
     const void* pf_ptr;           // next layer's filters (nullptr: no prefetch blocks)
     int pf_first;                 // first prefetch block (work_blocks rounded up to 8, set by the launchers)
-    int pf_pairs, pf_splits, pf_cps, pf_nchunks;   // the next launch: pairs, K slices, chunks per slice, chunks
+    int pf_ntn, pf_splits, pf_cps, pf_nchunks;     // the next launch: N-tiles (a power of two), K slices, chunks per slice, chunks
     int pf_tile_stride, pf_chunk_bytes;            // its filter layout: bytes per N-tile and per 32-k chunk (contiguous per pair)
-    int pf_cap;                   // bytes pulled per pair at most
+    int pf_cap;                   // bytes pulled per (N-tile, K-slice) pair at most
 };
 
 // tile configuration ids for launch_conv
@@ -151,9 +157,10 @@ void launch_f32_to_planes(const float* in, int ld, long long pixels, int C, unsi
 void launch_planes_to_f32(const unsigned short* planes, long long plane_elems, int np, float* out, int ld, long long pixels, int C,
                           hipStream_t s);
 int conv_tiles(const ConvParams& p, int tile);   // blocks per K-slice
-void conv_grid_setup(ConvParams& q, int bm, int bn);   // fills mtiles / n_tiles / work_blocks / pf_first from M, CoutPad, splits, xcd_map
+void conv_grid_setup(ConvParams& q, int bm, int bn);   // fills mtiles / n_tiles / work_blocks / pf_first from M, CoutPad, splits, xcd_home
 int conv_grid_blocks(const ConvParams& q);
-int conv_xcd_map(const ConvParams& c, int tile, int splits);   // engine.cpp: 1 when the launch is laid out by XCD
+int xcc_base();                                                // engine.cpp: XCC_ID of block 0 (round-robin dispatch), -1: unusable
+bool conv_home_layout(int tile, int splits);                   // engine.cpp: the launch keeps all K slices of a tile on one XCD
 void conv_prefetch_of(ConvParams& p, const ConvParams& next, int next_tile, int next_splits, int next_cps);   // engine.cpp              // work blocks + padding + prefetch blocks
 int conv_tile_bm(int tile);
 int conv_tile_bn(int tile);

@@ -540,13 +540,16 @@ int bp_conv2d_planes(const float* d_in, int N, int H, int W, int Cin, const floa
     if (sp > 1) {
         const int tiles = bp::conv_tiles(p, t);
         p.partial = net.arena_.alloc((size_t)sp * tiles * bp::conv_tile_bm(t) * bp::conv_tile_bn(t));
-        p.tickets = (int*)net.arena_.alloc_bytes((size_t)tiles * sizeof(int));
-        BP_HIP(hipMemset(p.tickets, 0, (size_t)tiles * sizeof(int)));
+        p.tickets = (int*)net.arena_.alloc_bytes((size_t)(2 + 64) * tiles * sizeof(int));
+        BP_HIP(hipMemset(p.tickets, 0, (size_t)(2 + 64) * tiles * sizeof(int)));
     }
-    if (std::getenv("BP_CONV_SELF_PREFETCH")) {   // (tests: the launch is laid out by XCD and carries prefetch blocks, for its own filters)
-        p.xcd_map = bp::conv_xcd_map(p, t, sp);
-        bp::conv_prefetch_of(p, p, t, sp, per);
+    if (bp::conv_home_layout(t, sp)) {   // as the engine launches it: all K slices of a tile on one XCD, hand-off through that XCD's L2
+        const int tiles = bp::conv_tiles(p, t);
+        p.xcd_home = 1;
+        p.tickets_local = p.tickets + tiles;
+        p.xcc_of = p.tickets + 2 * tiles;
     }
+    if (std::getenv("BP_CONV_SELF_PREFETCH")) bp::conv_prefetch_of(p, p, t, sp, per);   // (tests: the launch carries prefetch blocks, for its own filters)
     bp::launch_conv(p, t, s);
     BP_HIP(hipStreamSynchronize(s));
     if (const char* e = std::getenv("BP_CONV_STAMPS")) {   // debug: per-block s_memtime marks of one extra launch

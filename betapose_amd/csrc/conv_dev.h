@@ -75,6 +75,26 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds, un
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)lds, 16, (int)voff, soff, 0, 0);
 }
 
+// xcd_home launches keep their split-K hand-off inside one XCD's L2: the block must really sit on the XCD its index says
+// (round-robin dispatch).  A violation would mean partial sums read from the wrong L2 -- silently wrong numbers -- so it
+// aborts the launch instead (the host sees a failed stream).
+__device__ __forceinline__ int xcc_id() {
+    unsigned id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+    return (int)(id & 15);
+}
+// at block start: publish this slice's XCD (a write-through store nobody waits for; it is acknowledged before the block's
+// ticket, which follows an s_waitcnt vmcnt(0))
+__device__ __forceinline__ void xcd_home_mark(const ConvParams& p, int tile_id, int split) {
+    if (threadIdx.x == 0) __hip_atomic_store(&p.xcc_of[tile_id * 64 + split], xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// in the reducing block: every slice of the tile must have run on this block's XCD
+__device__ __forceinline__ void xcd_home_verify(const ConvParams& p, int tile_id) {
+    if ((int)threadIdx.x < p.splits &&
+        __hip_atomic_load(&p.xcc_of[tile_id * 64 + (int)threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != xcc_id())
+        __builtin_trap();
+}
+
 // A block past the work grid (ConvParams::pf_*): pull its share of the next layer's filters through the memory hierarchy.
 // The bytes are dropped into 1 KB of LDS per wave (LDS-DMA: no registers, nothing for the compiler to discard); the wave
 // ends when they have arrived.
@@ -82,9 +102,13 @@ template <int NT>
 __device__ __forceinline__ void prefetch_block(const ConvParams& p, char* lds) {
     const int e = (int)blockIdx.x - p.pf_first;
     if (e < 0) return;                                   // padding between the work grid and the first prefetch block
-    const int q = (e >> 3) * 8 + ((int)blockIdx.x & 7);  // pf_first is a multiple of 8: this block sits on XCD q % 8
-    if (q >= p.pf_pairs) return;
-    const int tile_n = q / p.pf_splits, split = q - tile_n * p.pf_splits;
+    // pf_first is a multiple of 8: this block sits on the XCD of residue x, whose work blocks of the next launch read the
+    // N-tiles n == x (mod g); it takes the ql-th (N-tile, K-slice) pair of those
+    const int x = (int)blockIdx.x & 7, ql = e >> 3;
+    const int g = p.pf_ntn < 8 ? p.pf_ntn : 8;
+    if (ql >= (p.pf_ntn / g) * p.pf_splits) return;
+    const int j = ql / p.pf_splits, split = ql - j * p.pf_splits;
+    const int tile_n = (x & (g - 1)) + g * j;
     const int c0 = split * p.pf_cps, c1 = min(p.pf_nchunks, c0 + p.pf_cps);
     if (c1 <= c0) return;
     const long long beg = (long long)tile_n * p.pf_tile_stride + (long long)c0 * p.pf_chunk_bytes;

@@ -351,13 +351,14 @@ __global__ __launch_bounds__(256) void conv_igemm_h_kernel(const ConvParams p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int n_tiles_n = p.CoutPad / BN;
     int split, tile_n, tile_m;
-    if (p.xcd_map) {   // all M-tiles of a (N-tile, K-slice) pair on one XCD (ConvParams::xcd_map)
-        const int i = (int)blockIdx.x >> 3, ql = i / p.mtiles;
-        const int q = ql * 8 + ((int)blockIdx.x & 7);
-        if (q >= n_tiles_n * p.splits) return;           // padding of the last round of pairs
-        tile_m = i - ql * p.mtiles;
-        tile_n = q / p.splits;
-        split = q - tile_n * p.splits;
+    if (p.xcd_home) {  // all K slices of a tile on one XCD (ConvParams::xcd_home)
+        const int i = (int)blockIdx.x >> 3, tl = i / p.splits;
+        const int t = tl * 8 + ((int)blockIdx.x & 7);
+        if (t >= p.n_tiles) return;                      // padding of the last round of tiles
+        split = i - tl * p.splits;
+        tile_n = t % n_tiles_n;
+        tile_m = t / n_tiles_n;
+        xcd_home_mark(p, t, split);
     } else {
         split = (int)blockIdx.x % p.splits;
         const int t = (int)blockIdx.x / p.splits;
@@ -604,16 +605,19 @@ __global__ __launch_bounds__(256) void conv_igemm_h_kernel(const ConvParams p) {
 
 thread_local ConvProfHook* g_conv_prof = nullptr;
 
-// the 1-D launch grid of the kernels that take ConvParams::xcd_map / pf_*: [work blocks | padding to 8 | prefetch blocks]
+// the 1-D launch grid of the kernels that take ConvParams::xcd_home / pf_*: [work blocks | padding to 8 | prefetch blocks]
 void conv_grid_setup(ConvParams& q, int bm, int bn) {
     q.mtiles = (q.M + bm - 1) / bm;
     const int ntn = (q.CoutPad + bn - 1) / bn;
     q.n_tiles = q.mtiles * ntn;
-    const int pairs = ntn * q.splits;
-    q.work_blocks = q.xcd_map ? ((pairs + 7) / 8) * 8 * q.mtiles : q.n_tiles * q.splits;
+    q.work_blocks = q.xcd_home ? ((q.n_tiles + 7) / 8) * 8 * q.splits : q.n_tiles * q.splits;
     q.pf_first = (q.work_blocks + 7) & ~7;
 }
-int conv_grid_blocks(const ConvParams& q) { return q.pf_ptr ? q.pf_first + ((q.pf_pairs + 7) / 8) * 8 : q.work_blocks; }
+int conv_grid_blocks(const ConvParams& q) {
+    if (!q.pf_ptr) return q.work_blocks;
+    const int g = q.pf_ntn < 8 ? q.pf_ntn : 8;
+    return q.pf_first + 8 * (q.pf_ntn / g) * q.pf_splits;   // one prefetch block per pair and XCD that reads it
+}
 
 int conv_tile_bm(int tile) {
     switch (tile) {

@@ -86,13 +86,12 @@ __global__ __launch_bounds__(64 * (WM * WN * KG + LW)) void conv_pl_kernel(const
     const int wm = (LW ? (wave_id < NWC ? wave_id : 0) : wv) / WN, wn = (LW ? (wave_id < NWC ? wave_id : 0) : wv) % WN;
     const int n_tiles_n = (p.CoutPad + BN - 1) / BN;
     int split, tile_id;
-    if (p.xcd_map) {   // all M-tiles of a (N-tile, K-slice) pair on one XCD (ConvParams::xcd_map)
-        const int i = (int)blockIdx.x >> 3, ql = i / p.mtiles;
-        const int q = ql * 8 + ((int)blockIdx.x & 7);
-        if (q >= n_tiles_n * p.splits) return;           // padding of the last round of pairs
-        const int tn = q / p.splits;
-        split = q - tn * p.splits;
-        tile_id = (i - ql * p.mtiles) * n_tiles_n + tn;
+    if (p.xcd_home) {  // all K slices of a tile on one XCD (ConvParams::xcd_home)
+        const int i = (int)blockIdx.x >> 3, tl = i / p.splits;
+        tile_id = tl * 8 + ((int)blockIdx.x & 7);
+        if (tile_id >= p.n_tiles) return;                // padding of the last round of tiles
+        split = i - tl * p.splits;
+        xcd_home_mark(p, tile_id, split);
     } else if (p.splits > 1) {
         // K-slice fastest: consecutive block ids (= consecutive XCDs) take different K ranges of one output tile, so every
         // XCD streams its own share of the filters through its private L2

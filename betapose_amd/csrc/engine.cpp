@@ -524,8 +524,8 @@ int Net::add_conv(const std::string& name, const Tensor& in, const Tensor& out_v
     c.stamps = nullptr;
     c.w16 = nullptr; c.w16s = nullptr;
     c.in16 = nullptr; c.out16 = nullptr; c.wpl = nullptr; c.in16_plane = c.out16_plane = 0; c.out_np = 0; c.abl = 0; c.skip_f32 = 0;
-    c.pf_ptr = nullptr; c.xcd_map = 0; c.mtiles = c.n_tiles = c.work_blocks = c.pf_first = 0;
-    c.pf_pairs = c.pf_splits = c.pf_cps = c.pf_nchunks = c.pf_tile_stride = c.pf_chunk_bytes = c.pf_cap = 0;
+    c.pf_ptr = nullptr; c.xcd_home = 0; c.xcc_of = nullptr; c.tickets_local = nullptr; c.mtiles = c.n_tiles = c.work_blocks = c.pf_first = 0;
+    c.pf_ntn = c.pf_splits = c.pf_cps = c.pf_nchunks = c.pf_tile_stride = c.pf_chunk_bytes = c.pf_cap = 0;
     c.CoutPad = CoutPad;
     const double Kalg = (double)k * k * Cin;   // algorithmic K (the packing pad is not work)
     op.flops = 2.0 * OH * OW * (double)Cout * Kalg;
@@ -553,6 +553,7 @@ size_t Net::workspace_need() const {
 }
 
 void Net::finalize() {
+    (void)xcc_base();   // the one-time dispatch probe runs here (it allocates and copies: not inside a stream capture)
     partial_floats_ = workspace_need();
     partial_ = arena_.alloc(partial_floats_);
     // arrival counters for the in-kernel split-K reduction: one per output tile of the widest layer
@@ -561,8 +562,8 @@ void Net::finalize() {
         if (op.type == OP_CONV)
             tiles = std::max(tiles, (size_t)(((size_t)max_batch_ * op.conv.OH * op.conv.OW + 63) / 64) * (op.conv.CoutPad / 64));
     tickets_count_ = tiles;
-    tickets_ = (int*)arena_.alloc_bytes(tiles * sizeof(int));
-    BP_HIP(hipMemset(tickets_, 0, tiles * sizeof(int)));
+    tickets_ = (int*)arena_.alloc_bytes((2 + 64) * tiles * sizeof(int));      // [agent-scope counters | L2-local counters (xcd_home) | xcc_of]
+    BP_HIP(hipMemset(tickets_, 0, (2 + 64) * tiles * sizeof(int)));
 }
 
 void Net::set_precision(int prec) {
@@ -740,24 +741,41 @@ static int planes_np(int prec) { return prec == PREC_F16 ? 1 : 3; }
 // filter prefetch (ConvParams::pf_*): one extra block per (N-tile, K-slice) pair of the next launch pulls at most this much
 static int env_int(const char* name, int dflt) { const char* v = std::getenv(name); return v ? std::atoi(v) : dflt; }
 static const int kPrefetchCap = env_int("BP_PF_CAP_KB", 128) * 1024;
-// the XCD-matched block layout pays when the filters of a pair are worth sharing and there are pairs for all 8 XCDs
-int conv_xcd_map(const ConvParams& c, int tile, int splits) {
-    if (!(tile == TILE_64x64_BD || tile == TILE_PL64)) return 0;
-    if (conv_tile_is_pl(tile) && splits == 1) return 0;          // conv_pl's one-slice layout keeps neighbouring M-tiles on an XCD
-    return ((c.CoutPad + 63) / 64) * splits >= 8 ? 1 : 0;
+// XCC_ID of block 0 of a launch, or -1 when the dispatch is not the round robin ConvParams::xcd_home relies on (or
+// BP_NO_XCD_HOME=1): one probe launch per process, 64 blocks, every block b must report (base + b) % 8
+int xcc_base() {
+    static const int base = [] {
+        if (std::getenv("BP_NO_XCD_HOME")) return -1;
+        const int blocks = 64;
+        int* d = nullptr;
+        if (hipMalloc(&d, 2 * blocks * sizeof(int)) != hipSuccess) return -1;
+        launch_probe_placement(d, blocks, nullptr);
+        std::vector<int> h(2 * blocks);
+        const bool ok = hipMemcpy(h.data(), d, h.size() * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+        hipFree(d);
+        if (!ok) return -1;
+        for (int b = 0; b < blocks; ++b)
+            if (((h[2 * b] - h[0] - b) & 7) != 0) return -1;
+        return h[0] & 7;
+    }();
+    return base;
 }
 
-// p's launch carries the prefetch blocks for `next` (launched with tile nt, ns K slices of nc chunks), when next's blocks
-// will be laid out by XCD (conv_xcd_map) and read a per-pair contiguous filter image
+// p's launch carries the prefetch blocks for `next` (launched with tile nt, ns K slices of nc chunks), when next's work
+// blocks of residue x read the N-tiles n == x (mod min(N-tiles, 8)) -- the xcd_home layout, or the plain one-slice grid of the
+// 64x64 filters-direct kernel -- from a filter image that is contiguous per (N-tile, K-slice) pair
+bool conv_home_layout(int tile, int splits) {
+    return splits > 1 && splits <= 64 && xcc_base() >= 0 && (tile == TILE_64x64_BD || conv_tile_is_pl(tile));
+}
 void conv_prefetch_of(ConvParams& p, const ConvParams& next, int nt, int ns, int nc) {
     p.pf_ptr = nullptr;
-    const bool pl = next.mfma_mode != PREC_F32 && conv_tile_is_pl(nt) && next.wpl;
-    const bool bd = nt == TILE_64x64_BD && next.mfma_mode == PREC_BF16X3 && next.w16s;
-    if (!(pl || bd) || !conv_xcd_map(next, nt, ns)) return;
+    const bool pl = next.mfma_mode != PREC_F32 && (nt == TILE_PL64) && next.wpl && conv_home_layout(nt, ns);
+    const bool bd = nt == TILE_64x64_BD && next.mfma_mode == PREC_BF16X3 && next.w16s && (ns == 1 || conv_home_layout(nt, ns));
+    const int ntn = (next.CoutPad + 63) / 64;
+    if (!(pl || bd) || (ntn & (ntn - 1)) != 0 || xcc_base() < 0) return;
     const int np = planes_np(next.mfma_mode);
     p.pf_ptr = pl ? (const void*)next.wpl : (const void*)next.w16s;
-    p.pf_splits = ns; p.pf_cps = nc; p.pf_nchunks = next.nchunks;
-    p.pf_pairs = ((next.CoutPad + 63) / 64) * ns;
+    p.pf_ntn = ntn; p.pf_splits = ns; p.pf_cps = nc; p.pf_nchunks = next.nchunks;
     p.pf_chunk_bytes = np * 4096;                  // 64 filter rows x 32 k x 2 B per plane
     p.pf_tile_stride = next.nchunks * p.pf_chunk_bytes;
     p.pf_cap = kPrefetchCap;
@@ -777,15 +795,20 @@ void Net::run_op(const Op& op, int batch, hipStream_t s) {
                 splits = (p.nchunks + cps - 1) / cps;
             }
             p.splits = splits; p.chunks_per_split = cps; p.partial = partial_; p.tickets = tickets_;
+            p.tickets_local = tickets_ + tickets_count_;
+            p.xcc_of = tickets_ + 2 * tickets_count_;
             p.stamps = nullptr;
             if (stamps_) {   // in-situ timing (set_stamps): this conv's region of the stamp buffer, when its grid fits
                 int ord = 0;
                 for (const Op* q = ops_.data(); q != &op; ++q) ord += q->type == OP_CONV;
                 if ((long long)conv_tiles(p, tile) * splits <= stamp_slots_) p.stamps = stamps_ + ((size_t)ord * stamp_slots_) * 8;
             }
-            // XCD-matched layout + prefetch of the next convolution's filters (set_prefetch; ConvParams::xcd_map / pf_*; a
-            // hint: a wrong guess about the next launch costs bandwidth, not correctness)
-            p.xcd_map = prefetch_ ? conv_xcd_map(p, tile, splits) : 0;
+            // lone-frame latency mode (set_prefetch; bp_common.h "launch layout by XCD"): all K slices of a tile on one XCD with
+            // the hand-off through its L2 (xcd_home), and blocks that pull the next convolution's filters into the L2 that
+            // will read them (pf_*; a hint: a wrong guess about the next launch costs bandwidth, not correctness).  One frame
+            // at a time: 377 -> 384 -> 395 frames/s (fp16 533 -> 545 -> 558); with four in flight 916 -> 908 -> 895, so it is
+            // a mode, not the default (profiles/r03_prefetch_ab.txt)
+            p.xcd_home = (prefetch_ && conv_home_layout(tile, splits)) ? 1 : 0;
             p.pf_ptr = nullptr;
             if (prefetch_ && (tile == TILE_64x64_BD || conv_tile_is_pl(tile))) {
                 for (const Op* q = &op + 1; q != ops_.data() + ops_.size(); ++q) {

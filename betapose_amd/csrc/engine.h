@@ -97,8 +97,9 @@ public:
     // (entry, index math done, -, K loop done, stores done, slab parked, slices combined, -) at d_buf + (conv ordinal * slots +
     // block) * 8; null switches it off.  Graphs must be re-captured (plan_version).
     void set_stamps(unsigned long long* d_buf, int slots) { stamps_ = d_buf; stamp_slots_ = slots; ++plan_version_; }
-    // XCD-matched block layout + prefetch of the next layer's filters (bp_common.h ConvParams::xcd_map / pf_*).  Off by
-    // default: it is a lone-frame latency feature (+3.4 % one frame at a time, -1 .. -2 % with two to four in flight)
+    // lone-frame latency mode: split-K hand-off inside one XCD's L2 + blocks that pull the next layer's filters into the L2
+    // that will read them (bp_common.h ConvParams::xcd_home / pf_*).  Off by default: +4.7 % one frame at a time, -1 .. -2 %
+    // with two to four in flight
     void set_prefetch(bool on) { prefetch_ = on; ++plan_version_; }
     bool prefetch() const { return prefetch_; }
     const char* op_name(int i) const { return ops_[i].name.c_str(); }

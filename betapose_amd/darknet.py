@@ -199,8 +199,8 @@ class Darknet:
         return np.array(ms, dtype=np.float64), np.array(info, dtype=np.int64).reshape(n, 4)
 
     def set_prefetch(self, on: bool = True):
-        """Lone-frame latency mode (include/betapose_hip.h bp_*_set_prefetch): XCD-matched block layout + prefetch of the
-        next layer's filters.  Bit-identical results; pays with one frame at a time, costs with several in flight."""
+        """Lone-frame latency mode (include/betapose_hip.h bp_*_set_prefetch): split-K hand-off inside one XCD's L2 +
+        prefetch of the next layer's filters.  Bit-identical results; pays with one frame at a time, costs with several in flight."""
         self._ensure()
         _lib.check(_lib.lib().bp_yolo_set_prefetch(self._h, int(bool(on))))
 

@@ -127,10 +127,12 @@ int bp_yolo_profile(bp_yolo* y, int batch, int iters, float* ms, int* info, int 
  * captured pipeline graph is rebuilt on the next run.  op_name: the layer behind op i of bp_*_op_stats / bp_*_profile; returns 1 for a convolution, 0 for any other op, -1 on error. */
 /* how long `ticks` marks of the clock those stamps read take (one thread spinning on s_memtime between two events) */
 int bp_calibrate_ticks(long long ticks, float* ms, void* stream);
-/* lone-frame latency mode (off by default): lay the launches with >= 8 (N-tile, K-slice) pairs out by XCD and let every
- * convolution launch carry blocks that pull the NEXT convolution's filters into the L2 of the XCD that will read them.
- * +3.4 % frames/s with one frame at a time, a loss with two or more frames in flight (no idle CUs to spare);
- * results are bit-identical either way.  A captured pipeline graph is rebuilt on the next run. */
+/* lone-frame latency mode (off by default): split-K launches keep all K slices of an output tile on ONE XCD and hand the
+ * partial sums over inside that XCD's L2 (checked in every launch against the XCC_ID the hardware reports: a block that is
+ * not where the round-robin dispatch puts it aborts the stream instead of reading stale sums), and every convolution launch
+ * carries blocks that pull the NEXT convolution's filters into the L2 of the XCD that will read them.  +4.7 % frames/s
+ * with one frame at a time (fp16 +4.8 %), a loss of 1-2 % with two or more frames in flight (no idle CUs to spare); results
+ * are bit-identical either way.  A captured pipeline graph is rebuilt on the next run. */
 int bp_yolo_set_prefetch(bp_yolo* y, int on);
 int bp_kpd_set_prefetch(bp_kpd* k, int on);
 int bp_yolo_set_stamps(bp_yolo* y, unsigned long long* d_buf, int slots);

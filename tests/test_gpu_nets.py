@@ -192,6 +192,24 @@ def test_kpd_batch_equals_single(kpd, cuda, pipe_gold):
         assert torch.equal(h1[0].view(50, -1).argmax(1), hb[i].view(50, -1).argmax(1))
 
 
+def test_latency_mode_is_bit_identical(yolo, kpd, cuda, pipe_gold):
+    """bp_*_set_prefetch: split-K hand-off inside one XCD's L2 (every launch verifies the XCC_ID of its slices) and
+    prefetch blocks for the next layer's filters change where blocks run and what they pull, not one bit of the result."""
+    xs = torch.cat([helpers.yolo_input_from_frame(f) for f in helpers.frames(2)])
+    crops = torch.cat(_crops_from_golden(pipe_gold, 2))
+    base_y, base_k = yolo(xs.to(cuda)).cpu(), kpd(crops.to(cuda)).cpu()
+    try:
+        yolo.set_prefetch(True)
+        kpd.set_prefetch(True)
+        for _ in range(3):       # (repeated: the local tickets / XCC records are re-armed by every launch)
+            assert torch.equal(yolo(xs.to(cuda)).cpu(), base_y)
+            assert torch.equal(kpd(crops.to(cuda)).cpu(), base_k)
+    finally:
+        yolo.set_prefetch(False)
+        kpd.set_prefetch(False)
+    assert torch.equal(yolo(xs.to(cuda)).cpu(), base_y)
+
+
 # ---- fp16-MFMA mode (BASELINE configs[2]: batched inference, 28 crops / batch, fp16 MFMA conv path).  Operands of
 # every conv with Cin % 32 == 0 are rounded to fp16, accumulation and activations stay fp32.  Stated tolerances against
 # the fp32 oracle: heat-maps <= 1e-2 absolute (measured 1.4e-3 at a heat-map scale of 2.3), box centres <= 0.25 px,
