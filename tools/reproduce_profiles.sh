@@ -1,11 +1,11 @@
 #!/bin/bash
 # Regenerates everything under profiles/ for one round on an MI355X box (writes into gpurun_out/, copy what you keep).
-#   tools/reproduce_profiles.sh [round tag, default r03] [blocks, default "1 2 3 4 5 6"]
+#   tools/reproduce_profiles.sh [round tag, default r03] [blocks, default "1 2 3 4 5 6 7"]
 # Each block is independent; PMC passes are separate rocprofv3 runs with --kernel-trace only.  The experimental library
 # (python -m betapose_amd.build --experimental) is needed by block 5 (A/B against the round-2 data path).
 set -u
 TAG=${1:-r03}
-BLOCKS=${2:-"1 2 3 4 5 6"}
+BLOCKS=${2:-"1 2 3 4 5 6 7"}
 REPO="$(cd "$(dirname "$0")/.." && pwd)"
 OUT=$REPO/gpurun_out
 EXP=$REPO/betapose_amd/libbetapose_hip_exp.so
@@ -90,5 +90,32 @@ if has 6; then
 for pr in bf16x3 f32 f16; do python tools/soak_determinism.py --iters 4000 --precision $pr; done > $OUT/${TAG}_soak.txt 2>/dev/null
 python tools/occlusion_scale.py --frames 384 > $OUT/${TAG}_occlusion_8obj.txt 2>&1
 for b in 1 2 4; do python evaluate.py --synthetic 768 --outdir /tmp/ev --fused --streams 4 --detbatch $b 2>&1 | grep frames/sec; done > $OUT/${TAG}_evaluate_fused.txt
+fi
+if has 7; then
+# 7. what the chip does meanwhile: clocks and power by mode, first-touch fetch rates, block -> XCD map,
+#    per-layer SQ counters of the plane kernels, latency-mode A/B by frames in flight, the cache-resident-filters bound
+clk() { tag=$1; shift; python bench.py --steps 100 --warmup 20 --no-roofline --no-cpu-baseline --other-modes , --repeats 2 "$@" 2>/dev/null | python -c 'import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(sys.argv[1], d["value"], json.dumps(d.get("clocks_under_load")))' "$tag"; }
+{
+clk "b3 4 streams"; clk "b3 1 stream" --streams 1; clk "b3 2 streams" --streams 2; clk "b3 3 streams" --streams 3
+BP_B3_PLANES=1 clk "b3 planes 4 streams"; clk "f16 4 streams" --precision f16; clk "f32 4 streams" --precision f32
+clk "b3 batch 28 x2" --batch 28 --streams 2 --steps 30; clk "f16 batch 28 x3" --batch 28 --streams 3 --steps 30 --precision f16
+[ -f $EXP ] && BP_LIB=$EXP clk "exp b3 4 streams fixed box" --fixed-box
+[ -f $EXP ] && BP_LIB=$EXP BP_ALIAS_WEIGHTS=1 clk "exp alias b3 4 streams fixed box (every layer reads ONE filter buffer: wrong results)" --fixed-box
+} > $OUT/${TAG}_clocks_power.txt
+tools/micro/run_cold_fetch.sh > $OUT/${TAG}_cold_fetch.txt 2>/dev/null
+tools/micro/run_xcc_map.sh 2>/dev/null | grep "^stream\|^checked\|^grid" > $OUT/${TAG}_xcc_map.txt
+tools/pmc_layer.sh y3x3_128_256_52 pl128 f16 28 pl128_f16 > /dev/null && cp $OUT/pmc_layer_pl128_f16.json $OUT/${TAG}_pmc_layer_pl128_f16.json
+tools/pmc_layer.sh y3x3_128_256_52 pl256x128 f16 28 pl256_f16 > /dev/null && cp $OUT/pmc_layer_pl256_f16.json $OUT/${TAG}_pmc_layer_pl256_f16.json
+tools/pmc_layer.sh y3x3_128_256_52 pl128 b3 28 pl128_b3 > /dev/null && cp $OUT/pmc_layer_pl128_b3.json $OUT/${TAG}_pmc_layer_pl128_b3.json
+{
+for st in 1 2 4; do
+  quick "bf16x3, $st in flight, default layout" --streams $st
+  quick "bf16x3, $st in flight, latency mode (xcd_home + filter prefetch)" --streams $st --prefetch
+  BP_NO_XCD_HOME=1 quick "bf16x3, $st in flight, latency mode without xcd_home (no prefetch either: it needs the layout)" --streams $st --prefetch
+done
+quick "fp16, 4 in flight, default layout" --precision f16; quick "fp16, 4 in flight, latency mode" --precision f16 --prefetch
+quick "fp16, one at a time, default layout" --precision f16 --streams 1; quick "fp16, one at a time, latency mode" --precision f16 --streams 1 --prefetch
+} > $OUT/${TAG}_prefetch_ab.txt
+[ -f $EXP ] && for m in b3 f16; do BP_LIB=$EXP python tools/bench_pl.py --mode $m --batch 1 --tiles pl64,pl64k2 --splits 1,2,3,4,5,6,8,10 --all-splits --iters 20 2>&1 | grep -v amdgpu.ids; done > $OUT/${TAG}_pl64_kgroups.txt
 fi
 ls -la $OUT | tail -40
