@@ -808,7 +808,7 @@ void Net::run_op(const Op& op, int batch, hipStream_t s) {
             // will read them (pf_*; a hint: a wrong guess about the next launch costs bandwidth, not correctness).  One frame
             // at a time: 377 -> 384 -> 395 frames/s (fp16 533 -> 545 -> 558); with four in flight 916 -> 908 -> 895, so it is
             // a mode, not the default (profiles/r03_prefetch_ab.txt)
-            p.xcd_home = (prefetch_ && conv_home_layout(tile, splits)) ? 1 : 0;
+            p.xcd_home = (prefetch_ && conv_home_layout(tile, splits)) ? 1 : 0;   // (with four frames in flight it gains nothing even on launches whose tiles divide evenly over the XCDs: 898 against 896)
             p.pf_ptr = nullptr;
             if (prefetch_ && (tile == TILE_64x64_BD || conv_tile_is_pl(tile))) {
                 for (const Op* q = &op + 1; q != ops_.data() + ops_.size(); ++q) {
