@@ -99,6 +99,10 @@ struct ConvParams {
     //    frame do not stay in the 256 MB MALL), pulled by the few blocks that need them at 17-22 B/clk/CU where an L2 hit
     //    delivers 46-60 (tools/micro/cold_fetch.hip).  Under both layouts used here (xcd_home, and the plain one-slice grid
     //    of the 64x64 filters-direct kernel) the blocks of residue x read the N-tiles n == x (mod g), g = min(N-tiles, 8).
+    // SE blocks: the global average pool of this convolution's output rides in its epilogue -- every 64-row tile writes
+    // the column sums of its rows (fixed order; the linear, residual-free output = accumulator + bias) to
+    // pool_out[tile_m][Cout], which the first fc of the block reads as `in_parts` slice sums (aux_kernels.hip fc_kernel)
+    float* pool_out;              // nullptr: none
     int xcd_home;                 // 1: block b -> x = b % 8, i = b / 8: tile (i / splits) * 8 + x, K slice i % splits
     int* xcc_of;                  // [tiles][64] XCC_ID of every K slice of the running launch
     int* tickets_local;           // [tiles] arrival counters of the xcd_home launches (touched by L2-local atomics only)

@@ -524,6 +524,7 @@ int Net::add_conv(const std::string& name, const Tensor& in, const Tensor& out_v
     c.stamps = nullptr;
     c.w16 = nullptr; c.w16s = nullptr;
     c.in16 = nullptr; c.out16 = nullptr; c.wpl = nullptr; c.in16_plane = c.out16_plane = 0; c.out_np = 0; c.abl = 0; c.skip_f32 = 0;
+    c.pool_out = nullptr;
     c.pf_ptr = nullptr; c.xcd_home = 0; c.xcc_of = nullptr; c.tickets_local = nullptr; c.mtiles = c.n_tiles = c.work_blocks = c.pf_first = 0;
     c.pf_ntn = c.pf_splits = c.pf_cps = c.pf_nchunks = c.pf_tile_stride = c.pf_chunk_bytes = c.pf_cap = 0;
     c.CoutPad = CoutPad;
@@ -781,6 +782,24 @@ void conv_prefetch_of(ConvParams& p, const ConvParams& next, int nt, int ns, int
     p.pf_cap = kPrefetchCap;
 }
 
+// The SE blocks' average pool inside the producing conv's epilogue (ConvParams::pool_out): for the 64-row tiles with the
+// staged vector epilogue, when a tile never spans two images.  BP_NO_POOL_FUSION=1: the separate kernel (A/B, tests).
+bool Net::pool_in_epilogue(const Op& conv, int batch, int tile) const {
+    static const bool off = std::getenv("BP_NO_POOL_FUSION") != nullptr;
+    const ConvParams& c = conv.conv;
+    if (off || !conv.pool_out || conv_tile_bm(tile) != 64 || conv_tile_bn(tile) != 64) return false;
+    if (c.store_mode != ST_NHWC || c.res || c.res_scale || c.act != ACT_LINEAR || (c.out_ld & 3) || (c.Cout & 3)) return false;
+    return batch == 1 || (c.OH * c.OW) % 64 == 0;
+}
+bool Net::pooled_by_conv(const Op& pool, int batch) const {
+    if (&pool == ops_.data()) return false;
+    const Op& prev = *(&pool - 1);
+    if (prev.type != OP_CONV || prev.pool_out != pool.out) return false;
+    int tile, splits, cps;
+    choose_launch(prev, batch, force_tile_, sk_target_, sk_min_chunks_, sk_max_splits_, &tile, &splits, &cps);
+    return pool_in_epilogue(prev, batch, tile);
+}
+
 void Net::run_op(const Op& op, int batch, hipStream_t s) {
     switch (op.type) {
         case OP_CONV: {
@@ -809,6 +828,7 @@ void Net::run_op(const Op& op, int batch, hipStream_t s) {
             // at a time: 377 -> 384 -> 395 frames/s (fp16 533 -> 545 -> 558); with four in flight 916 -> 908 -> 895, so it is
             // a mode, not the default (profiles/r03_prefetch_ab.txt)
             p.xcd_home = (prefetch_ && conv_home_layout(tile, splits)) ? 1 : 0;   // (with four frames in flight it gains nothing even on launches whose tiles divide evenly over the XCDs: 898 against 896)
+            p.pool_out = pool_in_epilogue(op, batch, tile) ? op.pool_out : nullptr;
             p.pf_ptr = nullptr;
             if (prefetch_ && (tile == TILE_64x64_BD || conv_tile_is_pl(tile))) {
                 for (const Op* q = &op + 1; q != ops_.data() + ops_.size(); ++q) {
@@ -844,11 +864,15 @@ void Net::run_op(const Op& op, int batch, hipStream_t s) {
             launch_pixel_shuffle2(op.a, op.out, batch, op.H, op.W, op.C, s, op.out16, op.out16_plane, planes_np(precision_));
             break;
         case OP_AVGPOOL:
+            if (pooled_by_conv(op, batch)) break;      // its slice sums were written by the producing conv's epilogue
             launch_avgpool(op.a, op.a_ld, op.out, batch, op.H * op.W, op.C, s);
             break;
-        case OP_FC:
-            launch_fc(op.a, op.w, op.bias, op.out, batch, op.Cin, op.Cout, op.act, op.in_parts, op.in_scale, s);
-            break;
+        case OP_FC: {
+            int parts = op.in_parts;
+            if (&op != ops_.data() && (&op - 1)->type == OP_AVGPOOL && (&op - 1)->out == op.a && pooled_by_conv(*(&op - 1), batch))
+                parts = ((&op - 1)->H * (&op - 1)->W + 63) / 64;
+            launch_fc(op.a, op.w, op.bias, op.out, batch, op.Cin, op.Cout, op.act, parts, op.in_scale, s);
+        } break;
         default:
             throw Error("unknown op");
     }
@@ -1257,7 +1281,9 @@ KpdNet::KpdNet(const float* stream, size_t n_floats, int n_classes, int max_batc
                 Tensor Tt = new_tensor(OH, OW, C);
                 add_conv(nm + ".conv3", t2, Tt, c3, C, 1, 1, 0, ACT_LINEAR, ST_NHWC, nullptr, nullptr, 0, 1e-5f, OH, OW);
                 const int parts = avgpool_parts(OH * OW);
-                float* pooled = arena_.alloc((size_t)max_batch * parts * C);
+                const int tpi = (OH * OW + 63) / 64;      // slice sums per image when the pool rides in conv3's epilogue (pool_in_epilogue)
+                float* pooled = arena_.alloc((size_t)max_batch * std::max(parts, tpi) * C);
+                ops_.back().pool_out = pooled;
                 float* hid = arena_.alloc((size_t)max_batch * C);
                 float* y = arena_.alloc((size_t)max_batch * C);
                 Op ap; ap.type = OP_AVGPOOL; ap.name = nm + ".se.pool";

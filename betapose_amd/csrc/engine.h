@@ -43,6 +43,7 @@ struct Op {
     // fc
     const float* w = nullptr; const float* bias = nullptr; int Cin = 0, Cout = 0, act = 0;
     int in_parts = 1; float in_scale = 1.f;
+    float* pool_out = nullptr;   // OP_CONV: the buffer of the OP_AVGPOOL that follows (its slice sums can ride in this conv's epilogue)
     unsigned short* out16 = nullptr; long long out16_plane = 0;   // operand planes of `out` (non-conv producers; set_precision)
     std::string name;
     double flops = 0;    // per image
@@ -101,6 +102,8 @@ public:
     // that will read them (bp_common.h ConvParams::xcd_home / pf_*).  Off by default: +4.7 % one frame at a time, -1 .. -2 %
     // with two to four in flight
     void set_prefetch(bool on) { prefetch_ = on; ++plan_version_; }
+    bool pool_in_epilogue(const Op& conv, int batch, int tile) const;
+    bool pooled_by_conv(const Op& pool, int batch) const;
     bool prefetch() const { return prefetch_; }
     const char* op_name(int i) const { return ops_[i].name.c_str(); }
 
