@@ -573,10 +573,15 @@ void launch_resize_bicubic(const uint8_t* in, int batch, int H, int W, uint8_t* 
 // ---- the same three planes, STAGE-PACKED for the filters-direct kernel (conv_igemm.hip; also conv_kg.hip / conv_rd.hip): per 64-row filter tile and 16-k stage one contiguous block
 // [plane][row 0..63][32 B] that already is the kernel's LDS image (granule g of row r at slot g ^ ((r >> 3) & 1)), so a
 // stage arrives by six 1 KB lane-linear DMA instructions from 6 KB of consecutive addresses
-__global__ void f32_to_bf16x3_staged_kernel(const float* __restrict__ in, __bf16* __restrict__ out, int CoutPad, int Kpad) {
+__global__ void f32_to_bf16x3_staged_kernel(const float* __restrict__ in, __bf16* __restrict__ out, int CoutPad, int Kpad, int Cin_pl) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)CoutPad * Kpad) return;
-    const int n = (int)(i / Kpad), k = (int)(i - (long long)n * Kpad);
+    const int n = (int)(i / Kpad);
+    int k = (int)(i - (long long)n * Kpad);
+    if (Cin_pl > 0) {   // source K order (tap, channel) -> conv_pl.hip's (32-channel group, tap, channel % 32)
+        const int tap = k / Cin_pl, ci = k - tap * Cin_pl;
+        k = ((ci >> 5) * (Kpad / Cin_pl) + tap) * 32 + (ci & 31);
+    }
     const float x = in[i];
     const __bf16 h1 = (__bf16)x;
     const float r1 = x - (float)h1;
@@ -590,10 +595,11 @@ __global__ void f32_to_bf16x3_staged_kernel(const float* __restrict__ in, __bf16
     out[base + 2 * 64 * 16] = (__bf16)r2;
 }
 
-void launch_f32_to_bf16x3_staged(const float* in, unsigned short* out, int CoutPad, int Kpad, hipStream_t s) {
+void launch_f32_to_bf16x3_staged(const float* in, unsigned short* out, int CoutPad, int Kpad, hipStream_t s, int Cin_pl) {
     const long long n = (long long)CoutPad * Kpad;
+    BP_CHECK(Cin_pl == 0 || (Cin_pl % 32 == 0 && Kpad % Cin_pl == 0), "stage-packed filters in conv_pl order: Cin % 32, Kpad = taps * Cin");
     hipLaunchKernelGGL(f32_to_bf16x3_staged_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in,
-                       reinterpret_cast<__bf16*>(out), CoutPad, Kpad);
+                       reinterpret_cast<__bf16*>(out), CoutPad, Kpad, Cin_pl);
 }
 
 #ifdef BP_EXPERIMENTAL   // filter formats of the other round-1/2 16-bit kernels (conv_igemm_h staged / conv_w64)

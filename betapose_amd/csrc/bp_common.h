@@ -85,6 +85,7 @@ struct ConvParams {
     int out_np;                   // planes the epilogue emits: 0 none, 1 fp16, 3 bf16x3
     int skip_f32;                 // 1: every reader of `out` takes the planes -- the fp32 store is dropped (engine.cpp plan_planes)
     int abl;                      // timing ablations, experimental builds only (-DBP_EXPERIMENTAL; tools/abl_pl.sh): 0 in the product
+    const unsigned short* wbd;    // filters as stage-packed fragments in conv_pl.hip's K order (TILE_PL64BD: launch_f32_to_bf16x3_staged with Cin)
     const unsigned short* wpl;    // filters as conv_pl.hip's LDS image: [CoutPad/64][nchunks][plane][64 rows][64 B swizzled]
     // ---- launch layout by XCD (the hardware puts block b of a 1-D grid on XCD (b + c) % 8, every XCD with its own 4 MB L2;
     // tools/micro/xcc_map.hip: one c per queue, also with four streams in flight)
@@ -132,9 +133,10 @@ enum ConvTile : int { TILE_64x64 = 0, TILE_128x64 = 1, TILE_W64_1x1 = 2, TILE_W6
                       TILE_PL128 = 14,      // 128x128, 2x2 waves of 64x64
                       TILE_PL128x64 = 15,   // 128x64, 2x2 waves of 64x32
                       TILE_PL256x128 = 16,  // 256x128, 4x2 waves of 64x64
+                      TILE_PL64BD = 19,     // 64x64 on operand planes, filter fragments direct from global memory (conv_pl.hip BDIR; bf16x3)
                       TILE_PL64K2 = 18,     // 64x64, two K groups of 2x2 waves (8 waves, a ring per group): for launches of at most one block per CU
                       TILE_PL128S = 17,     // 128x128, 2x2 compute waves of 64x64 + 4 loader waves (wave specialisation; no K slices)
-                      TILE_LAST = 18 };
+                      TILE_LAST = 19 };
 
 // when non-null, launch_conv brackets the implicit-GEMM kernel itself (not the split-K reduce) with these events
 struct ConvProfHook { hipEvent_t e0, e1; };
@@ -209,7 +211,7 @@ void launch_heatmap_argmax(const float* hm, int N, int C, int H, int W, float* o
 void launch_f32_to_f16(const float* in, unsigned short* out, long long n, hipStream_t s);
 void launch_f32_to_bf16x3(const float* in, unsigned short* out_planes, long long n, hipStream_t s);
 void launch_f32_to_f16_staged(const float* in, unsigned short* out, int CoutPad, int Kpad, hipStream_t s);      // ... fp16 mode
-void launch_f32_to_bf16x3_staged(const float* in, unsigned short* out, int CoutPad, int Kpad, hipStream_t s);   // conv_kg.hip's layout
+void launch_f32_to_bf16x3_staged(const float* in, unsigned short* out, int CoutPad, int Kpad, hipStream_t s, int Cin_pl = 0);   // Cin_pl > 0: K in conv_pl.hip's order (32-channel group, tap, channel)   // conv_kg.hip's layout
 void launch_probe_placement(int* d_out, int blocks, hipStream_t s);
 void launch_spin_ticks(long long ticks, hipStream_t s);   // one thread spinning until bp_clock() has advanced by `ticks`
 

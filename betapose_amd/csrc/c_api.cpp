@@ -520,6 +520,16 @@ int bp_conv2d_planes(const float* d_in, int N, int H, int W, int Cin, const floa
             it = packed.emplace(p.w, d).first;
         }
         p.wpl = it->second;
+        if (t == bp::TILE_PL64BD) {   // the filters-direct plane tile reads stage-packed fragments in the plane kernels' K order
+            auto& staged = net.weight_store()->wbd3;
+            auto ib = staged.find(p.w);
+            if (ib == staged.end()) {
+                unsigned short* d = (unsigned short*)net.weight_store()->arena.alloc_bytes((size_t)3 * p.CoutPad * p.Kpad * 2);
+                bp::launch_f32_to_bf16x3_staged(p.w, d, p.CoutPad, p.Kpad, s, p.Cin);
+                ib = staged.emplace(p.w, d).first;
+            }
+            p.wbd = ib->second;
+        }
     }
     if (const char* e = std::getenv("BP_PL_ABL")) p.abl = std::atoi(e);   // (read by experimental builds only)
     if (d_out_planes) {   // the epilogue's operand planes of the output (any kernel): [np][the output tensor's elements]

@@ -51,15 +51,24 @@ namespace bp {
 // LDS-DMA instruction holds it for 60+ cycles, so with one wave per SIMD the matrix pipe idles through every DMA issue
 // (measured 860 cycles per 384-cycle bf16x3 chunk); a second wave on the SIMD multiplies meanwhile -- K parallelism without
 // the slab hand-off of the K slices between blocks (3-5 us per launch, tools/bench_pl.py with BP_CONV_STAMPS).
-template <int NP, int WM, int WN, int TM, int TN, int NST, int CPS, int LW = 0, int KG = 1>
+//
+// BDIR: the FILTER fragments skip LDS -- every wave fetches the 16-B fragments of its 32 columns straight from the
+// stage-packed image ConvParams::wbd (fully coalesced 1 KB per instruction, one chunk ahead, into registers), as the
+// round-2 filters-direct kernel does, while the activations still arrive as operand planes by LDS-DMA.  LDS then carries
+// the activation planes only (12 KB per bf16x3 stage instead of 24: four blocks per CU instead of two), the K loop has
+// neither the in-kernel fp32 -> 3 x bf16 conversion of the round-2 kernel (44 vector instructions per thread and chunk
+// beside 12 MFMAs per wave: it is what the shader clock gives way to) nor the filter DMAs of the plain
+// plane kernel.  64x64 tile, one chunk per stage.
+template <int NP, int WM, int WN, int TM, int TN, int NST, int CPS, int LW = 0, int KG = 1, bool BDIR = false>
 __global__ __launch_bounds__(64 * (WM * WN * KG + LW)) void conv_pl_kernel(const ConvParams p) {
     static_assert(LW == 0 || KG == 1, "loader waves and K groups are alternatives");
+    static_assert(!BDIR || (TM == 1 && TN == 1 && CPS == 1 && LW == 0 && KG == 1 && WM == 2 && WN == 2), "filters-direct form: 64x64 tile, 2x2 waves");
     constexpr int NWC = WM * WN;                  // compute waves (per K group)
     constexpr int NW = LW ? LW : NWC;             // waves (of a group) that issue DMAs
     constexpr int NT = 64 * (NWC * KG + LW);
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int LDT = BN + 4;
-    constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64;        // bytes per plane and chunk
+    constexpr int A_PLANE = BM * 64, B_PLANE = BDIR ? 0 : BN * 64;        // LDS bytes per plane and chunk
     constexpr int CHUNK = NP * (A_PLANE + B_PLANE);
     constexpr int STAGE = CPS * CHUNK;
     constexpr int EP_SLABS_ = BM > 128 ? BM / 64 : 1;       // epilogue staging in 64-row slabs on the big tiles (conv_tail.inc)
@@ -128,7 +137,7 @@ __global__ __launch_bounds__(64 * (WM * WN * KG + LW)) void conv_pl_kernel(const
     const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<unsigned short*>(p.in16), 0, (int)min(2ll * pl_bytes + (long long)p.N * p.H * p.W * p.in_ld * 2, (long long)OOB), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<unsigned short*>(p.wpl), 0, (int)((long long)NP * p.CoutPad * p.Kpad * 2), 0x00020000);
+        const_cast<unsigned short*>(BDIR ? p.wbd : p.wpl), 0, (int)((long long)NP * p.CoutPad * p.Kpad * 2), 0x00020000);
 
     // ---- A side: a DMA instruction covers 16 tile rows of one plane; wave w owns row groups w, w + NW, ... (all planes)
     constexpr int RGA = BM / 16;
@@ -170,7 +179,7 @@ __global__ __launch_bounds__(64 * (WM * WN * KG + LW)) void conv_pl_kernel(const
     // owns row groups w, w + NW, ... of the block's BN rows (all planes), so every offset is (wave base) + constant
     constexpr int RGB = BN / 16;
     static_assert(RGB % NW == 0 && (NW == 4 || NW == 8), "filter row groups must divide over the waves");
-    constexpr int KB = RGB / NW;
+    constexpr int KB = BDIR ? 0 : RGB / NW;
     // row group wave + NW k: filter row n0 + 16 wave + 16 NW k -> 64-row tile (n0 >> 6) + (NW / 4) k [+ wave >> 2], row 16 (wave & 3)
     const int b_src0 = (((n0 >> 6) + (wave >> 2)) * p.nchunks * NP) * 4096 + (wave & 3) * 1024;
     const int b_srck = (NW / 4) * p.nchunks * NP * 4096;                 // per k
@@ -257,6 +266,23 @@ __global__ __launch_bounds__(64 * (WM * WN * KG + LW)) void conv_pl_kernel(const
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // ---- BDIR: filter fragments of chunk c for this wave's 32 columns = NP x 2 pieces of 1 KB at bd_tile + c * (2 NP) KB x 2:
+    // [k-step][plane][64 rows x 32 B]; lane -> row 32 wn + (lane & 31), granule (lane >> 5) at slot granule ^ ((row >> 3) & 1)
+    // (the image of launch_f32_to_bf16x3_staged, in this kernel's K order).  Past the K range: out of range, zeros.
+    const int bd_tile = tile_n * p.nchunks * (2 * NP * 2048);
+    const unsigned bd_voff = (unsigned)((32 * wn + (lane & 31)) * 32 + (((lane >> 5) ^ ((lane >> 3) & 1)) << 4));
+    int bd_c = c_begin;
+    frag_t fbq[2][NP][2];          // [chunk parity][plane][k-step]
+    auto load_b = [&](auto bufc) __attribute__((always_inline)) {
+        constexpr int buf = decltype(bufc)::value;
+        const int so = bd_c < c_end ? bd_tile + bd_c * (2 * NP * 2048) : (int)OOB;
+        ++bd_c;
+        static_for<NP * 2>([&](auto ec) __attribute__((always_inline)) {
+            constexpr int pl = decltype(ec)::value / 2, ks = decltype(ec)::value % 2;
+            fbq[buf][pl][ks] = __builtin_bit_cast(frag_t, __builtin_amdgcn_raw_buffer_load_b128(rsrcB, (int)bd_voff, so + ks * (NP * 2048) + pl * 2048, 0));
+        });
+    };
+
     // ---- fragment reads: lane -> row (lane & 31), logical granule 2 ks + (lane >> 5)
     const int fsw = ((lane & 31) >> 2) & 3;
     const int fr0 = (lane & 31) * 64 + ((((lane >> 5)) ^ fsw) << 4);          // k-step 0; k-step 1 = fr0 ^ 32
@@ -267,14 +293,15 @@ __global__ __launch_bounds__(64 * (WM * WN * KG + LW)) void conv_pl_kernel(const
     constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
     constexpr int NSTEP = 2 * CPS;                 // 16-k MFMA steps per stage
     constexpr int NMF = NPROD * TM * TN;           // MFMAs per step
-    constexpr int NRD = NP * (TM + TN);            // fragments per step
+    constexpr int TNR = BDIR ? 0 : TN;             // filter fragments read from LDS per plane and step
+    constexpr int NRD = NP * (TM + TNR);           // fragments per step
     frag_t fa[2][NP][TM], fb[2][NP][TN];
     // fragment r of a step, in the order the step's MFMAs first need them: (A plane 2, B plane 0), (A 1, B 1), (A 0, B 2)
     constexpr int RPA[3] = {2, 1, 0}, RPB[3] = {0, 1, 2};
     auto read_frag = [&](int so, auto sc, auto rc) __attribute__((always_inline)) {
         constexpr int s = decltype(sc)::value, r = decltype(rc)::value, fs = s & 1;
         constexpr int j = s >> 1, ks = s & 1;
-        constexpr int grp = r / (TM + TN), e = r % (TM + TN);
+        constexpr int grp = r / (TM + TNR), e = r % (TM + TNR);
         if (abl & 8) return;
         const char* const base = sb + so + j * CHUNK;
         if constexpr (e < TM) {
@@ -285,11 +312,12 @@ __global__ __launch_bounds__(64 * (WM * WN * KG + LW)) void conv_pl_kernel(const
             fb[fs][pl][e - TM] = *reinterpret_cast<const frag_t*>(base + pl * B_PLANE + (e - TM) * (32 * 64) + (ks ? (b_rd ^ 32) : b_rd));
         }
     };
-    auto mfma_one = [&](auto sc, auto mc) __attribute__((always_inline)) {
-        constexpr int fs = decltype(sc)::value & 1, m = decltype(mc)::value;
+    auto mfma_one = [&](auto sc, auto mc, auto parc) __attribute__((always_inline)) {
+        constexpr int fs = decltype(sc)::value & 1, m = decltype(mc)::value, par = decltype(parc)::value;
         constexpr int q = m / (TM * TN), i = (m / TN) % TM, jn = m % TN;
         if (abl & 4) return;
-        acc[i][jn] = HalfOps<NP>::mfma(fa[fs][NP == 1 ? 0 : PA[q]][i], fb[fs][NP == 1 ? 0 : PB[q]][jn], acc[i][jn]);
+        if constexpr (BDIR) acc[i][jn] = HalfOps<NP>::mfma(fa[fs][NP == 1 ? 0 : PA[q]][i], fbq[par][NP == 1 ? 0 : PB[q]][fs], acc[i][jn]);
+        else acc[i][jn] = HalfOps<NP>::mfma(fa[fs][NP == 1 ? 0 : PA[q]][i], fb[fs][NP == 1 ? 0 : PB[q]][jn], acc[i][jn]);
     };
 
 #define PL_STAMP(k_) if (p.stamps && tid == 0) p.stamps[(long long)(tile_id * p.splits + split) * 8 + (k_)] = bp_clock();
@@ -313,17 +341,26 @@ __global__ __launch_bounds__(64 * (WM * WN * KG + LW)) void conv_pl_kernel(const
             stage_addr();
             if (LW == 0 || is_loader)
                 static_for<IPW>([&](auto dc) __attribute__((always_inline)) { dma_piece(decltype(sc)::value * STAGE, dc); });
+            // BDIR: filter fragments run TWO chunks ahead (a cold chunk comes from HBM: ~2 us against ~0.3 us of work per
+            // chunk); issue order [stage 0, filters 0, stage 1, filters 1] so that the first counted wait covers stage 0 and
+            // filters 0
+            if constexpr (BDIR) {
+                static_assert(NST == 3, "the filters-direct form counts on a 3-deep ring");
+                load_b(std::integral_constant<int, decltype(sc)::value>{});
+            }
         });
         int rd_off = 0, wr_off = (NST - 1) * STAGE;
         int it = 0;
-        do {
+        auto stage_body = [&](auto parc) __attribute__((always_inline)) {
             stage_addr();
             // this wave's DMAs of the oldest stage have landed (NST - 2 younger stages stay in flight); behind the barrier
             // everybody's have, and everybody is done reading the slot the next issue overwrites
 #ifdef BP_EXPERIMENTAL
             const unsigned long long tw0 = p.stamps ? bp_clock() : 0ull;
 #endif
-            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"((NST - 2) * IPW) : "memory");
+            // (BDIR: per stage the wave issues [the IPW DMAs of stage i + 2, then the 2 NP filter loads of chunk i + 2]; in
+            // flight behind the wait = what the previous stage issued -- stage i and chunk i, issued before that, are in)
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(BDIR ? IPW + 2 * NP : (NST - 2) * IPW) : "memory");
 #ifdef BP_EXPERIMENTAL
             if (p.stamps) t_wait += bp_clock() - tw0;
 #endif
@@ -334,7 +371,7 @@ __global__ __launch_bounds__(64 * (WM * WN * KG + LW)) void conv_pl_kernel(const
                 PL_SB();
                 static_for<SLOTS>([&](auto gc) __attribute__((always_inline)) {
                     constexpr int g = decltype(gc)::value, s = g / NMF, m = g % NMF;
-                    mfma_one(std::integral_constant<int, s>{}, std::integral_constant<int, m>{});
+                    mfma_one(std::integral_constant<int, s>{}, std::integral_constant<int, m>{}, parc);
                     constexpr int d_lo = N0 + (g * DREM + SLOTS - 1) / SLOTS, d_hi = N0 + ((g + 1) * DREM + SLOTS - 1) / SLOTS;
                     static_for<d_hi - d_lo>([&](auto k) __attribute__((always_inline)) {
                         dma_piece(wr_off, std::integral_constant<int, d_lo + decltype(k)::value>{});
@@ -354,7 +391,7 @@ __global__ __launch_bounds__(64 * (WM * WN * KG + LW)) void conv_pl_kernel(const
                 PL_SB();
                 static_for<SLOTS>([&](auto gc) __attribute__((always_inline)) {
                     constexpr int g = decltype(gc)::value, s = g / NMF, m = g % NMF;
-                    mfma_one(std::integral_constant<int, s>{}, std::integral_constant<int, m>{});
+                    mfma_one(std::integral_constant<int, s>{}, std::integral_constant<int, m>{}, parc);
                     if constexpr (s + 1 < NSTEP && m < HALF) {
                         constexpr int r_lo = (m * NRD + HALF - 1) / HALF, r_hi = ((m + 1) * NRD + HALF - 1) / HALF;
                         static_for<r_hi - r_lo>([&](auto k) __attribute__((always_inline)) {
@@ -364,10 +401,23 @@ __global__ __launch_bounds__(64 * (WM * WN * KG + LW)) void conv_pl_kernel(const
                     PL_SB();
                 });
             }
+            // BDIR: the registers this stage multiplied from take the filter fragments of the chunk two stages on (requested
+            // behind the stage's last MFMA: the loads return long after it has read its operands)
+            if constexpr (BDIR) { load_b(parc); PL_SB(); }
             wr_off = (wr_off + STAGE == NST * STAGE) ? 0 : wr_off + STAGE;
             rd_off = (rd_off + STAGE == NST * STAGE) ? 0 : rd_off + STAGE;
             ++it;
-        } while (it < n_it);
+        };
+        if constexpr (BDIR) {     // two stages per trip: the filter fragment registers swap roles at compile time
+            for (;;) {
+                stage_body(std::integral_constant<int, 0>{});
+                if (it >= n_it) break;
+                stage_body(std::integral_constant<int, 1>{});
+                if (it >= n_it) break;
+            }
+        } else {
+            do { stage_body(std::integral_constant<int, 0>{}); } while (it < n_it);
+        }
     }
     // the ring (still receiving the out-of-range tail issues) becomes the epilogue's staging tile
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
@@ -415,27 +465,28 @@ __global__ __launch_bounds__(64 * (WM * WN * KG + LW)) void conv_pl_kernel(const
 
 bool conv_tile_is_pl(int tile) {
 #ifdef BP_EXPERIMENTAL
-    if (tile == TILE_PL128S || tile == TILE_PL64K2) return true;
+    if (tile == TILE_PL128S || tile == TILE_PL64K2 || tile == TILE_PL64BD) return true;
 #endif
     return tile == TILE_PL64 || tile == TILE_PL128 || tile == TILE_PL128x64 || tile == TILE_PL256x128;
 }
 
 bool conv_pl_eligible(const ConvParams& p) {
-    return p.in16 != nullptr && p.wpl != nullptr && (p.Cin % 32 == 0) && (p.in_ld % 8 == 0) && p.ksize * p.ksize <= 32 &&
+    return p.in16 != nullptr && (p.wpl != nullptr || p.wbd != nullptr) && (p.Cin % 32 == 0) && (p.in_ld % 8 == 0) && p.ksize * p.ksize <= 32 &&
            ((reinterpret_cast<uintptr_t>(p.in16) & 15) == 0) && (p.in16_plane % 8 == 0);
 }
 
-template <int NP, int WM, int WN, int TM, int TN, int NST, int CPS, int LW = 0, int KG = 1>
+template <int NP, int WM, int WN, int TM, int TN, int NST, int CPS, int LW = 0, int KG = 1, bool BDIR = false>
 static void launch_pl_t(const ConvParams& p, hipStream_t s) {
+    BP_CHECK(BDIR ? p.wbd != nullptr : p.wpl != nullptr, "conv_pl: the filter image of this tile is missing");
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     BP_CHECK(LW == 0 || p.splits == 1, "the wave-specialised operand-plane tiles do not take K slices");
     ConvParams q = p;
     conv_grid_setup(q, BM, BN);
     dim3 grid(conv_grid_blocks(q));
     if (g_conv_prof)
-        hipExtLaunchKernelGGL((conv_pl_kernel<NP, WM, WN, TM, TN, NST, CPS, LW, KG>), grid, dim3(64 * (WM * WN * KG + LW)), 0, s, g_conv_prof->e0, g_conv_prof->e1, 0, q);
+        hipExtLaunchKernelGGL((conv_pl_kernel<NP, WM, WN, TM, TN, NST, CPS, LW, KG, BDIR>), grid, dim3(64 * (WM * WN * KG + LW)), 0, s, g_conv_prof->e0, g_conv_prof->e1, 0, q);
     else
-        hipLaunchKernelGGL((conv_pl_kernel<NP, WM, WN, TM, TN, NST, CPS, LW, KG>), grid, dim3(64 * (WM * WN * KG + LW)), 0, s, q);
+        hipLaunchKernelGGL((conv_pl_kernel<NP, WM, WN, TM, TN, NST, CPS, LW, KG, BDIR>), grid, dim3(64 * (WM * WN * KG + LW)), 0, s, q);
 }
 
 template <int NP>
@@ -446,6 +497,13 @@ static void launch_pl_np(const ConvParams& p, int tile, hipStream_t s) {
         case TILE_PL128x64: launch_pl_t<NP, 2, 2, 2, 1, 3, NP == 1 ? 2 : 1>(p, s); break;
         case TILE_PL256x128: launch_pl_t<NP, 4, 2, 2, 2, NP == 1 ? 3 : 2, 1>(p, s); break;
 #ifdef BP_EXPERIMENTAL   // two round-3 forms that are parity-green and bring nothing:
+        // planes for the activations + filter fragments direct from global memory (BDIR): 4 blocks per CU and no in-kernel
+        // operand split, but both waves of a column pair pull the same fragments through the vector-memory path -- alone
+        // within 10 % of the all-DMA tile, in the pipeline 778 against 900 frames/s (K loops 25-35 % longer, in-situ stamps)
+        case TILE_PL64BD:
+            if constexpr (NP == 3) launch_pl_t<3, 2, 2, 1, 1, 3, 1, 0, 1, true>(p, s);
+            else throw Error("the filters-direct plane tile is a bf16x3 tile");
+            break;
         // K groups inside the block (8 waves, two rings): the M <= 1 280 layers at 7.8-24.2 us against 7.7-25.0 us
         case TILE_PL64K2: launch_pl_t<NP, 2, 2, 1, 1, 3, NP == 1 ? 2 : 1, 0, 2>(p, s); break;
         // wave specialisation (4 loader waves): fp16 batch-28 3x3 115 us against 76 us

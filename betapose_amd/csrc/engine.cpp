@@ -394,6 +394,14 @@ static void choose_pl(const ConvParams& c, long long M, int mode, int sk_max, in
     }
     *tile = t; *splits = s;
 }
+#ifdef BP_EXPERIMENTAL   // BP_B3_PL64BD=1: bf16x3 on planes with the filters-direct plane tile (conv_pl.hip BDIR; A/B runs)
+static void pl64_form(const ConvParams& c, int mode, int* tile) {
+    static const bool bd = std::getenv("BP_B3_PL64BD") != nullptr;
+    if (*tile == TILE_PL64 && mode == PREC_BF16X3 && c.wbd && bd) *tile = TILE_PL64BD;
+}
+#else
+static void pl64_form(const ConvParams&, int, int*) {}
+#endif
 
 static void choose_h16(const ConvParams& c, long long M, int mode, int sk_max, int* tile, int* splits) {
     // layers with operand planes (the fp16 mode; bf16x3 under BP_B3_PLANES) run on conv_pl.hip
@@ -402,7 +410,7 @@ static void choose_h16(const ConvParams& c, long long M, int mode, int sk_max, i
 #else
     constexpr bool legacy = false;
 #endif
-    if (conv_pl_eligible(c) && !legacy) { choose_pl(c, M, mode, sk_max, tile, splits); return; }
+    if (conv_pl_eligible(c) && !legacy) { choose_pl(c, M, mode, sk_max, tile, splits); pl64_form(c, mode, tile); return; }
     if (mode == PREC_BF16X3)
         for (const PlanEntry& e : plan_file_entries())
             if (e.M == (int)M && e.CoutPad == c.CoutPad && e.nchunks == c.nchunks && !conv_tile_is_pl(e.tile)) { *tile = e.tile; *splits = e.splits; return; }
@@ -523,7 +531,7 @@ int Net::add_conv(const std::string& name, const Tensor& in, const Tensor& out_v
     c.tickets = nullptr;
     c.stamps = nullptr;
     c.w16 = nullptr; c.w16s = nullptr;
-    c.in16 = nullptr; c.out16 = nullptr; c.wpl = nullptr; c.in16_plane = c.out16_plane = 0; c.out_np = 0; c.abl = 0; c.skip_f32 = 0;
+    c.in16 = nullptr; c.out16 = nullptr; c.wpl = nullptr; c.wbd = nullptr; c.in16_plane = c.out16_plane = 0; c.out_np = 0; c.abl = 0; c.skip_f32 = 0;
     c.pool_out = nullptr;
     c.pf_ptr = nullptr; c.xcd_home = 0; c.xcc_of = nullptr; c.tickets_local = nullptr; c.mtiles = c.n_tiles = c.work_blocks = c.pf_first = 0;
     c.pf_ntn = c.pf_splits = c.pf_cps = c.pf_nchunks = c.pf_tile_stride = c.pf_chunk_bytes = c.pf_cap = 0;
@@ -662,7 +670,7 @@ Net::ActAlloc* Net::find_act(const float* p) {
 void Net::plan_planes(int prec) {
     for (Op& op : ops_) {
         op.out16 = nullptr; op.out16_plane = 0;
-        if (op.type == OP_CONV) { op.conv.in16 = nullptr; op.conv.out16 = nullptr; op.conv.wpl = nullptr; op.conv.out_np = 0; op.conv.in16_plane = op.conv.out16_plane = 0; op.conv.skip_f32 = 0; }
+        if (op.type == OP_CONV) { op.conv.in16 = nullptr; op.conv.out16 = nullptr; op.conv.wpl = nullptr; op.conv.wbd = nullptr; op.conv.out_np = 0; op.conv.in16_plane = op.conv.out16_plane = 0; op.conv.skip_f32 = 0; }
     }
     for (ActAlloc& a : acts_) a.f32_read = true;
     if (prec == PREC_F32) return;
@@ -706,6 +714,18 @@ void Net::plan_planes(int prec) {
                 made = true;
             }
             c.wpl = it->second;
+#ifdef BP_EXPERIMENTAL
+            if (np == 3 && std::getenv("BP_B3_PL64BD")) {   // the filters-direct plane tile's fragment image (TILE_PL64BD)
+                auto ib = store_->wbd3.find(c.w);
+                if (ib == store_->wbd3.end()) {
+                    unsigned short* d = (unsigned short*)store_->arena.alloc_bytes((size_t)3 * c.CoutPad * c.Kpad * sizeof(unsigned short));
+                    launch_f32_to_bf16x3_staged(c.w, d, c.CoutPad, c.Kpad, nullptr, c.Cin);
+                    ib = store_->wbd3.emplace(c.w, d).first;
+                    made = true;
+                }
+                c.wbd = ib->second;
+            }
+#endif
         } else if (op.out) {
             if (ActAlloc* o = find_act(op.out); o && o->planes) {
                 op.out16 = o->planes + (op.out - o->base);
@@ -770,12 +790,13 @@ bool conv_home_layout(int tile, int splits) {
 }
 void conv_prefetch_of(ConvParams& p, const ConvParams& next, int nt, int ns, int nc) {
     p.pf_ptr = nullptr;
-    const bool pl = next.mfma_mode != PREC_F32 && (nt == TILE_PL64) && next.wpl && conv_home_layout(nt, ns);
+    const bool plbd = nt == TILE_PL64BD && next.mfma_mode == PREC_BF16X3 && next.wbd && conv_home_layout(nt, ns);
+    const bool pl = plbd || (next.mfma_mode != PREC_F32 && (nt == TILE_PL64) && next.wpl && conv_home_layout(nt, ns));
     const bool bd = nt == TILE_64x64_BD && next.mfma_mode == PREC_BF16X3 && next.w16s && (ns == 1 || conv_home_layout(nt, ns));
     const int ntn = (next.CoutPad + 63) / 64;
     if (!(pl || bd) || (ntn & (ntn - 1)) != 0 || xcc_base() < 0) return;
     const int np = planes_np(next.mfma_mode);
-    p.pf_ptr = pl ? (const void*)next.wpl : (const void*)next.w16s;
+    p.pf_ptr = plbd ? (const void*)next.wbd : pl ? (const void*)next.wpl : (const void*)next.w16s;
     p.pf_ntn = ntn; p.pf_splits = ns; p.pf_cps = nc; p.pf_nchunks = next.nchunks;
     p.pf_chunk_bytes = np * 4096;                  // 64 filter rows x 32 k x 2 B per plane
     p.pf_tile_stride = next.nchunks * p.pf_chunk_bytes;

@@ -64,6 +64,7 @@ struct WeightStore {
     std::map<const float*, unsigned short*> bf16x3;   // three bf16 planes per filter (PREC_BF16X3)
     std::map<const float*, unsigned short*> bf16x3s;  // ... and their stage-packed copy (filters-direct kernels, conv_kg/rd.hip)
     std::map<const float*, unsigned short*> f16s;     // stage-packed fp16 copy
+    std::map<const float*, unsigned short*> wbd3;         // stage-packed bf16x3 fragments in conv_pl.hip's K order (TILE_PL64BD)
     std::map<const float*, unsigned short*> wpl1, wpl3;   // conv_pl.hip's LDS image of the filters: fp16 / three bf16 planes
     std::mutex f16_mutex;
 };

@@ -242,9 +242,11 @@ def test_conv_filters_direct_is_bit_identical_to_the_staged_kernel(cuda, case, s
 
 
 
-# ---- two round-3 forms of conv_pl.hip that were measured and left out of the product: K groups inside the
-# block (pl64k2: 8 waves, a ring per group, partial sums combined through LDS) and wave specialisation (pl128s: 4 loader waves)
-@pytest.mark.parametrize("tile,splits", [("pl64k2_b3", 1), ("pl64k2_b3", 3), ("pl64k2_f16", 1), ("pl64k2_f16", 2), ("pl128s_b3", 1), ("pl128s_f16", 1)])
+# ---- three round-3 forms of conv_pl.hip that were measured and left out of the product: K groups inside the
+# block (pl64k2: 8 waves, a ring per group, partial sums combined through LDS), wave specialisation (pl128s: 4 loader waves),
+# filter fragments direct from global memory beside activation planes by LDS-DMA (pl64bd)
+@pytest.mark.parametrize("tile,splits", [("pl64k2_b3", 1), ("pl64k2_b3", 3), ("pl64k2_f16", 1), ("pl64k2_f16", 2), ("pl128s_b3", 1), ("pl128s_f16", 1),
+                                          ("pl64bd_b3", 1), ("pl64bd_b3", 2), ("pl64bd_b3", 5)])
 @pytest.mark.parametrize("shape", [(20, 16, 256, 256, 3), (26, 26, 128, 192, 1), (13, 13, 96, 128, 3)])
 def test_conv_pl_round3_experiments(cuda, tile, splits, shape):
     H, W, Cin, Cout, k = shape

@@ -55,8 +55,8 @@ PL = "--pl" in sys.argv            # the operand-plane kernels (conv_pl.hip), th
 if PL:
     TILES = [t + SUF for t in (["pl64", "pl128x64"] + (["pl128", "pl256x128", "pl128s"] if "--big" in sys.argv else []))]
 ENGINE_LIKE = PL                   # residual after the activation + operand planes emitted, as most layers of the networks run
-TILE_ID = {"pl64": 13, "pl128": 14, "pl128x64": 15, "pl256x128": 16, "pl128s": 17, "pl64k2": 18, "64x64": 0, "128x64": 1, "w1x1": 2, "w1x2": 3, "w2x1": 5, "w2x2": 6, "kg1": 7, "kg2": 8, "kg4": 9, "rd4": 10, "rd8": 11, "bd": 12}
-BMN = {"pl64": (64, 64), "pl128": (128, 128), "pl128x64": (128, 64), "pl256x128": (256, 128), "pl128s": (128, 128), "pl64k2": (64, 64), "64x64": (64, 64), "128x64": (128, 64), "w1x1": (64, 64), "w1x2": (64, 128), "w2x1": (128, 64), "w2x2": (128, 128),
+TILE_ID = {"pl64": 13, "pl128": 14, "pl128x64": 15, "pl256x128": 16, "pl128s": 17, "pl64k2": 18, "pl64bd": 19, "64x64": 0, "128x64": 1, "w1x1": 2, "w1x2": 3, "w2x1": 5, "w2x2": 6, "kg1": 7, "kg2": 8, "kg4": 9, "rd4": 10, "rd8": 11, "bd": 12}
+BMN = {"pl64": (64, 64), "pl128": (128, 128), "pl128x64": (128, 64), "pl256x128": (256, 128), "pl128s": (128, 128), "pl64k2": (64, 64), "pl64bd": (64, 64), "64x64": (64, 64), "128x64": (128, 64), "w1x1": (64, 64), "w1x2": (64, 128), "w2x1": (128, 64), "w2x2": (128, 128),
        "kg1": (64, 64), "kg2": (64, 64), "kg4": (64, 64), "rd4": (64, 64), "rd8": (64, 64), "bd": (64, 64)}
 BATCH = int(sys.argv[sys.argv.index("--batch") + 1]) if "--batch" in sys.argv else 1
 dev = torch.device("cuda:0")
