@@ -335,6 +335,8 @@ def layer_classes(det, pose, batch, peak_mode):
         flops, byts = net.op_stats()
         for i, (nm, is_conv) in enumerate(net.op_names()):
             c = cls.setdefault(op_class(nm, is_conv), {"launches": 0, "ms": 0.0, "gflop": 0.0, "MB": 0.0})
+            if int(info[i][1]) == -1:       # launches nothing: the op rides in its producer's epilogue (SE average pools)
+                continue
             c["launches"] += 1
             c["ms"] += float(ms[i])
             c["gflop"] += float(flops[i]) * batch / 1e9

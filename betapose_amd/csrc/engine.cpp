@@ -936,6 +936,9 @@ int Net::profile(int batch, int iters, float* ms, int* info, int cap, hipStream_
     for (auto& e : ev) (void)hipEventDestroy(e);
     for (int i = 0; i < n; ++i) {
         ms[i] = (float)(acc[i] / iters);
+        // an average pool whose slice sums ride in the producing conv's epilogue launches nothing: 0 ms, info tile = -1
+        const bool fused_away = ops_[i].type == OP_AVGPOOL && pooled_by_conv(ops_[i], batch);
+        if (fused_away) ms[i] = 0.f;
         if (info) {
             int tile = 0, splits = 1, cps = 0, vec = 0, conv = ops_[i].type == OP_CONV;
             if (conv) {
@@ -944,7 +947,7 @@ int Net::profile(int batch, int iters, float* ms, int* info, int cap, hipStream_
                 if (ops_[i].conv.mfma_mode != PREC_F32 && tile != TILE_64x64 && tile != TILE_128x64)
                     vec = 1 + ops_[i].conv.mfma_mode;   // 2 fp16 operands, 3 bf16x3 operands
             }
-            info[4 * i] = conv; info[4 * i + 1] = tile; info[4 * i + 2] = vec; info[4 * i + 3] = splits;
+            info[4 * i] = conv; info[4 * i + 1] = fused_away ? -1 : tile; info[4 * i + 2] = vec; info[4 * i + 3] = splits;
         }
     }
     return n;
