@@ -133,10 +133,11 @@ enum ConvTile : int { TILE_64x64 = 0, TILE_128x64 = 1, TILE_W64_1x1 = 2, TILE_W6
                       TILE_PL128 = 14,      // 128x128, 2x2 waves of 64x64
                       TILE_PL128x64 = 15,   // 128x64, 2x2 waves of 64x32
                       TILE_PL256x128 = 16,  // 256x128, 4x2 waves of 64x64
+                      TILE_STEM3 = 20,      // the 3x3 / stride-1 / 3-channel stem as a direct convolution on the vector pipe (conv_igemm.hip stem3x3_kernel)
                       TILE_PL64BD = 19,     // 64x64 on operand planes, filter fragments direct from global memory (conv_pl.hip BDIR; bf16x3)
                       TILE_PL64K2 = 18,     // 64x64, two K groups of 2x2 waves (8 waves, a ring per group): for launches of at most one block per CU
                       TILE_PL128S = 17,     // 128x128, 2x2 compute waves of 64x64 + 4 loader waves (wave specialisation; no K slices)
-                      TILE_LAST = 19 };
+                      TILE_LAST = 20 };
 
 // when non-null, launch_conv brackets the implicit-GEMM kernel itself (not the split-K reduce) with these events
 struct ConvProfHook { hipEvent_t e0, e1; };
@@ -163,6 +164,7 @@ void launch_f32_to_planes(const float* in, int ld, long long pixels, int C, unsi
 void launch_planes_to_f32(const unsigned short* planes, long long plane_elems, int np, float* out, int ld, long long pixels, int C,
                           hipStream_t s);
 int conv_tiles(const ConvParams& p, int tile);   // blocks per K-slice
+bool conv_stem3_eligible(const ConvParams& p);   // conv_igemm.hip: the layer can run on TILE_STEM3
 void conv_grid_setup(ConvParams& q, int bm, int bn);   // fills mtiles / n_tiles / work_blocks / pf_first from M, CoutPad, splits, xcd_home
 int conv_grid_blocks(const ConvParams& q);
 int xcc_base();                                                // engine.cpp: XCC_ID of block 0 (round-robin dispatch), -1: unusable

@@ -605,6 +605,106 @@ __global__ __launch_bounds__(256) void conv_igemm_h_kernel(const ConvParams p) {
 
 thread_local ConvProfHook* g_conv_prof = nullptr;
 
+// =====================================================================================================================
+// The RGB stem of YOLOv3 (conv0: 416x416x3 -> 32, 3x3, stride 1, pad 1; yolo/darknet.py:240-259 with cfg/yolov3 layer 0) as
+// a DIRECT convolution on the vector pipe.  As an implicit GEMM the layer is K = 27, N = 32 on tiles of K = 64 x N = 64 --
+// 4.7x the multiplies, on the fp32 MFMA pipe (157 TFLOP/s): 24.6 us at batch 1 and 546 us at batch 28, the slowest launch
+// of the batched runs at 12-15 TFLOP/s.  Here a lane owns one output pixel and 8 of the output channels (a wave = 64
+// consecutive pixels, the waves of a block = the channel groups): nine 16-B loads of the packed RGBx input per lane
+// (coalesced, zero outside the image), the filters broadcast from LDS, 216 FMAs per lane, then bias / activation / store
+// (fp32 and / or the operand planes of the next layer).  Same sums as the GEMM in a fixed tap-major order.
+// =====================================================================================================================
+template <int CG>   // channel groups of 8 = waves per block
+__global__ __launch_bounds__(64 * CG) void stem3x3_kernel(const ConvParams p) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int cg = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // the filters of the wave's 8 channels are wave-uniform: scalar loads (p.w [CoutPad][Kpad], k = tap * 4 + ci), operands of
+    // the FMAs straight from scalar registers
+    const float* __restrict__ wrow = p.w + (long long)(cg * 8) * p.Kpad;
+    __shared__ f32x4 tile[64 * (2 * CG + 1)];          // the block's 64 pixels x 8 CG channels (+ 16 B per row against bank conflicts)
+    const int m0 = (int)blockIdx.x * 64;
+    const int m = min(m0 + lane, p.M - 1);      // (rows past M compute a duplicate of the last pixel and are not stored)
+    const int hw = p.OH * p.OW;
+    const int b = m / hw, rem = m - b * hw;
+    const int oy = rem / p.OW, ox = rem - oy * p.OW;
+    float acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+    // a tap = one 16-B buffer load at the pixel (RGB frames are 12 B per pixel: the fourth lane is the neighbour's red and
+    // meets no multiply); outside the image the offset is out of range: zeros
+    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.in), 0, (int)min((long long)p.N * p.H * p.W * p.in_ld * 4, (long long)OOB), 0x00020000);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int iy = oy + ky - 1, ix = ox + kx - 1;
+            const bool in_img = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const f32x4 x = buf_load4(rsrcA, in_img ? (unsigned)((((b * p.H + iy) * p.W + ix) * p.in_ld) * 4) : OOB, 0);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(wrow + c * p.Kpad + (ky * 3 + kx) * 4);
+                acc[c] = fmaf(x.x, w.x, acc[c]);
+                acc[c] = fmaf(x.y, w.y, acc[c]);
+                acc[c] = fmaf(x.z, w.z, acc[c]);
+                if (p.Cin == 4) acc[c] = fmaf(x.w, w.w, acc[c]);      // (the packed RGB frames carry three channels)
+            }
+        }
+    // through LDS, so that every lane stores 16 contiguous bytes of a pixel's channel row (a wave covers whole 128-B lines)
+    tile[lane * (2 * CG + 1) + 2 * cg] = f32x4{acc[0], acc[1], acc[2], acc[3]};
+    tile[lane * (2 * CG + 1) + 2 * cg + 1] = f32x4{acc[4], acc[5], acc[6], acc[7]};
+    __syncthreads();
+    const PlaneDesc pd = make_plane_desc(p);
+    const __amdgpu_buffer_rsrc_t rsrcO =
+        __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)min((long long)p.M * p.out_ld * 4, (long long)OOB), 0x00020000);
+    const int q = tid % (2 * CG), n = 4 * q;     // this thread's four channels
+    if (n < p.Cout) {
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int r = pass * 32 + tid / (2 * CG);
+            if (m0 + r >= p.M) break;
+            f32x4 v = tile[r * (2 * CG + 1) + q];
+            v += bias;
+            if (p.act == ACT_LEAKY) {
+                v.x = v.x > 0.f ? v.x : 0.1f * v.x; v.y = v.y > 0.f ? v.y : 0.1f * v.y;
+                v.z = v.z > 0.f ? v.z : 0.1f * v.z; v.w = v.w > 0.f ? v.w : 0.1f * v.w;
+            } else if (p.act == ACT_RELU) {
+                v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
+                v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+            }
+            const unsigned off = (unsigned)(((m0 + r) * p.out_ld + n) * 4);
+            const u32x4 o = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+            if (pd.f32) __builtin_amdgcn_raw_buffer_store_b128(o, rsrcO, (int)off, 0, 0);
+            emit_planes4(pd, v, off >> 1);
+        }
+    }
+}
+
+bool conv_stem3_eligible(const ConvParams& p) {
+    return p.cin_pack == 4 && p.Cin <= 4 && p.in_ld >= p.Cin && p.in_ld <= 4 && p.ksize == 3 && p.stride == 1 && p.pad == 1 && p.OH == p.H && p.OW == p.W &&
+           p.Cout % 4 == 0 && p.Cout <= 64 && p.CoutPad >= ((p.Cout + 7) / 8) * 8 && p.Kpad >= 36 && p.store_mode == ST_NHWC &&
+           p.res == nullptr && p.res_scale == nullptr && (p.out_ld & 3) == 0 && p.pool_out == nullptr &&
+           (long long)p.M * p.out_ld * 4 < (long long)OOB;
+}
+
+static void launch_stem3(const ConvParams& p, hipStream_t s) {
+    BP_CHECK(conv_stem3_eligible(p) && p.splits == 1, "not a 3x3 / stride-1 / packed-RGB stem");
+    const int cg = (p.Cout + 7) / 8;
+    const dim3 grid((p.M + 63) / 64);
+#define BP_STEM(CG_)                                                                                                       \
+    if (g_conv_prof) hipExtLaunchKernelGGL((stem3x3_kernel<CG_>), grid, dim3(64 * CG_), 0, s, g_conv_prof->e0, g_conv_prof->e1, 0, p); \
+    else hipLaunchKernelGGL((stem3x3_kernel<CG_>), grid, dim3(64 * CG_), 0, s, p)
+    switch (cg) {
+        case 1: BP_STEM(1); break;
+        case 2: BP_STEM(2); break;
+        case 4: BP_STEM(4); break;
+        case 8: BP_STEM(8); break;
+        default: throw Error("stem kernel: 8, 16, 32 or 64 output channels");
+    }
+#undef BP_STEM
+}
+
 // the 1-D launch grid of the kernels that take ConvParams::xcd_home / pf_*: [work blocks | padding to 8 | prefetch blocks]
 void conv_grid_setup(ConvParams& q, int bm, int bn) {
     q.mtiles = (q.M + bm - 1) / bm;
@@ -691,7 +791,9 @@ void launch_conv(const ConvParams& p, int tile, hipStream_t s) {
     BP_CHECK((long long)p.N * p.H * p.W * p.in_ld * 4 < (long long)OOB, "activation tensor too large for 32-bit offsets");
     BP_CHECK((long long)p.M * p.out_ld * 4 < (long long)OOB && (p.res == nullptr || (long long)p.M * p.res_ld * 4 < (long long)OOB),
              "output / residual tensor too large for 32-bit offsets");
-    if (conv_tile_is_pl(tile)) {
+    if (tile == TILE_STEM3) {
+        launch_stem3(p, s);
+    } else if (conv_tile_is_pl(tile)) {
         launch_conv_pl(p, tile, s);
     } else if (tile == TILE_64x64_BD && p.mfma_mode == PREC_BF16X3) {
         BP_CHECK(conv_h16_eligible(p) && p.w16s != nullptr, "filters-direct tile needs the stage-packed filter copy and Cin % 32 == 0");

@@ -446,6 +446,13 @@ static bool tile_runs(int tile, const ConvParams& c) {
     return false;
 }
 
+// the 3x3 / stride-1 RGB stem runs as a direct convolution (conv_igemm.hip stem3x3_kernel) unless a tile is forced;
+// BP_NO_STEM3=1: on the fp32 MFMA kernel as before (A/B runs)
+static bool stem3_wanted(const ConvParams& c, int force_tile) {
+    static const bool off = std::getenv("BP_NO_STEM3") != nullptr;
+    return !off && (force_tile < 0 || force_tile == TILE_STEM3) && conv_stem3_eligible(c);
+}
+
 static void choose_launch(const Op& op, int batch, int force_tile, int sk_target, int sk_min_chunks, int sk_max,
                           int* tile, int* splits, int* cps) {
     const int mode = op.conv.mfma_mode;
@@ -462,6 +469,8 @@ static void choose_launch(const Op& op, int batch, int force_tile, int sk_target
             s = 1;
             while (blocks * s < sk_target && c.nchunks / (s + 1) >= sk_min_chunks && s < sk_max) ++s;
         }
+    } else if (stem3_wanted(c, force_tile)) {
+        t = TILE_STEM3;       // the RGB 3x3 stem: direct convolution, no K slices
     } else {
         if (force_tile == TILE_64x64 || force_tile == TILE_128x64) t = force_tile;
         const int bm = conv_tile_bm(t);

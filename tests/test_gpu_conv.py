@@ -340,3 +340,21 @@ def test_conv_xcd_layout_and_prefetch_blocks(cuda, monkeypatch, tile, shape):
     ref = _ref(x, w, b, 1, k // 2, "leaky", None, False)
     tol = 2e-2 if tile.endswith("f16") else 2e-5
     _check(plain.cpu().permute(0, 3, 1, 2), ref, tol=tol * max(1.0, float(ref.abs().mean())))
+
+
+@pytest.mark.parametrize("shape", [(1, 32, 32, 32, "leaky"), (2, 19, 23, 16, "relu"), (1, 52, 40, 64, "linear"), (3, 8, 8, 8, "leaky")])
+def test_conv_stem3_direct(cuda, shape):
+    """The 3x3 / stride-1 / 4-channel-packed stem as a direct convolution on the vector pipe (TILE_STEM3, what the engine
+    plans for YOLO's layer 0): against torch, against the fp32 MFMA kernel, planes included."""
+    N, H, W, Cout, act = shape
+    g = torch.Generator().manual_seed(7300 + H + Cout)
+    x = torch.randn(N, H, W, 4, generator=g)
+    w = torch.randn(Cout, 4, 3, 3, generator=g) / 6
+    b = torch.randn(Cout, generator=g)
+    ref = _ref(x, w, b, 1, 1, act, None, False)
+    out = ops.conv2d_nhwc(x.to(cuda), w, b, pad=1, act=act, tile="stem3")
+    again = ops.conv2d_nhwc(x.to(cuda), w, b, pad=1, act=act, tile="auto")          # auto picks the same kernel
+    mfma = ops.conv2d_nhwc(x.to(cuda), w, b, pad=1, act=act, tile="64x64")
+    assert torch.equal(out, again)
+    _check(out.cpu().permute(0, 3, 1, 2), ref)
+    _check(out.cpu().permute(0, 3, 1, 2), mfma.cpu().permute(0, 3, 1, 2))
