@@ -634,22 +634,24 @@ __global__ __launch_bounds__(64 * CG) void stem3x3_kernel(const ConvParams p) {
     // meets no multiply); outside the image the offset is out of range: zeros
     const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.in), 0, (int)min((long long)p.N * p.H * p.W * p.in_ld * 4, (long long)OOB), 0x00020000);
+    // a REAL loop over the taps (unrolled, hipcc loads all 72 filter quads up front whatever the source order: 288 registers --
+    // scalar ones spilled lane by lane into vector registers, or 256 vector registers at one wave per SIMD; both measured
+    // slower than the MFMA kernel).  Eight waves per SIMD cover the per-tap load latency instead.
+#pragma unroll 1
+    for (int t = 0; t < 9; ++t) {
+        const int ky = (t * 11) >> 5, kx = t - 3 * ky;          // t / 3 for t < 9
+        const int iy = oy + ky - 1, ix = ox + kx - 1;
+        const bool in_img = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const f32x4 x = buf_load4(rsrcA, in_img ? (unsigned)((((b * p.H + iy) * p.W + ix) * p.in_ld) * 4) : OOB, 0);
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int iy = oy + ky - 1, ix = ox + kx - 1;
-            const bool in_img = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            const f32x4 x = buf_load4(rsrcA, in_img ? (unsigned)((((b * p.H + iy) * p.W + ix) * p.in_ld) * 4) : OOB, 0);
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const f32x4 w = *reinterpret_cast<const f32x4*>(wrow + c * p.Kpad + (ky * 3 + kx) * 4);
-                acc[c] = fmaf(x.x, w.x, acc[c]);
-                acc[c] = fmaf(x.y, w.y, acc[c]);
-                acc[c] = fmaf(x.z, w.z, acc[c]);
-                if (p.Cin == 4) acc[c] = fmaf(x.w, w.w, acc[c]);      // (the packed RGB frames carry three channels)
-            }
+        for (int c = 0; c < 8; ++c) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(wrow + c * p.Kpad + t * 4);
+            acc[c] = fmaf(x.x, w.x, acc[c]);
+            acc[c] = fmaf(x.y, w.y, acc[c]);
+            acc[c] = fmaf(x.z, w.z, acc[c]);
+            if (p.Cin == 4) acc[c] = fmaf(x.w, w.w, acc[c]);      // (the packed RGB frames carry three channels)
         }
+    }
     // through LDS, so that every lane stores 16 contiguous bytes of a pixel's channel row (a wave covers whole 128-B lines)
     tile[lane * (2 * CG + 1) + 2 * cg] = f32x4{acc[0], acc[1], acc[2], acc[3]};
     tile[lane * (2 * CG + 1) + 2 * cg + 1] = f32x4{acc[4], acc[5], acc[6], acc[7]};
