@@ -87,7 +87,7 @@ fi
 if has 6; then
 # 6. determinism soak (bit-identical records over 4000 frames under 4-stream load, every precision), BASELINE configs[4]
 #    (eight resident objects, (frame, object) units), files-on-disk harness
-for pr in bf16x3 f32 f16; do python tools/soak_determinism.py --iters 4000 --precision $pr; done > $OUT/${TAG}_soak.txt 2>/dev/null
+{ for pr in bf16x3 f32 f16; do python tools/soak_determinism.py --iters 4000 --precision $pr; done; for pr in bf16x3 f16; do python tools/soak_determinism.py --iters 4000 --precision $pr --latency-mode; done; } 2>/dev/null | grep "^soak" > $OUT/${TAG}_soak.txt
 python tools/occlusion_scale.py --frames 384 > $OUT/${TAG}_occlusion_8obj.txt 2>&1
 for b in 1 2 4; do python evaluate.py --synthetic 768 --outdir /tmp/ev --fused --streams 4 --detbatch $b 2>&1 | grep frames/sec; done > $OUT/${TAG}_evaluate_fused.txt
 fi

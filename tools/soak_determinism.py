@@ -15,6 +15,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=3000)
 ap.add_argument("--streams", type=int, default=4)
 ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3", "f16"])
+ap.add_argument("--latency-mode", action="store_true",
+                help="bp_*_set_prefetch: split-K hand-off inside one XCD's L2 + filter prefetch blocks; the reference pass is taken WITHOUT it, "
+                     "so the soak also proves the mode bit-identical to the default under load")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 blocks = C.parse_cfg_text(C.yolov3_single_cfg_text())
@@ -32,6 +35,10 @@ ref_rec, ref_hm = [], []
 for k in range(S):
     pipes[k].frames.copy_(frames[k]); pipes[k].enqueue(); torch.cuda.synchronize()
     ref_rec.append(pipes[k].results.clone()); ref_hm.append(pipes[k].heatmaps.clone())
+if a.latency_mode:
+    for d_, p_ in zip(dets, poses):
+        d_.set_prefetch(True)
+        p_.set_prefetch(True)
 bad = 0
 for it in range(a.iters):
     for k in range(S):
@@ -45,5 +52,5 @@ for it in range(a.iters):
                 bad += 1
                 d = (pipes[k].heatmaps - ref_hm[k]).abs().max().item()
                 print("MISMATCH iter", it, "stream", k, "max |d hm|", d, flush=True)
-print("soak[%s]: %d iterations x %d streams, mismatching checks: %d" % (a.precision, a.iters, S, bad))
+print("soak[%s%s]: %d iterations x %d streams, mismatching checks: %d" % (a.precision, ", latency mode" if a.latency_mode else "", a.iters, S, bad))
 sys.exit(1 if bad else 0)
