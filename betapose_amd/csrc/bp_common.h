@@ -104,6 +104,11 @@ struct ConvParams {
     // the column sums of its rows (fixed order; the linear, residual-free output = accumulator + bias) to
     // pool_out[tile_m][Cout], which the first fc of the block reads as `in_parts` slice sums (aux_kernels.hip fc_kernel)
     float* pool_out;              // nullptr: none
+    // Hybrid grid (conv_pl.hip, launches with splits == 1 whose tile count leaves the chip badly filled at the end -- 296 tiles
+    // of 256x128 on 256 CUs, 1 184 of 128x128): the first hy_full tiles run whole, the rest are cut hy_splits ways along K
+    // (hy_cps chunks each) and combined by the usual last-arriver reduction, so that the tail of the launch spreads over all
+    // CUs instead of running one more round on a few.  Block b < hy_full: tile b; else tile hy_full + (b - hy_full) / hy_splits.
+    int hy_full, hy_splits, hy_cps;   // hy_splits == 0: off
     int xcd_home;                 // 1: block b -> x = b % 8, i = b / 8: tile (i / splits) * 8 + x, K slice i % splits
     int* xcc_of;                  // [tiles][64] XCC_ID of every K slice of the running launch
     int* tickets_local;           // [tiles] arrival counters of the xcd_home launches (touched by L2-local atomics only)
@@ -168,6 +173,7 @@ bool conv_stem3_eligible(const ConvParams& p);   // conv_igemm.hip: the layer ca
 void conv_grid_setup(ConvParams& q, int bm, int bn);   // fills mtiles / n_tiles / work_blocks / pf_first from M, CoutPad, splits, xcd_home
 int conv_grid_blocks(const ConvParams& q);
 int xcc_base();                                                // engine.cpp: XCC_ID of block 0 (round-robin dispatch), -1: unusable
+bool conv_hybrid_plan(const ConvParams& p, int tile, size_t partial_floats, int* full, int* hs, int* hcps);   // engine.cpp
 bool conv_home_layout(int tile, int splits);                   // engine.cpp: the launch keeps all K slices of a tile on one XCD
 void conv_prefetch_of(ConvParams& p, const ConvParams& next, int next_tile, int next_splits, int next_cps);   // engine.cpp              // work blocks + padding + prefetch blocks
 int conv_tile_bm(int tile);

@@ -555,6 +555,17 @@ int bp_conv2d_planes(const float* d_in, int N, int H, int W, int Cin, const floa
         p.tickets = (int*)net.arena_.alloc_bytes((size_t)(2 + 64) * tiles * sizeof(int));
         BP_HIP(hipMemset(p.tickets, 0, (size_t)(2 + 64) * tiles * sizeof(int)));
     }
+    if (sp == 1 && !std::getenv("BP_CONV_SELF_PREFETCH")) {   // as the engine launches it: hybrid grid when the last round is badly filled
+        const size_t cap = (size_t)8 * 256 * bp::conv_tile_bm(t) * bp::conv_tile_bn(t);     // <= 8 slices of <= 256 tail tiles
+        int full = 0, hs = 0, hcps = 0;
+        if (bp::conv_hybrid_plan(p, t, cap, &full, &hs, &hcps)) {
+            const int tail = bp::conv_tiles(p, t) - full;
+            p.partial = net.arena_.alloc((size_t)hs * tail * bp::conv_tile_bm(t) * bp::conv_tile_bn(t));
+            p.tickets = (int*)net.arena_.alloc_bytes((size_t)tail * sizeof(int));
+            BP_HIP(hipMemset(p.tickets, 0, (size_t)tail * sizeof(int)));
+            p.hy_full = full; p.hy_splits = hs; p.hy_cps = hcps;
+        }
+    }
     if (bp::conv_home_layout(t, sp)) {   // as the engine launches it: all K slices of a tile on one XCD, hand-off through that XCD's L2
         const int tiles = bp::conv_tiles(p, t);
         p.xcd_home = 1;

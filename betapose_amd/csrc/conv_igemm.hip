@@ -712,7 +712,8 @@ void conv_grid_setup(ConvParams& q, int bm, int bn) {
     q.mtiles = (q.M + bm - 1) / bm;
     const int ntn = (q.CoutPad + bn - 1) / bn;
     q.n_tiles = q.mtiles * ntn;
-    q.work_blocks = q.xcd_home ? ((q.n_tiles + 7) / 8) * 8 * q.splits : q.n_tiles * q.splits;
+    q.work_blocks = q.hy_splits > 0 ? q.hy_full + (q.n_tiles - q.hy_full) * q.hy_splits
+                   : q.xcd_home ? ((q.n_tiles + 7) / 8) * 8 * q.splits : q.n_tiles * q.splits;
     q.pf_first = (q.work_blocks + 7) & ~7;
 }
 int conv_grid_blocks(const ConvParams& q) {

@@ -95,7 +95,14 @@ __global__ __launch_bounds__(64 * (WM * WN * KG + LW)) void conv_pl_kernel(const
     const int wm = (LW ? (wave_id < NWC ? wave_id : 0) : wv) / WN, wn = (LW ? (wave_id < NWC ? wave_id : 0) : wv) % WN;
     const int n_tiles_n = (p.CoutPad + BN - 1) / BN;
     int split, tile_id;
-    if (p.xcd_home) {  // all K slices of a tile on one XCD (ConvParams::xcd_home)
+    int my_splits = p.splits, my_cps = p.chunks_per_split;      // K slices of this block's tile (hybrid grids: 1 or hy_splits)
+    if (p.hy_splits > 0 && (int)blockIdx.x >= p.hy_full) {      // hybrid grid: one of the last tiles, cut along K
+        const int e = (int)blockIdx.x - p.hy_full, tl = e / p.hy_splits;
+        tile_id = p.hy_full + tl;
+        split = e - tl * p.hy_splits;
+        my_splits = p.hy_splits;
+        my_cps = p.hy_cps;
+    } else if (p.xcd_home) {  // all K slices of a tile on one XCD (ConvParams::xcd_home)
         const int i = (int)blockIdx.x >> 3, tl = i / p.splits;
         tile_id = tl * 8 + ((int)blockIdx.x & 7);
         if (tile_id >= p.n_tiles) return;                // padding of the last round of tiles
@@ -109,7 +116,7 @@ __global__ __launch_bounds__(64 * (WM * WN * KG + LW)) void conv_pl_kernel(const
     } else {
         // block b runs on XCD b % 8: give every XCD a CONTIGUOUS range of tiles (N-tiles of one M-tile next to each other,
         // neighbouring M-tiles share their halo rows), so the re-reads of an activation tile hit that XCD's L2
-        const int nblk = p.n_tiles ? p.n_tiles : (int)gridDim.x, q = nblk >> 3, r = nblk & 7;
+        const int nblk = p.hy_splits > 0 ? p.hy_full : (p.n_tiles ? p.n_tiles : (int)gridDim.x), q = nblk >> 3, r = nblk & 7;
         const int xcd = (int)blockIdx.x & 7, i = (int)blockIdx.x >> 3;
         split = 0;
         tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
@@ -117,7 +124,7 @@ __global__ __launch_bounds__(64 * (WM * WN * KG + LW)) void conv_pl_kernel(const
     const int tile_n = tile_id % n_tiles_n;
     const int tile_m = tile_id / n_tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int cb_blk = split * p.chunks_per_split, ce_blk = min(p.nchunks, cb_blk + p.chunks_per_split);
+    const int cb_blk = split * my_cps, ce_blk = min(p.nchunks, cb_blk + my_cps);
     const int c_per = (ce_blk - cb_blk + KG - 1) / KG;                // chunks per K group (the last may get fewer, or none)
     const int c_begin = KG > 1 ? min(cb_blk + kgrp * c_per, ce_blk) : cb_blk;
     const int c_end = KG > 1 ? min(c_begin + c_per, ce_blk) : ce_blk;
@@ -320,9 +327,9 @@ __global__ __launch_bounds__(64 * (WM * WN * KG + LW)) void conv_pl_kernel(const
         else acc[i][jn] = HalfOps<NP>::mfma(fa[fs][NP == 1 ? 0 : PA[q]][i], fb[fs][NP == 1 ? 0 : PB[q]][jn], acc[i][jn]);
     };
 
-#define PL_STAMP(k_) if (p.stamps && tid == 0) p.stamps[(long long)(tile_id * p.splits + split) * 8 + (k_)] = bp_clock();
+#define PL_STAMP(k_) if (p.stamps && tid == 0) p.stamps[(long long)(p.hy_splits > 0 ? (int)blockIdx.x : tile_id * p.splits + split) * 8 + (k_)] = bp_clock();
 #define PL_SB() __builtin_amdgcn_sched_barrier(0)
-    if (p.stamps && tid == 0) p.stamps[(long long)(tile_id * p.splits + split) * 8 + 0] = t_entry;
+    if (p.stamps && tid == 0) p.stamps[(long long)(p.hy_splits > 0 ? (int)blockIdx.x : tile_id * p.splits + split) * 8 + 0] = t_entry;
     PL_STAMP(1);   // index math done
     unsigned long long t_wait = 0;     // debug (p.stamps): cycles parked at the stage waits
     // One stage = NSTEP x NMF MFMA slots.  An LDS-DMA instruction costs the issuing wave 60-180 cycles and a wave issues in
@@ -442,7 +449,7 @@ __global__ __launch_bounds__(64 * (WM * WN * KG + LW)) void conv_pl_kernel(const
             });
         __syncthreads();
     }
-    if (p.stamps && tid == 0) p.stamps[(long long)(tile_id * p.splits + split) * 8 + 7] = t_entry + t_wait;   // (read as a duration)
+    if (p.stamps && tid == 0) p.stamps[(long long)(p.hy_splits > 0 ? (int)blockIdx.x : tile_id * p.splits + split) * 8 + 7] = t_entry + t_wait;   // (read as a duration)
 
     const int w_row0 = wm * (32 * TM), w_col0 = wn * (32 * TN);
 #define BP_NT NT
@@ -451,7 +458,13 @@ __global__ __launch_bounds__(64 * (WM * WN * KG + LW)) void conv_pl_kernel(const
 #define BP_TAIL_STAMP(k_) PL_STAMP(k_)
 #define BP_EP_SLABS EP_SLABS_
 #define BP_HAS_ACC has_acc
+#define BP_SPLITS my_splits
+#define BP_SLAB_TILE (p.hy_splits > 0 ? tile_id - p.hy_full : tile_id)
+#define BP_SLAB_TILES (p.hy_splits > 0 ? p.n_tiles - p.hy_full : (p.n_tiles ? p.n_tiles : (int)gridDim.x / p.splits))
 #include "conv_tail.inc"
+#undef BP_SPLITS
+#undef BP_SLAB_TILE
+#undef BP_SLAB_TILES
 #undef BP_HAS_ACC
 #undef BP_EP_SLABS
 #undef BP_NT
@@ -480,8 +493,11 @@ static void launch_pl_t(const ConvParams& p, hipStream_t s) {
     BP_CHECK(BDIR ? p.wbd != nullptr : p.wpl != nullptr, "conv_pl: the filter image of this tile is missing");
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     BP_CHECK(LW == 0 || p.splits == 1, "the wave-specialised operand-plane tiles do not take K slices");
+    BP_CHECK(p.hy_splits == 0 || (p.splits == 1 && !p.xcd_home && LW == 0 && KG == 1 && p.partial != nullptr && p.tickets != nullptr && p.hy_splits >= 2 && p.hy_cps >= 1),
+             "hybrid grid: a one-slice launch with a split-K workspace");
     ConvParams q = p;
     conv_grid_setup(q, BM, BN);
+    BP_CHECK(q.hy_splits == 0 || (q.hy_full >= 0 && q.hy_full < q.n_tiles), "hybrid grid: whole tiles out of range");
     dim3 grid(conv_grid_blocks(q));
     if (g_conv_prof)
         hipExtLaunchKernelGGL((conv_pl_kernel<NP, WM, WN, TM, TN, NST, CPS, LW, KG, BDIR>), grid, dim3(64 * (WM * WN * KG + LW)), 0, s, g_conv_prof->e0, g_conv_prof->e1, 0, q);

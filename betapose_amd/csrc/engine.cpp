@@ -541,7 +541,7 @@ int Net::add_conv(const std::string& name, const Tensor& in, const Tensor& out_v
     c.stamps = nullptr;
     c.w16 = nullptr; c.w16s = nullptr;
     c.in16 = nullptr; c.out16 = nullptr; c.wpl = nullptr; c.wbd = nullptr; c.in16_plane = c.out16_plane = 0; c.out_np = 0; c.abl = 0; c.skip_f32 = 0;
-    c.pool_out = nullptr;
+    c.pool_out = nullptr; c.hy_full = c.hy_splits = c.hy_cps = 0;
     c.pf_ptr = nullptr; c.xcd_home = 0; c.xcc_of = nullptr; c.tickets_local = nullptr; c.mtiles = c.n_tiles = c.work_blocks = c.pf_first = 0;
     c.pf_ntn = c.pf_splits = c.pf_cps = c.pf_nchunks = c.pf_tile_stride = c.pf_chunk_bytes = c.pf_cap = 0;
     c.CoutPad = CoutPad;
@@ -561,9 +561,13 @@ size_t Net::workspace_need() const {
             int tile, splits, cps;
             choose_launch(op, b, force_tile_, sk_target_, sk_min_chunks_, 64, &tile, &splits, &cps);
             // worst case over policies that may be set later: allow up to 64 splits at batch 1
+            ConvParams q = op.conv; q.N = b; q.M = b * q.OH * q.OW; q.splits = splits;
             if (splits > 1) {
-                ConvParams q = op.conv; q.M = b * q.OH * q.OW;
                 need = std::max(need, (size_t)splits * conv_tiles(q, tile) * conv_tile_bm(tile) * conv_tile_bn(tile));
+            } else {   // a hybrid grid parks the slices of its last tiles (ConvParams::hy_*)
+                int full = 0, hs = 0, hcps = 0;
+                if (conv_hybrid_plan(q, tile, (size_t)-1, &full, &hs, &hcps))
+                    need = std::max(need, (size_t)hs * (conv_tiles(q, tile) - full) * conv_tile_bm(tile) * conv_tile_bn(tile));
             }
         }
     }
@@ -794,6 +798,29 @@ int xcc_base() {
 // p's launch carries the prefetch blocks for `next` (launched with tile nt, ns K slices of nc chunks), when next's work
 // blocks of residue x read the N-tiles n == x (mod min(N-tiles, 8)) -- the xcd_home layout, or the plain one-slice grid of the
 // 64x64 filters-direct kernel -- from a filter image that is contiguous per (N-tile, K-slice) pair
+// Hybrid grid of a one-slice conv_pl launch (ConvParams::hy_*): when the launch is ONE block per CU plus a few more (256 < tiles
+// <= 422 on 256 CUs), 256 tiles run whole and the rest are cut along K so that they spread over every CU instead of doubling
+// up on a few.  Measured at batch 28, fp16 (profiles/r03_hybrid_grid.txt): 296 tiles of 256x128 72.2 -> 65.9 us, 280 tiles
+// 124.8 -> 106.1 us, 296 tiles of 128x128 72.5 -> 67.5 us; with several blocks per CU in flight the dispatcher balances the
+// tail by itself and the cut only adds its reduction (1 184 tiles of 128x128: 79.8 -> 98.8 us), so longer grids stay whole.
+// In the PIPELINE it loses -- fp16 batch 28 x 3 streams 3 940-4 010 against 4 060-4 140 frames/s, the other runs unchanged: with
+// other streams' blocks on the CUs there is no "one block per CU" to complete -- so it is OFF unless BP_HYBRID=1 (A/B runs, tests).
+bool conv_hybrid_plan(const ConvParams& p, int tile, size_t partial_floats, int* full, int* hs, int* hcps) {
+    const bool off = std::getenv("BP_HYBRID") == nullptr;
+    if (off || !conv_tile_is_pl(tile) || p.splits != 1 || p.xcd_home || p.nchunks < 16) return false;
+    if (!(tile == TILE_PL64 || tile == TILE_PL128 || tile == TILE_PL128x64 || tile == TILE_PL256x128)) return false;
+    const int T = conv_tiles(p, tile), unit = 256;
+    const int rem = T - unit;
+    if (rem <= 0 || rem * 100 > unit * 65) return false;
+    int s = std::min(std::min(unit / rem, 8), p.nchunks / 8);
+    if (s < 2) return false;
+    const int cps = (p.nchunks + s - 1) / s;
+    s = (p.nchunks + cps - 1) / cps;
+    if ((size_t)s * rem * conv_tile_bm(tile) * conv_tile_bn(tile) > partial_floats) return false;
+    *full = unit; *hs = s; *hcps = cps;
+    return true;
+}
+
 bool conv_home_layout(int tile, int splits) {
     return splits > 1 && splits <= 64 && xcc_base() >= 0 && (tile == TILE_64x64_BD || conv_tile_is_pl(tile));
 }
@@ -859,6 +886,10 @@ void Net::run_op(const Op& op, int batch, hipStream_t s) {
             // a mode, not the default (profiles/r03_prefetch_ab.txt)
             p.xcd_home = (prefetch_ && conv_home_layout(tile, splits)) ? 1 : 0;   // (with four frames in flight it gains nothing even on launches whose tiles divide evenly over the XCDs: 898 against 896)
             p.pool_out = pool_in_epilogue(op, batch, tile) ? op.pool_out : nullptr;
+            p.hy_splits = 0;
+            if (splits == 1 && !p.pool_out && conv_hybrid_plan(p, tile, partial_floats_, &p.hy_full, &p.hy_splits, &p.hy_cps)) {
+                if ((long long)(conv_tiles(p, tile) - p.hy_full) > (long long)tickets_count_) p.hy_splits = 0;
+            }
             p.pf_ptr = nullptr;
             if (prefetch_ && (tile == TILE_64x64_BD || conv_tile_is_pl(tile))) {
                 for (const Op* q = &op + 1; q != ops_.data() + ops_.size(); ++q) {

@@ -358,3 +358,28 @@ def test_conv_stem3_direct(cuda, shape):
     assert torch.equal(out, again)
     _check(out.cpu().permute(0, 3, 1, 2), ref)
     _check(out.cpu().permute(0, 3, 1, 2), mfma.cpu().permute(0, 3, 1, 2))
+
+
+@pytest.mark.parametrize("tile,mode", [("pl128", "f16"), ("pl128", "b3"), ("pl64", "f16"), ("pl64", "b3")])
+def test_conv_pl_hybrid_grid(cuda, monkeypatch, tile, mode):
+    """One-slice launches whose last round would leave the chip badly filled run their last tiles cut along K (ConvParams::hy_*,
+    engine.cpp conv_hybrid_plan): 296 tiles = 256 whole + 40 cut along K here.  Same tolerances as every other
+    launch of the kernel, bit-reproducible, and the emitted planes are the stored output."""
+    monkeypatch.setenv("BP_HYBRID", "1")          # (off by default: it pays on a lone launch, not in the pipeline)
+    g = torch.Generator().manual_seed(9100)
+    H, W, Cin, Cout = (74, 128, 64, 512) if tile != "pl64" else (74, 64, 64, 256)       # pl64: 74 x 4 = 296 tiles too
+    x = torch.randn(1, H, W, Cin, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / 24
+    b = torch.randn(Cout, generator=g)
+    if mode == "f16":
+        x, w = x.half().float(), w.half().float()
+    ref = _ref(x, w, b, 1, 1, "relu", None, False)
+    out, pl = ops.conv2d_nhwc(x.to(cuda), w, b, pad=1, act="relu", tile=tile + "_" + mode, splits=1, planes=True)
+    again = ops.conv2d_nhwc(x.to(cuda), w, b, pad=1, act="relu", tile=tile + "_" + mode, splits=1)
+    assert torch.equal(out, again)
+    monkeypatch.delenv("BP_HYBRID")
+    whole = ops.conv2d_nhwc(x.to(cuda), w, b, pad=1, act="relu", tile=tile + "_" + mode, splits=1)
+    assert not torch.equal(out, whole) and float((out - whole).abs().max()) < 1e-3      # really another summation order
+    exact = (lambda o: o) if mode == "b3" else (lambda o: o.half().float())
+    assert torch.equal(_planes_to_f32(pl, mode), exact(out))
+    _check(out.cpu().permute(0, 3, 1, 2), ref)
