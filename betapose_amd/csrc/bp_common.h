@@ -142,7 +142,11 @@ enum ConvTile : int { TILE_64x64 = 0, TILE_128x64 = 1, TILE_W64_1x1 = 2, TILE_W6
                       TILE_PL64BD = 19,     // 64x64 on operand planes, filter fragments direct from global memory (conv_pl.hip BDIR; bf16x3)
                       TILE_PL64K2 = 18,     // 64x64, two K groups of 2x2 waves (8 waves, a ring per group): for launches of at most one block per CU
                       TILE_PL128S = 17,     // 128x128, 2x2 compute waves of 64x64 + 4 loader waves (wave specialisation; no K slices)
-                      TILE_LAST = 20 };
+                      // conv_halo.hip (round 4): 3x3 / stride 1, the nine taps read from ONE LDS-resident activation halo per 32-channel group;
+                      // 64 rows x 32 columns per wave, filter fragments direct from global memory (bf16x3)
+                      TILE_HALO64 = 21,     // 64x64 block, 2 waves
+                      TILE_HALO128 = 22,    // 64x128 block, 4 waves
+                      TILE_LAST = 22 };
 
 // when non-null, launch_conv brackets the implicit-GEMM kernel itself (not the split-K reduce) with these events
 struct ConvProfHook { hipEvent_t e0, e1; };
@@ -159,6 +163,12 @@ void launch_conv_rd(const ConvParams& p, int tile, hipStream_t s);    // conv_rd
 bool conv_tile_is_rd(int tile);
 void launch_conv_pl(const ConvParams& p, int tile, hipStream_t s);    // conv_pl.hip
 bool conv_tile_is_pl(int tile);
+void launch_conv_halo(const ConvParams& p, int tile, hipStream_t s);  // conv_halo.hip
+bool conv_tile_is_halo(int tile);
+bool conv_halo_eligible(const ConvParams& p, int tile);   // 3x3 / stride 1 / pad 1, Cin % 32 == 0, stage-packed filters, W within the LDS budget
+// K slices of a launch: `want` slices asked for -> slices and chunks per slice the kernel `tile` runs (the halo tiles cut K
+// by whole 32-channel groups = 9 chunks)
+void conv_split_plan(const ConvParams& p, int tile, int want, int* splits, int* cps);
 bool conv_pl_eligible(const ConvParams& p);   // planes + wpl present, Cin % 32 == 0, taps fit the 32-bit mask
 // filters [CoutPad][Kpad] fp32 -> conv_pl.hip's LDS image, np = 1 (fp16) or 3 (exact bf16 split)
 void launch_pack_wpl(const float* in, unsigned short* out, int CoutPad, int Kpad, int Cin, int ksize, int np, hipStream_t s);

@@ -495,7 +495,7 @@ int bp_conv2d_planes(const float* d_in, int N, int H, int W, int Cin, const floa
         net.set_precision(prec);
         net.ops_[0].conv.mfma_mode = prec;
 #ifndef BP_EXPERIMENTAL
-        BP_CHECK(bp::conv_tile_is_pl(t) || (t == bp::TILE_64x64_BD && prec == bp::PREC_BF16X3),
+        BP_CHECK(bp::conv_tile_is_pl(t) || ((t == bp::TILE_64x64_BD || bp::conv_tile_is_halo(t)) && prec == bp::PREC_BF16X3),
                  "this kernel id exists only in the experimental library (python -m betapose_amd.build --experimental, BP_LIB)");
 #endif
     } else {
@@ -546,8 +546,8 @@ int bp_conv2d_planes(const float* d_in, int N, int H, int W, int Cin, const floa
         sp = 1;
         while (blocks * sp < 512 && p.nchunks / (sp + 1) >= 4 && sp < 64) ++sp;
     }
-    int per = (p.nchunks + sp - 1) / sp;
-    sp = (p.nchunks + per - 1) / per;
+    int per = 0;
+    bp::conv_split_plan(p, t, sp, &sp, &per);
     p.splits = sp; p.chunks_per_split = per;
     if (sp > 1) {
         const int tiles = bp::conv_tiles(p, t);

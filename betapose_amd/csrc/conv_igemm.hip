@@ -731,7 +731,7 @@ int conv_tile_bm(int tile) {
 }
 int conv_tile_bn(int tile) {
     switch (tile) {
-        case TILE_W64_1x2: case TILE_W64_2x2: case TILE_PL128: case TILE_PL256x128: case TILE_PL128S: return 128;
+        case TILE_W64_1x2: case TILE_W64_2x2: case TILE_PL128: case TILE_PL256x128: case TILE_PL128S: case TILE_HALO128: return 128;
         default: return 64;
     }
 }
@@ -782,6 +782,15 @@ bool conv_h16_eligible(const ConvParams& p) {   // the fp32-activation 16-bit ke
     return (p.w16 != nullptr || p.w16s != nullptr) && (p.Cin % 32 == 0) && (p.in_ld % 4 == 0) && p.ksize <= 8;
 }
 
+void conv_split_plan(const ConvParams& p, int tile, int want, int* splits, int* cps) {
+    const int unit = conv_tile_is_halo(tile) ? 9 : 1;          // chunks that stay together
+    const int units = p.nchunks / unit;
+    int s = want < 1 ? 1 : (want > units ? units : want);
+    const int per = (units + s - 1) / s;
+    s = (units + per - 1) / per;
+    *splits = s; *cps = per * unit;
+}
+
 int conv_tiles(const ConvParams& p, int tile) {
     const int bm = conv_tile_bm(tile), bn = conv_tile_bn(tile);
     return ((p.M + bm - 1) / bm) * ((p.CoutPad + bn - 1) / bn);
@@ -798,6 +807,8 @@ void launch_conv(const ConvParams& p, int tile, hipStream_t s) {
         launch_stem3(p, s);
     } else if (conv_tile_is_pl(tile)) {
         launch_conv_pl(p, tile, s);
+    } else if (conv_tile_is_halo(tile)) {
+        launch_conv_halo(p, tile, s);
     } else if (tile == TILE_64x64_BD && p.mfma_mode == PREC_BF16X3) {
         BP_CHECK(conv_h16_eligible(p) && p.w16s != nullptr, "filters-direct tile needs the stage-packed filter copy and Cin % 32 == 0");
         BP_CHECK((long long)3 * p.CoutPad * p.Kpad * 2 < (long long)OOB, "filter planes too large for 32-bit offsets");

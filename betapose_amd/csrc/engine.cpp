@@ -440,6 +440,7 @@ static bool tile_runs(int tile, const ConvParams& c) {
     if (tile == TILE_64x64 || tile == TILE_128x64) return true;
     if (conv_tile_is_pl(tile)) return c.mfma_mode != PREC_F32 && conv_pl_eligible(c);
     if (tile == TILE_64x64_BD) return c.mfma_mode == PREC_BF16X3 && conv_h16_eligible(c) && c.w16s != nullptr;
+    if (conv_tile_is_halo(tile)) return c.mfma_mode == PREC_BF16X3 && c.in16 == nullptr && conv_halo_eligible(c, tile);
 #ifdef BP_EXPERIMENTAL
     if (tile >= 0 && tile <= TILE_LAST) return c.mfma_mode != PREC_F32 && conv_h16_eligible(c);
 #endif
@@ -484,8 +485,8 @@ static void choose_launch(const Op& op, int batch, int force_tile, int sk_target
         static const int pct = std::getenv("BP_SPLIT_PCT") ? std::atoi(std::getenv("BP_SPLIT_PCT")) : 100;
         if (pct != 100 && s > 1) s = std::max(1, (s * pct + 50) / 100);
     }
-    int per = (c.nchunks + s - 1) / s;
-    s = (c.nchunks + per - 1) / per;
+    int per = 0;
+    conv_split_plan(c, t, s, &s, &per);
     *tile = t; *splits = s; *cps = per;
 }
 
@@ -866,9 +867,7 @@ void Net::run_op(const Op& op, int batch, hipStream_t s) {
             int tile, splits, cps;
             choose_launch(op, batch, force_tile_, sk_target_, sk_min_chunks_, sk_max_splits_, &tile, &splits, &cps);
             while (splits > 1 && (size_t)splits * conv_tiles(p, tile) * conv_tile_bm(tile) * conv_tile_bn(tile) > partial_floats_) {
-                --splits;
-                cps = (p.nchunks + splits - 1) / splits;
-                splits = (p.nchunks + cps - 1) / cps;
+                conv_split_plan(p, tile, splits - 1, &splits, &cps);
             }
             p.splits = splits; p.chunks_per_split = cps; p.partial = partial_; p.tickets = tickets_;
             p.tickets_local = tickets_ + tickets_count_;

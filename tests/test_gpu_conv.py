@@ -383,3 +383,100 @@ def test_conv_pl_hybrid_grid(cuda, monkeypatch, tile, mode):
     exact = (lambda o: o) if mode == "b3" else (lambda o: o.half().float())
     assert torch.equal(_planes_to_f32(pl, mode), exact(out))
     _check(out.cpu().permute(0, 3, 1, 2), ref)
+
+
+# ---- conv_halo.hip (round 4): 3x3 / stride-1 convolutions with a tap-resident activation halo -- the 64 + 2W + 2 input pixels
+# of a 64-pixel strip parked in LDS once per 32-channel group (three bf16 planes), the nine taps as per-lane LDS row addresses
+# (a shared zero row for taps outside the image), 64x32 outputs per wave, filter fragments direct from global memory.  Same bars
+# as the filters-direct kernel: fp32-accurate, bit-reproducible, every epilogue / store mode, K slices by channel groups.
+HALO_CASES = [
+    # N, H, W, Cin, Cout, act      (all 3x3 / stride 1 / pad 1)
+    (1, 13, 13, 256, 256, "leaky"),      # YOLO 13x13 class, M tail (169 = 2 x 64 + 41)
+    (2, 13, 13, 128, 256, "leaky"),      # batch 2: strips cross the image boundary (338 rows)
+    (1, 26, 26, 64, 128, "leaky"),
+    (1, 52, 52, 32, 128, "leaky"),       # W = 52: three loader passes on the 64x128 tile, six on the 64x64 tile
+    (1, 80, 64, 64, 64, "relu"),         # KPD layer1 class: W = 64 (the widest map either tile takes), Cout = one 64-wide tile
+    (1, 20, 16, 256, 256, "relu"),       # KPD layer3 class
+    (1, 10, 8, 512, 128, "relu"),        # KPD layer4 class: W = 8, M = 80
+    (1, 7, 5, 96, 128, "relu"),          # odd sizes: the whole image inside one strip
+    (3, 9, 11, 32, 192, "linear"),       # one channel group, CoutPad = 192 (64x64 tile only), three images in 5 strips
+    (1, 20, 16, 128, 50, "linear"),      # conv_out class: Cout below the tile
+]
+
+
+def _halo_tiles(cout):
+    return ["halo64"] + (["halo128"] if ((cout + 63) // 64 * 64) % 128 == 0 else [])
+
+
+@pytest.mark.parametrize("case", HALO_CASES)
+@pytest.mark.parametrize("splits", [1, 2, 3])
+def test_conv_halo_bf16x3_is_fp32_accurate(cuda, case, splits):
+    N, H, W, Cin, Cout, act = case
+    if splits > Cin // 32:
+        pytest.skip("fewer channel groups than K slices")
+    g = torch.Generator().manual_seed(2300 + HALO_CASES.index(case))
+    x = torch.randn(N, H, W, Cin, generator=g) * torch.exp(2 * torch.randn(N, H, W, 1, generator=g))   # wide dynamic range
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / np.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g)
+    res = torch.randn(N, H, W, Cout, generator=g)
+    for tile in _halo_tiles(Cout):
+        for after in (False, True):
+            ref64 = _ref(x.double(), w.double(), b.double(), 1, 1, act, res.double(), after)
+            kw = dict(stride=1, pad=1, act=act, res=res.to(cuda), res_after_act=after, splits=splits)
+            out3, pl = ops.conv2d_nhwc(x.to(cuda), w, b, tile=tile + "_b3", planes=True, **kw)
+            out32 = ops.conv2d_nhwc(x.to(cuda), w, b, tile="64x64", **kw)
+            assert torch.equal(out3, ops.conv2d_nhwc(x.to(cuda), w, b, tile=tile + "_b3", **kw))     # fixed summation order
+            assert torch.equal(_planes_to_f32(pl, "b3"), out3)      # the emitted planes ARE the fp32 output, exactly
+            out3, out32 = out3.cpu().permute(0, 3, 1, 2), out32.cpu().permute(0, 3, 1, 2)
+            scale = float(ref64.abs().mean())
+            e3 = float((out3.double() - ref64).abs().max()) / scale
+            e32 = float((out32.double() - ref64).abs().max()) / scale
+            assert e3 <= max(1.5 * e32, 2e-6), (tile, e3, e32)
+            _check(out3, ref64.float(), tol=2e-5 * max(1.0, scale))
+
+
+@pytest.mark.parametrize("tile", ["halo64_b3", "halo128_b3"])
+def test_conv_halo_store_modes(cuda, tile):
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(2, 10, 8, 64, generator=g)
+    w = torch.randn(128, 64, 3, 3, generator=g) / 24
+    b = torch.randn(128, generator=g)
+    ref = _ref(x, w, b, 1, 1, "relu", None, False)
+    xd = x.to(cuda)
+    up = ops.conv2d_nhwc(xd, w, b, pad=1, act="relu", store="up2", tile=tile).cpu().permute(0, 3, 1, 2)
+    _check(up, F.interpolate(ref, scale_factor=2, mode="nearest"))
+    ps = ops.conv2d_nhwc(xd, w, b, pad=1, act="relu", store="pixshuf", tile=tile).cpu().permute(0, 3, 1, 2)
+    _check(ps, F.pixel_shuffle(ref, 2))
+    nc = ops.conv2d_nhwc(xd, w, b, pad=1, act="relu", store="nchw", tile=tile, splits=2).cpu()
+    _check(nc, ref)
+
+
+def test_conv_halo_rejects_what_it_cannot_run(cuda):
+    from betapose_amd import _lib
+    g = torch.Generator().manual_seed(22)
+    for (H, W, Cin, Cout, k, st, tile) in [(16, 16, 64, 64, 1, 1, "halo64_b3"), (16, 16, 64, 64, 3, 2, "halo64_b3"),
+                                           (8, 104, 32, 64, 3, 1, "halo64_b3"), (16, 16, 64, 64, 3, 1, "halo128_b3")]:
+        x = torch.randn(1, H, W, Cin, generator=g)
+        w = torch.randn(Cout, Cin, k, k, generator=g)
+        with pytest.raises(_lib.BetaposeHipError, match="halo tile"):
+            ops.conv2d_nhwc(x.to(cuda), w, None, stride=st, pad=k // 2, tile=tile)
+
+
+def test_conv_halo_full_size_layers(cuda):
+    """Full-size 3x3 layers of both networks on the halo tiles: against the definition (fp64) and the size-independent linearity
+    property, and equal -- up to the summation order -- to the filters-direct kernel."""
+    g = torch.Generator().manual_seed(29)
+    for (H, W, Cin, Cout, tile, splits) in [(52, 52, 128, 256, "halo128", 2), (52, 52, 128, 256, "halo64", 1), (26, 26, 256, 512, "halo128", 4),
+                                            (13, 13, 512, 1024, "halo128", 8), (20, 16, 256, 256, "halo128", 8), (80, 64, 64, 64, "halo64", 2),
+                                            (40, 32, 128, 128, "halo128", 2)]:
+        x1 = torch.randn(1, H, W, Cin, generator=g)
+        x2 = torch.randn(1, H, W, Cin, generator=g)
+        w = torch.randn(Cout, Cin, 3, 3, generator=g) / np.sqrt(Cin * 9)
+        y1 = ops.conv2d_nhwc(x1.to(cuda), w, None, pad=1, tile=tile + "_b3", splits=splits)
+        y2 = ops.conv2d_nhwc(x2.to(cuda), w, None, pad=1, tile=tile + "_b3", splits=splits)
+        y3 = ops.conv2d_nhwc((2.0 * x1 + x2).to(cuda), w, None, pad=1, tile=tile + "_b3", splits=splits)
+        assert float((y3 - (2.0 * y1 + y2)).abs().max()) < 5e-5
+        ref = F.conv2d(x1.double().permute(0, 3, 1, 2), w.double(), padding=1).float()
+        _check(y1.cpu().permute(0, 3, 1, 2), ref)
+        bd = ops.conv2d_nhwc(x1.to(cuda), w, None, pad=1, tile="bd_b3", splits=splits)
+        assert float((y1 - bd).abs().max()) < 2e-5
