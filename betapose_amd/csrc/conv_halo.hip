@@ -20,7 +20,7 @@
 //     per 768 MFMA cycles a block moves 24 KB of filters + 1.4-2.4 KB of activations through the vector-memory path
 //     (33 B/clk/CU against 85) and issues a third of the split VALU;
 //   * filter fragments two taps ahead in a three-deep register ring, the next channel group's halo in flight from the
-//     start of the current group and split / parked in the other LDS stage under the MFMAs of taps 3..; one block-wide
+//     start of the current group and split / parked in the other LDS stage under the MFMAs of taps .. 7; one block-wide
 //     barrier per channel group (216 MFMAs per wave).
 // K slices are ranges of channel groups (all nine taps of a group stay in one block).  Split-K hand-off and the fused
 // epilogue are the shared conv_tail.inc (same 64-row M tiles as the other kernels: slabs, pooled epilogue, residuals,
@@ -206,8 +206,9 @@ __global__ __launch_bounds__(64 * NW) void conv_halo_kernel(const ConvParams p) 
                         acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                             fr[par][PA[q]][i], __builtin_bit_cast(frag_t, rb[tap % 3][PB[q]][ks]), acc[i][0], 0, 0, 0);
             });
-            // the next group's halo: one loader pass per tap from tap 3 on (its loads are a few thousand cycles old by then)
-            if constexpr (tap >= 3 && tap - 3 < NPASS) park_a(std::integral_constant<int, tap - 3>{}, so_nxt);
+            // the next group's halo: one loader pass per tap, the last one behind tap 7 (all of them parked before the barrier
+            // inside tap 8; their loads are a few thousand cycles old by then)
+            if constexpr (tap <= 7 && tap >= 8 - NPASS) park_a(std::integral_constant<int, tap - (8 - NPASS)>{}, so_nxt);
         });
         const unsigned t_ = so_cur; so_cur = so_nxt; so_nxt = t_;
     }

@@ -783,7 +783,7 @@ bool conv_h16_eligible(const ConvParams& p) {   // the fp32-activation 16-bit ke
 }
 
 void conv_split_plan(const ConvParams& p, int tile, int want, int* splits, int* cps) {
-    const int unit = conv_tile_is_halo(tile) ? 9 : 1;          // chunks that stay together
+    const int unit = (conv_tile_is_halo(tile) && p.nchunks % 9 == 0 && p.nchunks >= 9) ? 9 : 1;          // chunks that stay together (a layer the halo tiles cannot run is refused by the launcher)
     const int units = p.nchunks / unit;
     int s = want < 1 ? 1 : (want > units ? units : want);
     const int per = (units + s - 1) / s;

@@ -101,6 +101,14 @@ static const SplitEntry kSplitTable[] = {
 // other shapes use the heuristic in choose_h16.
 struct PlanEntry { int M, CoutPad, nchunks, tile, splits; };
 static const PlanEntry kPlanB3[] = {
+    // round 4, conv_halo.hip: the 3x3 / stride-1 layers on the tap-resident halo tile -- rows apply where conv_halo_eligible()
+    // holds (a stride-2 layer of the same {M, CoutPad, K-chunks} falls through to its filters-direct row below).  Slice counts from
+    // A/B runs of the whole pipeline, four frames in flight (profiles/r04_halo_ab.txt)
+    {   169,  1024,  144, TILE_HALO128,  8},
+    {   320,  1024,  144, TILE_HALO128,  6},
+    {   676,   512,   72, TILE_HALO128,  4},
+    {  1280,   512,   72, TILE_HALO128,  3},
+    {  2704,   256,   36, TILE_HALO128,  2},
     {    80,   512,   64, TILE_64x64_BD,  6},
     {    80,   512,  144, TILE_64x64_BD, 10},
     {    80,  2048,   16, TILE_64x64_BD,  3},
@@ -413,13 +421,16 @@ static void choose_h16(const ConvParams& c, long long M, int mode, int sk_max, i
     if (conv_pl_eligible(c) && !legacy) { choose_pl(c, M, mode, sk_max, tile, splits); pl64_form(c, mode, tile); return; }
     if (mode == PREC_BF16X3)
         for (const PlanEntry& e : plan_file_entries())
-            if (e.M == (int)M && e.CoutPad == c.CoutPad && e.nchunks == c.nchunks && !conv_tile_is_pl(e.tile)) { *tile = e.tile; *splits = e.splits; return; }
+            if (e.M == (int)M && e.CoutPad == c.CoutPad && e.nchunks == c.nchunks && !conv_tile_is_pl(e.tile) &&
+                (!conv_tile_is_halo(e.tile) || conv_halo_eligible(c, e.tile))) { *tile = e.tile; *splits = e.splits; return; }
+    static const bool halo_off = std::getenv("BP_NO_HALO") != nullptr;   // A/B runs: the round-3 plan (filters-direct kernel everywhere)
 #ifdef BP_EXPERIMENTAL
     for (const PlanEntry* e = (mode == PREC_F16 ? kPlanF16 : kPlanB3); e->M != 0; ++e)   // tables end with a zero row
 #else
     for (const PlanEntry* e = kPlanB3; e->M != 0; ++e)
 #endif
-        if (e->M == (int)M && e->CoutPad == c.CoutPad && e->nchunks == c.nchunks) { *tile = e->tile; *splits = e->splits; return; }
+        if (e->M == (int)M && e->CoutPad == c.CoutPad && e->nchunks == c.nchunks &&
+            (!conv_tile_is_halo(e->tile) || (!halo_off && mode == PREC_BF16X3 && conv_halo_eligible(c, e->tile)))) { *tile = e->tile; *splits = e->splits; return; }
     int t = TILE_64x64_BD;   // bf16x3: the filters-direct 64x64 kernel at every batch size (profiles/r02_tune_b3_batch28.txt)
 #ifdef BP_EXPERIMENTAL
     const long long tiles128 = ((M + 127) / 128) * ((c.CoutPad + 127) / 128);

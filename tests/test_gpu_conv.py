@@ -432,7 +432,10 @@ def test_conv_halo_bf16x3_is_fp32_accurate(cuda, case, splits):
             e3 = float((out3.double() - ref64).abs().max()) / scale
             e32 = float((out32.double() - ref64).abs().max()) / scale
             assert e3 <= max(1.5 * e32, 2e-6), (tile, e3, e32)
-            _check(out3, ref64.float(), tol=2e-5 * max(1.0, scale))
+            # element-wise bar, sound under cancellation (the per-pixel scales spread over e^+-6, so small outputs sit next to large
+            # addends): |error| <= 1e-5 x the sum of the |terms| that made the element (fp32 accumulation of K <= 4608 terms)
+            terms = F.conv2d(x.abs().double().permute(0, 3, 1, 2), w.abs().double(), b.abs().double(), padding=1) + res.abs().double().permute(0, 3, 1, 2)
+            assert bool(((out3.double() - ref64).abs() <= 1e-5 * terms + 1e-6).all()), tile
 
 
 @pytest.mark.parametrize("tile", ["halo64_b3", "halo128_b3"])
