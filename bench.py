@@ -56,6 +56,8 @@ def parse_args():
                          "the same workload and report them under \"other_precisions\" (never as \"value\"); '' = skip")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-side-runs", action="store_true", help="skip the one-frame-at-a-time and H2D-inclusive runs")
+    ap.add_argument("--no-flip-rate", action="store_true", help="skip the planted-margin flip-rate object")
+    ap.add_argument("--no-served-legs", action="store_true", help="skip the configs[2] leg (fp16, 28 frames per launch x 3 streams) and the other_configs lines")
     ap.add_argument("--repeats", type=int, default=5,
                     help="K-step timed regions run back to back: `value` is the FIRST (the contract's region), \"repeats\" "
                          "reports p50 / min / max over all of them")
@@ -191,6 +193,40 @@ class ClockSampler:
         import threading
         self.period, self.samples, self._stop = period, [], threading.Event()
         self._t = threading.Thread(target=self._loop, daemon=True)
+        self.before = self.after = None
+        self.t_before = self.t_after = 0.0
+
+    @staticmethod
+    def _smi_json(*flags):
+        import subprocess
+        try:
+            out = subprocess.run(["amd-smi", "metric", "-g", "0", *flags, "--json"], capture_output=True, text=True, timeout=10).stdout
+            d = json.loads(out[out.index("{"):])
+            d = d.get("gpu_data", d) if isinstance(d, dict) else d
+            return d[0] if isinstance(d, list) else d
+        except Exception:
+            return None
+
+    @classmethod
+    def _snapshot(cls):
+        """The SMU's throttle accumulators (one count per sample interval in which the limiter was active) and the socket's
+        energy counter: amd-smi metric --throttle / --energy."""
+        snap = {}
+        t = cls._smi_json("--throttle")
+        if t and isinstance(t.get("throttle"), dict):
+            for k, v in t["throttle"].items():
+                if k.endswith("_accumulated") or k == "accumulation_counter":
+                    if isinstance(v, dict):            # per XCC: {"xcp_0": [...]}
+                        v = [x for lst in v.values() if isinstance(lst, list) for x in lst if isinstance(x, (int, float))]
+                        v = sum(v) / len(v) if v else None
+                    if isinstance(v, (int, float)):
+                        snap[k] = float(v)
+        e = cls._smi_json("--energy")
+        try:
+            snap["energy_J"] = float(e["energy"]["total_energy_consumption"]["value"])
+        except Exception:
+            pass
+        return snap
 
     def _loop(self):
         import re
@@ -207,12 +243,35 @@ class ClockSampler:
             self._stop.wait(self.period)
 
     def __enter__(self):
+        self.before, self.t_before = self._snapshot(), time.perf_counter()
         self._t.start()
         return self
 
     def __exit__(self, *exc):
+        self.after, self.t_after = self._snapshot(), time.perf_counter()
         self._stop.set()
         self._t.join(timeout=6)
+
+    def limits(self, frames):
+        """Which limiter the SMU reports for the sampled window (accumulator deltas over the window's sample count) and the
+        socket energy per frame.  None when amd-smi gave nothing."""
+        if not self.before or not self.after:
+            return None
+        n = self.after.get("accumulation_counter", 0.0) - self.before.get("accumulation_counter", 0.0)
+        out = {"window_s": round(self.t_after - self.t_before, 2), "smu_samples": int(n)}
+        active = {}
+        for k, v in self.after.items():
+            if k.endswith("_accumulated") and k in self.before:
+                d = v - self.before[k]
+                if d > 0:
+                    active[k[:-len("_accumulated")]] = round(d / n, 4) if n > 0 else d
+        out["limiters_active_fraction_of_samples"] = active
+        out["throttle_reason"] = (max(active, key=active.get) if active else "none reported (no accumulator advanced)")
+        if "energy_J" in self.after and "energy_J" in self.before and frames > 0:
+            out["joules_per_frame"] = round((self.after["energy_J"] - self.before["energy_J"]) / frames, 4)
+            out["mean_socket_W_from_energy"] = round((self.after["energy_J"] - self.before["energy_J"]) / max(self.t_after - self.t_before, 1e-9), 1)
+        out["limits_source"] = "amd-smi metric --throttle / --energy, before and after the sampled window (accumulators count SMU samples with the limiter active)"
+        return out
 
     def summary(self):
         busy = [x for x in self.samples if x[1] > 400.0] or self.samples       # samples taken while the pipeline was loaded
@@ -221,6 +280,17 @@ class ClockSampler:
         clk, pw = sorted(x[0] for x in busy), sorted(x[1] for x in busy)
         return {"sclk_MHz_p50": clk[len(clk) // 2], "sclk_MHz_min": clk[0], "package_W_p50": pw[len(pw) // 2], "package_W_max": pw[-1],
                 "samples": len(busy), "source": "rocm-smi --showclocks --showpower, polled during the timed regions (GPU 0)"}
+
+
+def _power_cap_w():
+    import re
+    import subprocess
+    try:
+        out = subprocess.run(["rocm-smi", "--showmaxpower"], capture_output=True, text=True, timeout=5).stdout
+        m = re.search(r"GPU\[0\]\s*:[^\n]*Power \(W\):\s*([0-9.]+)", out)
+        return float(m.group(1)) if m else None
+    except Exception:
+        return None
 
 
 def _cpu_model():
@@ -268,6 +338,8 @@ def roofline(det, pose, batch):
             return "bp::conv_pl_kernel<%d, %s>" % (np_, PL_TILE_ARGS[tile][np_])
         if tile == 12:
             return "bp::conv_igemm_h_kernel<1, 1, 3, true>"        # filters direct
+        if tile in (21, 22):
+            return "bp::conv_halo_kernel<%d, *>" % (2 if tile == 21 else 4)   # tap-resident halo (conv_halo.hip); * = loader passes, by map width
         if tile in (7, 8, 9):
             return "bp::conv_kg_kernel<%d, 3>" % {7: 1, 8: 2, 9: 4}[tile]
         if tile in (10, 11):
@@ -276,7 +348,15 @@ def roofline(det, pose, batch):
             return "bp::conv_w64_kernel<%s, %d>" % (TILE_NAMES.get(tile, "?"), np_)
         return "bp::conv_igemm_h_kernel<%s, %d, false>" % (TILE_NAMES.get(tile, "?"), np_)
     name = kernel_name(key[0], mode)
-    want = name.split(">")[0]
+    want = name.split(">")[0].split(", *")[0]
+    peak_of = {"f32": PEAK_FP32_MFMA_TFLOPS, "f16": PEAK_F16_MFMA_TFLOPS, "bf16x3": PEAK_BF16X3_TFLOPS}
+    per_kernel = []
+    for k_, g_ in sorted(groups.items(), key=lambda kv: -kv[1]["ms"]):
+        m_ = {2: "f16", 3: "bf16x3"}.get(k_[1], "f32")
+        tf_ = g_["flops"] / (g_["ms"] * 1e-3) / 1e12
+        per_kernel.append({"kernel": kernel_name(k_[0], m_) if m_ != "f32" else ("bp::stem3x3_kernel" if k_[0] == 20 else "bp::conv_igemm_kernel<1, 1, %d>" % k_[1]),
+                           "launches": g_["launches"], "us_per_step": round(g_["ms"] * 1e3, 1), "avg_launch_us": round(g_["ms"] / g_["launches"] * 1e3, 2),
+                           "gflop": round(g_["flops"] / 1e9, 2), "achieved_TFLOPs": round(tf_, 1), "frac": round(tf_ / peak_of[m_], 4)})
     try:
         import glob
         for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic*.json")))[::-1]:
@@ -303,6 +383,7 @@ def roofline(det, pose, batch):
                      "frac": round(achieved / peak, 4),
                      "all_conv": {"achieved": round(conv_flops / (conv_ms * 1e-3) / 1e12, 2), "ms_per_step": round(conv_ms, 4)},
                      "device_ms_per_step_eager_sum": round(total_ms, 4)},
+        "kernels": per_kernel,
         "gflop_per_step": round(conv_flops / 1e9, 2), **extra,
         "layer_classes": layer_classes(det, pose, batch, peak),
         "algorithmic_bytes_per_step": sum(float(n_.op_stats()[1].sum()) for n_ in (det, pose)),
@@ -467,6 +548,75 @@ def insitu_layers(dets, poses, run, S, batch, path, precision):
     return summary
 
 
+def served_leg(ys, ks, local, batch, streams, precision, steps, kp3d, cam_K, label):
+    """One more line of the same hot path with `batch` frames per launch on `n_streams` streams (the reference's --detbatch,
+    dataloader.py:284-289): its own engines (max_batch = batch), frames resident in HBM, host tail inside the timed region,
+    barrier-free single-GPU timing (synchronize both sides).  Returns frames/s, ms per step and the convolution GFLOP per frame."""
+    import torch
+    from betapose_amd.darknet import Darknet
+    from betapose_amd.kpd import FastPoseHIP
+    from betapose_amd.pipeline import FramePipeline, finish_record
+    from betapose_amd import synth
+    dev = torch.device("cuda", local)
+    det = Darknet("yolo/cfg/yolov3-single.cfg", reso=416, max_batch=batch, device=local)
+    det.load_stream(ys)
+    pose = FastPoseHIP.from_stream(ks, n_classes=50, max_batch=batch, device=local)
+    det.cuda(); pose.cuda()
+    det.set_precision(precision); pose.set_precision(precision)
+    # the HIP streams of the main run are reused: streams created now would share hardware queues unevenly with them (the runtime
+    # maps streams onto 4 queues round robin; measured here: 686 instead of 1 110 frames/s at 2 x 4 with fresh streams)
+    S = len(streams)
+    dets = [det] + [det.clone() for _ in range(S - 1)]
+    poses = [pose] + [pose.clone() for _ in range(S - 1)]
+    pipes = [FramePipeline(dets[k], poses[k], 480, 640, batch=batch, confidence=0.01, num_classes=80, use_graph=True) for k in range(S)]
+    pool = [torch.from_numpy(np.stack(synth.synth_frames(batch, 4321 + 37 * j))).to(dev) for j in range(4)]
+    NS = 2 * S
+    pinned = [torch.empty((batch, pipes[0].results.shape[1]), dtype=torch.float32).pin_memory() for _ in range(NS)]
+    events = [torch.cuda.Event() for _ in range(NS)]
+    got = {"poses": 0}
+
+    def issue(i):
+        k = i % S
+        with torch.cuda.stream(streams[k]):
+            pipes[k].frames.copy_(pool[i % len(pool)], non_blocking=True)
+            pipes[k].enqueue(streams[k].cuda_stream)
+            pinned[i % NS].copy_(pipes[k].results, non_blocking=True)
+            events[i % NS].record(streams[k])
+
+    def finish(i):
+        events[i % NS].synchronize()
+        rec = pinned[i % NS].numpy()
+        for b in range(batch):
+            got["poses"] += len(finish_record(rec[b], "%06d.png" % (i * batch + b), kp3d, cam_K)["result"]) > 0
+
+    def run(n):
+        for i in range(n):
+            issue(i)
+            if i >= S:
+                finish(i - S)
+        for i in range(max(0, n - S), n):
+            finish(i)
+
+    run(max(2 * S, 8))                       # graphs captured, buffers touched
+    torch.cuda.synchronize()
+    tw = time.perf_counter()
+    run(max(2 * S, 8))                       # warm, and the step time the timed region is sized from (>= `steps`, >= ~1.5 s)
+    torch.cuda.synchronize()
+    tw = (time.perf_counter() - tw) / max(2 * S, 8)
+    steps = int(min(max(steps, 1.5 / max(tw, 1e-6)), 4000))
+    t0 = time.perf_counter()
+    run(steps)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    gflop = sum(float(n_.op_stats()[0].sum()) for n_ in (det, pose)) / 1e9          # conv FLOPs per frame (op_stats is per image)
+    alg_bytes = sum(float(n_.op_stats()[1].sum()) for n_ in (det, pose))
+    res = {"label": label, "value": round(steps * batch / el, 2), "unit": "frames/sec", "batch": batch, "streams": S, "precision": precision,
+           "steps": steps, "ms_per_step": round(el / steps * 1e3, 4), "poses": got["poses"], "graph_nodes": pipes[0].kernel_count()}
+    del pipes, dets, poses, det, pose
+    torch.cuda.synchronize()
+    return res, gflop, alg_bytes
+
+
 def main():
     a = parse_args()
     import torch
@@ -495,7 +645,6 @@ def main():
     det = Darknet("yolo/cfg/yolov3-single.cfg", reso=416, max_batch=a.batch, device=local)
     det.load_stream(ys)
     pose = FastPoseHIP.from_stream(ks, n_classes=50, max_batch=a.batch, device=local)
-    del ys, ks
     det.cuda()
     pose.cuda()
 
@@ -575,10 +724,10 @@ def main():
         for i in range(max(0, nsteps - d), nsteps):
             finish(i, keep)
 
-    # the W warm-up steps asked for, and never fewer than ~60 frames: the device's clock / power state and the four streams'
-    # stagger need that long to settle (K = 20, one box: 902-912 frames/s after 5 warm-up steps, 933-938 after 60);
-    # untimed either way, reported as `warmup_steps_run`
-    warmup_run = max(a.warmup, -(-60 // max(a.batch, 1)), 1)
+    # exactly the W warm-up steps asked for (round 4; rounds 2-3 ran at least 60): `value` is the K-step region right behind
+    # them.  The device's clock / power state and the streams' stagger settle over ~60 frames (K = 20, one box: 902-912
+    # frames/s after 5 warm-up steps, 933-938 after 60) -- that figure is reported beside it as `value_settled`
+    warmup_run = max(a.warmup, 1)
     run(warmup_run, False)
     torch.cuda.synchronize()
     bpd.barrier()
@@ -601,7 +750,13 @@ def main():
     # ---- more K-step regions, back to back, each bracketed like the first (barrier + synchronize both sides, max over
     # ranks): a single 20-step region is a 20 ms window
     region_fps = [world * a.steps * a.batch / el]
-    for _ in range(max(0, a.repeats - 1)):
+    # regions that START after >= 60 frames have run are "settled"; at least three of those (short regions: a few more)
+    frames_before = [warmup_run * a.batch]
+    n_regions = max(1, a.repeats)
+    while sum(1 for i in range(n_regions) if (warmup_run + i * a.steps) * a.batch >= 60) < 3 and n_regions < 16:
+        n_regions += 1
+    for _ in range(n_regions - 1):
+        frames_before.append(frames_before[-1] + a.steps * a.batch)
         torch.cuda.synchronize()
         bpd.barrier()
         torch.cuda.synchronize()
@@ -650,6 +805,10 @@ def main():
             t_c = time.perf_counter() - t_c
         if cs.summary():
             side["clocks"] = dict(cs.summary(), frames_per_sec_meanwhile=round(n_c * a.batch / t_c, 1))
+            lim = cs.limits(n_c * a.batch)
+            if lim:
+                side["clocks"]["power_cap_W"] = _power_cap_w()
+                side["clocks"].update(lim)
         src["pool"] = pool_host
         n2 = min(a.steps, 200)
         run(2 * S, False)
@@ -670,6 +829,7 @@ def main():
         out = {
             "metric": "frames/sec (640x480, 50-kp KPD)", "value": round(frames_total / el, 2), "unit": "frames/sec",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "warmup_steps_run": warmup_run, "ms_per_step": round(el / a.steps * 1e3, 4),
+            "value_settled": round(float(np.percentile([v for v, fb in zip(region_fps, frames_before) if fb >= 60] or region_fps, 50)), 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"f32": "f32", "f16": "f16 MFMA operands, f32 accumulate and activations",
                       "bf16x3": "f32 as an exact 3-way bf16 operand split (6 bf16 MFMA products), f32 accumulate and "
@@ -690,7 +850,8 @@ def main():
             **({"clocks_under_load": side["clocks"]} if "clocks" in side else {}),
             "repeats": {"regions": len(region_fps), "steps_each": a.steps, "fps": [round(v, 2) for v in region_fps],
                         "p50": round(float(np.percentile(region_fps, 50)), 2), "min": round(min(region_fps), 2),
-                        "max": round(max(region_fps), 2), "note": "`value` is region 0"},
+                        "max": round(max(region_fps), 2), "frames_run_before_each": frames_before,
+                        "note": "`value` is region 0 (right behind the commanded warm-up); `value_settled` = p50 of the regions that started after >= 60 frames"},
             "detections": stats["det"], "poses": stats["pose"],
             "records_gathered": int((gathered[:, 0].view(np.int32) >= -1).sum()) if gathered is not None else 0,
         }
@@ -743,6 +904,27 @@ def main():
         other["note"] = ("bf16x3 = fp32-accurate (exact 3-way bf16 operand split, passes the whole parity suite); "
                          "f16 = fp16 operands (stated-tolerance mode, BASELINE configs[2])")
         out["other_precisions"] = other
+    if rank == 0 and world == 1 and not a.no_served_legs and len(streams) >= 4 and not a.partition:
+        # BASELINE configs[2] on the driver's clock: fp16 MFMA operands, 28 crops / frames per launch, 3 streams
+        c2, gf, ab = served_leg(ys, ks, local, 28, streams[:3], "f16", max(30, min(a.steps, 60)), kp3d, cam_K,
+                                "BASELINE configs[2]: batched inference, 28 frames per launch x 3 streams, fp16 MFMA conv path")
+        tf = gf * c2["value"] / 1e3
+        c2["roofline"] = {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_F16_MFMA_TFLOPS, 4),
+                          "gflop_per_frame": round(gf, 2), "definition": "algorithmic conv FLOPs of the timed steps / wall clock, all streams",
+                          "hbm": {"algorithmic_GBps": round(ab * c2["value"] / 1e9, 1), "peak": PEAK_HBM_GBPS, "frac_algorithmic": round(ab * c2["value"] / 1e9 / PEAK_HBM_GBPS, 4),
+                                  "note": "algorithmic bytes per frame (fp32 operands and results, weights once per frame) x frames/s; counter bytes: profiles/*_pmc_frame_traffic_f16*.json"}}
+        out["configs2"] = c2
+        # served-stream lines of the default precision with several frames per launch: NOT configs[1] (whose batch is 1)
+        oc = []
+        for b_, s_ in ((2, 4), (4, 3)):
+            r_, _, _ = served_leg(ys, ks, local, b_, streams[:s_], a.precision, max(30, min(a.steps, 100)), kp3d, cam_K,
+                                  "not configs[1]: %d frames per launch x %d streams (--detbatch %d)" % (b_, s_, b_))
+            oc.append(r_)
+        out["other_configs"] = oc
+    if rank == 0 and world == 1 and not a.no_flip_rate:
+        # low-margin flip rate of the arg-max stages per arithmetic (betapose_amd/fliprate.py; asserted in tests/test_gpu_flip_rate.py)
+        from betapose_amd import fliprate
+        out["flip_rate"] = fliprate.measure(device="cuda:%d" % local, trials=2)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.cpu_seconds, kp3d, cam_K)
     if rank == 0:

@@ -88,7 +88,10 @@ __device__ __forceinline__ int xcc_id() {
 __device__ __forceinline__ void xcd_home_mark(const ConvParams& p, int tile_id, int split) {
     if (threadIdx.x == 0) __hip_atomic_store(&p.xcc_of[tile_id * 64 + split], xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// in the reducing block: every slice of the tile must have run on this block's XCD
+// in the reducing block: every slice of the tile must have run on this block's XCD.  A mismatch TRAPS: the whole HIP context
+// (every stream of the process) is lost, not just this launch -- which is why the layout is used in the opt-in latency mode only,
+// on ordinary (unmasked) streams whose dispatch the one-time probe (engine.cpp xcc_base) has seen to be round robin; bench.py
+// never combines it with --partition (CU-masked queues)
 __device__ __forceinline__ void xcd_home_verify(const ConvParams& p, int tile_id) {
     if ((int)threadIdx.x < p.splits &&
         __hip_atomic_load(&p.xcc_of[tile_id * 64 + (int)threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != xcc_id())

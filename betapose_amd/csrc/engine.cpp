@@ -448,9 +448,13 @@ static void choose_h16(const ConvParams& c, long long M, int mode, int sk_max, i
 // a forced kernel id (bp_*_set_policy, tests and sweeps) applies to the layers it can run and is ignored for the others:
 // the fp32-MFMA tiles run any layer (they read the fp32 activations), the operand-plane tiles the layers with planes
 static bool tile_runs(int tile, const ConvParams& c) {
-    if (tile == TILE_64x64 || tile == TILE_128x64) return true;
+    // a layer planned on the operand planes (in16 + wpl) may have NO fp32 input: plan_planes() dropped the fp32 store of producers
+    // whose readers all take the planes.  The kernels that read fp32 activations are therefore never forced onto such a layer
+    // (round-3 advisor finding: a forced tile 0 / 1 in the fp16 mode read tensors nobody stored)
+    const bool on_planes = c.in16 != nullptr && c.wpl != nullptr;
+    if (tile == TILE_64x64 || tile == TILE_128x64) return !on_planes;
     if (conv_tile_is_pl(tile)) return c.mfma_mode != PREC_F32 && conv_pl_eligible(c);
-    if (tile == TILE_64x64_BD) return c.mfma_mode == PREC_BF16X3 && conv_h16_eligible(c) && c.w16s != nullptr;
+    if (tile == TILE_64x64_BD) return c.mfma_mode == PREC_BF16X3 && conv_h16_eligible(c) && c.w16s != nullptr && !on_planes;
     if (conv_tile_is_halo(tile)) return c.mfma_mode == PREC_BF16X3 && c.in16 == nullptr && conv_halo_eligible(c, tile);
 #ifdef BP_EXPERIMENTAL
     if (tile >= 0 && tile <= TILE_LAST) return c.mfma_mode != PREC_F32 && conv_h16_eligible(c);
@@ -484,7 +488,7 @@ static void choose_launch(const Op& op, int batch, int force_tile, int sk_target
     } else if (stem3_wanted(c, force_tile)) {
         t = TILE_STEM3;       // the RGB 3x3 stem: direct convolution, no K slices
     } else {
-        if (force_tile == TILE_64x64 || force_tile == TILE_128x64) t = force_tile;
+        if ((force_tile == TILE_64x64 || force_tile == TILE_128x64) && tile_runs(force_tile, c)) t = force_tile;
         const int bm = conv_tile_bm(t);
         const long long blocks = ((M + bm - 1) / bm) * (c.CoutPad / 64);
         while (blocks * s < sk_target && c.nchunks / (s + 1) >= sk_min_chunks && s < sk_max) ++s;
@@ -790,7 +794,15 @@ static const int kPrefetchCap = env_int("BP_PF_CAP_KB", 128) * 1024;
 // XCC_ID of block 0 of a launch, or -1 when the dispatch is not the round robin ConvParams::xcd_home relies on (or
 // BP_NO_XCD_HOME=1): one probe launch per process, 64 blocks, every block b must report (base + b) % 8
 int xcc_base() {
-    static const int base = [] {
+    // one probe per DEVICE (round-3 advisor finding: a process that drives several GPUs must not reuse the first device's answer)
+    static std::mutex mu;
+    static std::map<int, int> by_device;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = by_device.find(dev);
+    if (it != by_device.end()) return it->second;
+    const int base = [] {
         if (std::getenv("BP_NO_XCD_HOME")) return -1;
         const int blocks = 64;
         int* d = nullptr;
@@ -798,12 +810,13 @@ int xcc_base() {
         launch_probe_placement(d, blocks, nullptr);
         std::vector<int> h(2 * blocks);
         const bool ok = hipMemcpy(h.data(), d, h.size() * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
-        hipFree(d);
+        (void)hipFree(d);
         if (!ok) return -1;
         for (int b = 0; b < blocks; ++b)
             if (((h[2 * b] - h[0] - b) & 7) != 0) return -1;
         return h[0] & 7;
     }();
+    by_device[dev] = base;
     return base;
 }
 
@@ -818,7 +831,7 @@ int xcc_base() {
 // In the PIPELINE it loses -- fp16 batch 28 x 3 streams 3 940-4 010 against 4 060-4 140 frames/s, the other runs unchanged: with
 // other streams' blocks on the CUs there is no "one block per CU" to complete -- so it is OFF unless BP_HYBRID=1 (A/B runs, tests).
 bool conv_hybrid_plan(const ConvParams& p, int tile, size_t partial_floats, int* full, int* hs, int* hcps) {
-    const bool off = std::getenv("BP_HYBRID") == nullptr;
+    static const bool off = std::getenv("BP_HYBRID") == nullptr;   // (read once: this runs for every conv launch in eager mode)
     if (off || !conv_tile_is_pl(tile) || p.splits != 1 || p.xcd_home || p.nchunks < 16) return false;
     if (!(tile == TILE_PL64 || tile == TILE_PL128 || tile == TILE_PL128x64 || tile == TILE_PL256x128)) return false;
     const int T = conv_tiles(p, tile), unit = 256;

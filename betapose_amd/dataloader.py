@@ -6,7 +6,7 @@ from __future__ import annotations
 import os
 import time
 from queue import Queue
-from threading import Thread
+from threading import Lock, Thread
 
 import numpy as np
 
@@ -230,7 +230,8 @@ class DataWriter(_Stage):
         self.kp_3d = kp_model_vertices
         self.cam_K = cam_K
         self.left_number = left_number
-        self._busy = False
+        self._pending = 0                 # items handed to save() and not yet fully processed by the writer thread
+        self._pending_lock = Lock()
         self._thread = None
 
     def start(self):
@@ -269,21 +270,24 @@ class DataWriter(_Stage):
                 frame_out = np.asarray(orig_img)
             if frame_out is not None:
                 self.stream.write(frame_out)
-            self._busy = False
+            with self._pending_lock:
+                self._pending -= 1
 
     def running(self):
         # the reference only tests Q.empty() (racy: the last item may still be in flight, dataloader.py:743-746)
         time.sleep(0.002)
-        return (not self.Q.empty()) or self._busy
+        with self._pending_lock:
+            return self._pending > 0
 
     def save(self, boxes, scores, hm_data, pt1, pt2, orig_img, im_name):
-        self._busy = True
+        with self._pending_lock:
+            self._pending += 1            # counted before the item is visible to the writer: running() can never miss it
         self.Q.put((boxes, scores, hm_data, pt1, pt2, orig_img, im_name))
 
     def stop(self):
         self.stopped = True
         if self._thread is not None:
-            self._thread.join(timeout=5.0)      # the writer thread may still be inside stream.write
+            self._thread.join()                 # the writer finishes the item it holds (PnP, stream.write) before the stream is released
         if self.stream is not None:
             self.stream.release()
 

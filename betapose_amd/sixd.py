@@ -29,39 +29,47 @@ class Benchmark:
         self.scale_to_meters = 0.001
 
 
-def _load_yaml(path):
+def _yaml(*parts):
     import yaml
-    with open(path, "r") as f:
+    with open(os.path.join(*parts), "r") as f:
         return yaml.safe_load(f)
 
 
+def _intrinsics(base_path):
+    """camera.yml (fx, fy, cx, cy) -> 3x3 K; identity when the tree has no camera file."""
+    K = np.identity(3)
+    if os.path.exists(os.path.join(base_path, "camera.yml")):
+        c = _yaml(base_path, "camera.yml")
+        K[[0, 1, 0, 1], [0, 1, 2, 2]] = c["fx"], c["fy"], c["cx"], c["cy"]
+    return K
+
+
+def _gt_tuple(entry, to_metres):
+    """One gt.yml record -> (obj_id, 4x4 model-to-camera pose with the translation in metres, [x, y, w, h])."""
+    T = np.identity(4)
+    T[:3, :3] = np.asarray(entry["cam_R_m2c"], dtype=np.float64).reshape(3, 3)
+    T[:3, 3] = np.asarray(entry["cam_t_m2c"], dtype=np.float64).reshape(3) * to_metres
+    return entry["obj_id"], T, entry["obj_bb"]
+
+
+def _frame(seq_dir, nr, gt_entries, info, to_metres):
+    fr = Frame()
+    fr.nr, fr.path = nr, "%srgb/%04d.png" % (seq_dir, nr)
+    fr.gt = [_gt_tuple(e, to_metres) for e in gt_entries]
+    if "cam_K" in info:
+        fr.cam = np.asarray(info["cam_K"], dtype=np.float64).reshape(3, 3)
+    return fr
+
+
 def load_sixd(base_path, seq, nr_frames=0, load_mesh=True):
+    """``seq`` None: intrinsics and diameters only.  ``nr_frames`` 0: every frame of the sequence."""
     bench = Benchmark()
-    bench.scale_to_meters = 0.001
-    cam_path = os.path.join(base_path, "camera.yml")
-    if os.path.exists(cam_path):
-        c = _load_yaml(cam_path)
-        bench.cam[0, 0], bench.cam[0, 2], bench.cam[1, 1], bench.cam[1, 2] = c["fx"], c["cx"], c["fy"], c["cy"]
-    info = _load_yaml(os.path.join(base_path, "models", "models_info.yml"))
-    bench.diameter.append(10000.0)                     # index 0 is unused: object ids start at 1 (sixd.py:73)
-    for _, val in info.items():
-        bench.diameter.append(val["diameter"])
-    if seq is None:
-        return bench
-    path = os.path.join(base_path, "test/{:02d}/".format(seq))
-    frame_info = _load_yaml(os.path.join(path, "info.yml"))
-    gts = _load_yaml(os.path.join(path, "gt.yml"))
-    nr_frames = nr_frames if nr_frames > 0 else len(frame_info)
-    for i in range(nr_frames):
-        fr = Frame()
-        fr.nr = i
-        fr.path = path + "rgb/" + "{:04d}".format(i) + ".png"
-        for gt in gts[i]:
-            pose = np.identity(4)
-            pose[:3, :3] = np.array(gt["cam_R_m2c"], dtype=np.float64).reshape(3, 3)
-            pose[:3, 3] = np.squeeze(np.array(gt["cam_t_m2c"], dtype=np.float64)) * bench.scale_to_meters
-            fr.gt.append((gt["obj_id"], pose, gt["obj_bb"]))
-        if "cam_K" in frame_info[i]:
-            fr.cam = np.array(frame_info[i]["cam_K"], dtype=np.float64).reshape(3, 3)
-        bench.frames.append(fr)
+    bench.cam = _intrinsics(base_path)
+    # diameters indexed by object id; ids start at 1, so slot 0 holds the reference's placeholder (utils/sixd.py:73)
+    bench.diameter = [10000.0] + [v["diameter"] for v in _yaml(base_path, "models", "models_info.yml").values()]
+    if seq is not None:
+        seq_dir = os.path.join(base_path, "test/%02d/" % seq)
+        infos, gts = _yaml(seq_dir, "info.yml"), _yaml(seq_dir, "gt.yml")
+        count = nr_frames if nr_frames > 0 else len(infos)
+        bench.frames = [_frame(seq_dir, i, gts[i], infos[i], bench.scale_to_meters) for i in range(count)]
     return bench

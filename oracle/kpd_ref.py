@@ -19,10 +19,29 @@ import torch.nn.functional as F
 STAGES = ((64, 3, 1), (128, 4, 2), (256, 23, 2), (512, 3, 2))
 
 
+_DT = torch.float32      # arithmetic of the restatement: fp32 as the reference runs it; fp64 only for the flip-rate tests' "exact" run
+
+
+class arithmetic:
+    """``with kpd_ref.arithmetic(torch.float64): ...`` -- the same restatement in double precision (inputs must be double too)."""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        global _DT
+        self._old, _DT = _DT, self.dtype
+
+    def __exit__(self, *exc):
+        global _DT
+        _DT = self._old
+        return False
+
+
 def _t(a) -> torch.Tensor:
     if isinstance(a, torch.Tensor):
-        return a.float()
-    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+        return a.to(_DT)
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(_DT)
 
 
 def _bn(x, sd, name):

@@ -233,6 +233,26 @@ def test_f16_mode_yolo(cuda, pipe_gold):
         assert int(p16[b, :, 4].argmax()) == int(p32[b, :, 4].argmax()) == int(pipe_gold["f%d_obj_argmax" % b])
 
 
+def test_f16_mode_forced_fp32_tile_is_ignored_on_plane_layers(cuda):
+    """Round-3 advisor finding: in the fp16 mode the producers of plane-path layers drop their fp32 store, so a forced fp32-activation
+    kernel (set_policy force_tile 0 / 1, bench.py --tile 0) must not be applied to those layers.  The forced run equals the
+    unforced one bit for bit on the layers that stay on the planes, and is a valid fp16-mode result."""
+    net = Darknet("yolo/cfg/yolov3-single.cfg", reso=416, max_batch=1).load_stream(helpers.yolo_stream()).cuda().eval()
+    x = helpers.yolo_input_from_frame(helpers.frames(1)[0])
+    net.set_precision("f32")
+    p32 = net(x.to(cuda)).cpu()
+    net.set_precision("f16")
+    p16 = net(x.to(cuda)).cpu()
+    for tile in (0, 1):
+        net.set_policy(512, 4, 8, tile)
+        forced = net(x.to(cuda)).cpu()
+        assert torch.isfinite(forced).all()
+        assert float((forced - p16).abs().max()) < 1e-3, tile           # same kernels on every plane layer (the RGB stem may differ)
+        assert int(forced[0, :, 4].argmax()) == int(p32[0, :, 4].argmax())
+    net.set_policy(512, 4, 8, -1)
+    assert torch.equal(net(x.to(cuda)).cpu(), p16)
+
+
 def test_f16_mode_kpd_batch28(cuda, pipe_gold):
     kpd16 = FastPoseHIP(helpers.kpd_state_dict(), n_classes=50, max_batch=28).cuda().eval()
     g = torch.Generator().manual_seed(11)
