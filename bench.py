@@ -486,7 +486,7 @@ def insitu_layers(dets, poses, run, S, batch, path, precision):
     TICKS = 2_000_000                 # 20 ms of the 100 MHz reference clock the stamps read
     _lib.check(_lib.lib().bp_calibrate_ticks(TICKS, ctypes.byref(ms), _lib.current_stream()))
     ghz = TICKS / (ms.value * 1e-3) / 1e9
-    rows, spans = [], []
+    rows, spans, dumps = [], [], []
     for k, tag, net, names, buf in nets:
         a = buf.cpu().numpy().reshape(len(names), SLOTS, 8)
         for c, nm in enumerate(names):
@@ -496,6 +496,12 @@ def insitu_layers(dets, poses, run, S, batch, path, precision):
                 continue
             entry = blk[:, 0]
             last = blk[:, 3:7].max(axis=1)
+            if os.environ.get("BP_INSITU_DUMP") and os.environ["BP_INSITU_DUMP"] in nm and k == 0:
+                # per-block marks of one layer (10-ns ticks since the layer's first entry): entry | K loop done | last mark
+                e0_ = int(entry.min())
+                order = np.argsort(entry)
+                dumps.append("# blocks of %s (stream 0), sorted by entry: entry kloop_done last [us]\n" % nm + "\n".join(
+                    "#   %7.2f %7.2f %7.2f" % ((entry[i] - e0_) / 100.0, (blk[i, 3] - e0_) / 100.0 if blk[i, 3] else -1, (last[i] - e0_) / 100.0) for i in order))
             kloop = (blk[:, 3] - blk[:, 0])[blk[:, 3] != 0]
             rows.append((k, tag, c, nm, len(blk), (int(entry.min()), int(last.max()), float(kloop.mean()) if len(kloop) else 0.0,
                                                     float((last - np.maximum(blk[:, 3], entry)).mean()))))
@@ -544,7 +550,7 @@ def insitu_layers(dets, poses, run, S, batch, path, precision):
         f.write("# in-situ per-layer times: %d frames in flight, precision %s, the LAST frame of every stream; clock %.3f GHz\n"
                 "# (bench.py --insitu; stamps = s_memrealtime written by the conv kernels: entry / K loop done / last store per block)\n"
                 "# span = first block entry -> last mark of the layer's grid; %.2f layers in flight on average\n" % (S, precision, ghz, conc))
-        f.write("# stream net conv layer\n" + "\n".join(lines) + "\n# " + json.dumps(summary) + "\n")
+        f.write("# stream net conv layer\n" + "\n".join(lines) + "\n" + "".join(d + "\n" for d in dumps) + "# " + json.dumps(summary) + "\n")
     return summary
 
 

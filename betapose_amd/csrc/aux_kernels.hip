@@ -381,6 +381,91 @@ void launch_yolo_select(const float* pred, int N, int rows, int attrs, float con
     hipLaunchKernelGGL(yolo_select_kernel, dim3(N), dim3(1024), 0, s, pred, rows, attrs, conf, num_classes, sel, sel_ld);
 }
 
+// DetectionLayer.forward + write_results in ONE launch (round 4, node diet): when nobody asks for the [rows][attrs] prediction
+// tensor -- the fused per-frame pipeline reads the select record only -- every thread decodes the objectness and class scores of its
+// rows from the head tensors with the SAME float operations as yolo_decode_kernel, the block reduces with the same first-max rule
+// as yolo_select_kernel, and thread 0 decodes the winner's box.  Identical records by construction (asserted in
+// tests/test_gpu_stages.py against the two-kernel path).
+__global__ __launch_bounds__(1024) void yolo_decode_select_kernel(YoloHeads hs, int reso, int attrs, int rows, float conf, int num_classes,
+                                                                   float* __restrict__ sel, int sel_ld) {
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    const int n = blockIdx.x;
+    const int ncls = min(num_classes, attrs - 5);
+    auto locate = [&](int row, int* a) -> const float* {
+        int hi = 0;
+        for (int k = 1; k < hs.n; ++k)
+            if (row >= hs.h[k].row_off) hi = k;
+        const YoloHead& H = hs.h[hi];
+        const int g = H.g, r = row - H.row_off;
+        *a = r / (g * g);
+        const int cell = r - *a * g * g;
+        return H.t + ((long long)n * g * g + cell) * (3 * attrs) + *a * attrs;
+    };
+    float best = -1.f;
+    int bi = 0x7fffffff;
+    for (int r = threadIdx.x; r < rows; r += blockDim.x) {
+        int a;
+        const float* t = locate(r, &a);
+        const float obj = sigmoidf_(t[4]);
+        if (!(obj > conf)) continue;
+        int cls = 0;
+        float cm = sigmoidf_(t[5]);
+        for (int k = 1; k < ncls; ++k) {
+            const float v = sigmoidf_(t[5 + k]);
+            if (v > cm) { cm = v; cls = k; }
+        }
+        if (cls != 0) continue;
+        if (obj > best || (obj == best && r < bi)) { best = obj; bi = r; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_down(best, off, 64);
+        const int oi = __shfl_down(bi, off, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sv[w] = best; si[w] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < (int)(blockDim.x >> 6); ++k)
+            if (sv[k] > best || (sv[k] == best && si[k] < bi)) { best = sv[k]; bi = si[k]; }
+        float* o = sel + (long long)n * sel_ld;
+        if (best < 0.f) {
+            o[0] = __int_as_float(-1);
+            for (int k = 1; k < 8; ++k) o[k] = 0.f;
+        } else {
+            int a, hi = 0;
+            const float* t = locate(bi, &a);
+            for (int k = 1; k < hs.n; ++k)
+                if (bi >= hs.h[k].row_off) hi = k;
+            const YoloHead& H = hs.h[hi];
+            const int g = H.g, r = bi - H.row_off, cell = r - a * g * g;
+            const int gy = cell / g, gx = cell - gy * g;
+            const float stride = (float)(reso / g);
+            const float q0 = (sigmoidf_(t[0]) + (float)gx) * stride;
+            const float q1 = (sigmoidf_(t[1]) + (float)gy) * stride;
+            const float q2 = (expf(t[2]) * (H.aw[a] / stride)) * stride;
+            const float q3 = (expf(t[3]) * (H.ah[a] / stride)) * stride;
+            o[0] = __int_as_float(bi);
+            o[1] = q0 - q2 / 2;
+            o[2] = q1 - q3 / 2;
+            o[3] = q0 + q2 / 2;
+            o[4] = q1 + q3 / 2;
+            o[5] = sigmoidf_(t[4]);
+            o[6] = sigmoidf_(t[5]);
+            o[7] = 0.f;
+        }
+    }
+}
+void launch_yolo_decode_select(const YoloHead* heads, int nheads, int N, int reso, int attrs, int rows, float conf, int num_classes,
+                               float* sel, hipStream_t s, int sel_ld) {
+    BP_CHECK(nheads <= 4, "at most 4 yolo heads");
+    YoloHeads hs;
+    hs.n = nheads;
+    for (int i = 0; i < nheads; ++i) hs.h[i] = heads[i];
+    hipLaunchKernelGGL(yolo_decode_select_kernel, dim3(N), dim3(1024), 0, s, hs, reso, attrs, rows, conf, num_classes, sel, sel_ld);
+}
+
 // ---------------------------------------------------------------- heat-map arg-max (+4 neighbours), eval.py:113-147
 __global__ __launch_bounds__(256) void heatmap_argmax_kernel(const float* __restrict__ hm, int H, int W,
                                                               float* __restrict__ out, int C, int out_ld) {

@@ -146,7 +146,8 @@ enum ConvTile : int { TILE_64x64 = 0, TILE_128x64 = 1, TILE_W64_1x1 = 2, TILE_W6
                       // 64 rows x 32 columns per wave, filter fragments direct from global memory (bf16x3)
                       TILE_HALO64 = 21,     // 64x64 block, 2 waves
                       TILE_HALO128 = 22,    // 64x128 block, 4 waves
-                      TILE_LAST = 22 };
+                      TILE_HALO64K2 = 23,   // 64x64 block, 4 waves = 2 K groups x 2 column halves: the K split inside the block (no slabs)
+                      TILE_LAST = 23 };
 
 // when non-null, launch_conv brackets the implicit-GEMM kernel itself (not the split-K reduce) with these events
 struct ConvProfHook { hipEvent_t e0, e1; };
@@ -222,6 +223,9 @@ void launch_yolo_decode(const YoloHead* heads, int nheads, int N, int reso, int 
 // sel_ld: floats between consecutive images' records (8 dense; the fused pipeline writes straight into its result rows)
 void launch_yolo_select(const float* pred, int N, int rows, int attrs, float conf, int num_classes,
                         float* sel, hipStream_t s, int sel_ld = 8);
+// both in one launch, for callers that read the select record only (no [rows][attrs] tensor is written): same records
+void launch_yolo_decode_select(const YoloHead* heads, int nheads, int N, int reso, int attrs, int rows, float conf, int num_classes,
+                               float* sel, hipStream_t s, int sel_ld = 8);
 // hm NCHW [N][C][H*W] -> out [N][C][6] = (idx as int bits, max, left, right, up, down)
 // out_ld: floats between consecutive images' [C][6] blocks (0 = dense C*6)
 void launch_heatmap_argmax(const float* hm, int N, int C, int H, int W, float* out, hipStream_t s, int out_ld = 0);

@@ -104,11 +104,13 @@ static const PlanEntry kPlanB3[] = {
     // round 4, conv_halo.hip: the 3x3 / stride-1 layers on the tap-resident halo tile -- rows apply where conv_halo_eligible()
     // holds (a stride-2 layer of the same {M, CoutPad, K-chunks} falls through to its filters-direct row below).  Slice counts from
     // A/B runs of the whole pipeline, four frames in flight (profiles/r04_halo_ab.txt)
-    {   169,  1024,  144, TILE_HALO128,  8},
-    {   320,  1024,  144, TILE_HALO128,  6},
-    {   676,   512,   72, TILE_HALO128,  4},
-    {  1280,   512,   72, TILE_HALO128,  3},
-    {  2704,   256,   36, TILE_HALO128,  2},
+    // (first the 64x128 tile with 8 / 6 / 4 / 3 / 2 slices: +4-5 %; then the 64x64 tile with two K groups inside the block and half the
+    // slices -- none at 52x52: a further +1.2-2 %, tools/plans/k2*.txt)
+    {   169,  1024,  144, TILE_HALO64K2,  4},
+    {   320,  1024,  144, TILE_HALO64K2,  4},
+    {   676,   512,   72, TILE_HALO64K2,  2},
+    {  1280,   512,   72, TILE_HALO64K2,  2},
+    {  2704,   256,   36, TILE_HALO64K2,  1},
     {    80,   512,   64, TILE_64x64_BD,  6},
     {    80,   512,  144, TILE_64x64_BD, 10},
     {    80,  2048,   16, TILE_64x64_BD,  3},
@@ -831,7 +833,9 @@ int xcc_base() {
 // In the PIPELINE it loses -- fp16 batch 28 x 3 streams 3 940-4 010 against 4 060-4 140 frames/s, the other runs unchanged: with
 // other streams' blocks on the CUs there is no "one block per CU" to complete -- so it is OFF unless BP_HYBRID=1 (A/B runs, tests).
 bool conv_hybrid_plan(const ConvParams& p, int tile, size_t partial_floats, int* full, int* hs, int* hcps) {
-    static const bool off = std::getenv("BP_HYBRID") == nullptr;   // (read once: this runs for every conv launch in eager mode)
+    // (read per call on purpose: tests/test_gpu_conv.py::test_conv_pl_hybrid_grid toggles it inside one process; the lookup only runs
+    // for one-slice conv_pl launches in eager mode and at graph capture, never in a graph replay)
+    const bool off = std::getenv("BP_HYBRID") == nullptr;
     if (off || !conv_tile_is_pl(tile) || p.splits != 1 || p.xcd_home || p.nchunks < 16) return false;
     if (!(tile == TILE_PL64 || tile == TILE_PL128 || tile == TILE_PL128x64 || tile == TILE_PL256x128)) return false;
     const int T = conv_tiles(p, tile), unit = 256;
@@ -1297,9 +1301,15 @@ void YoloNet::forward(const float* d_img, bool nhwc_input, int batch, float* d_p
     }
     run_ops(batch, s);
     // heads hold per-image strides for max_batch_ == layout of batch b (contiguous by image), so decode as is
-    float* pred = d_pred ? d_pred : pred_;
-    launch_yolo_decode(heads_.data(), (int)heads_.size(), batch, reso_, attrs_, rows_, pred, s);
-    if (d_sel) launch_yolo_select(pred, batch, rows_, attrs_, conf, num_classes, d_sel, s, sel_ld);
+    static const bool two_kernels = std::getenv("BP_NO_DECODE_FUSION") != nullptr;   // A/B runs, tests
+    if (d_sel && !d_pred && !two_kernels) {
+        // nobody reads the prediction tensor (the fused per-frame pipeline): decode + select in one launch, same record
+        launch_yolo_decode_select(heads_.data(), (int)heads_.size(), batch, reso_, attrs_, rows_, conf, num_classes, d_sel, s, sel_ld);
+    } else {
+        float* pred = d_pred ? d_pred : pred_;
+        launch_yolo_decode(heads_.data(), (int)heads_.size(), batch, reso_, attrs_, rows_, pred, s);
+        if (d_sel) launch_yolo_select(pred, batch, rows_, attrs_, conf, num_classes, d_sel, s, sel_ld);
+    }
     BP_HIP(hipGetLastError());
 }
 

@@ -405,7 +405,7 @@ HALO_CASES = [
 
 
 def _halo_tiles(cout):
-    return ["halo64"] + (["halo128"] if ((cout + 63) // 64 * 64) % 128 == 0 else [])
+    return ["halo64", "halo64k2"] + (["halo128"] if ((cout + 63) // 64 * 64) % 128 == 0 else [])
 
 
 @pytest.mark.parametrize("case", HALO_CASES)
@@ -438,7 +438,7 @@ def test_conv_halo_bf16x3_is_fp32_accurate(cuda, case, splits):
             assert bool(((out3.double() - ref64).abs() <= 1e-5 * terms + 1e-6).all()), tile
 
 
-@pytest.mark.parametrize("tile", ["halo64_b3", "halo128_b3"])
+@pytest.mark.parametrize("tile", ["halo64_b3", "halo128_b3", "halo64k2_b3"])
 def test_conv_halo_store_modes(cuda, tile):
     g = torch.Generator().manual_seed(21)
     x = torch.randn(2, 10, 8, 64, generator=g)
@@ -471,7 +471,8 @@ def test_conv_halo_full_size_layers(cuda):
     g = torch.Generator().manual_seed(29)
     for (H, W, Cin, Cout, tile, splits) in [(52, 52, 128, 256, "halo128", 2), (52, 52, 128, 256, "halo64", 1), (26, 26, 256, 512, "halo128", 4),
                                             (13, 13, 512, 1024, "halo128", 8), (20, 16, 256, 256, "halo128", 8), (80, 64, 64, 64, "halo64", 2),
-                                            (40, 32, 128, 128, "halo128", 2)]:
+                                            (40, 32, 128, 128, "halo128", 2), (52, 52, 128, 256, "halo64k2", 1), (26, 26, 256, 512, "halo64k2", 2),
+                                            (80, 64, 64, 64, "halo64k2", 1), (13, 13, 512, 1024, "halo64k2", 4)]:
         x1 = torch.randn(1, H, W, Cin, generator=g)
         x2 = torch.randn(1, H, W, Cin, generator=g)
         w = torch.randn(Cout, Cin, 3, 3, generator=g) / np.sqrt(Cin * 9)

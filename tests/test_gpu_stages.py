@@ -314,3 +314,19 @@ def test_crop_from_dets_reference_signature(cuda):
     np.testing.assert_array_equal(pt2.numpy(), e["crop_pt2"][idx])
     assert np.abs(inps.reshape(len(idx), -1).numpy()[:, e["crop_samp_idx"]] - e["crop_samples"][idx]).max() <= 2e-6
     np.testing.assert_allclose((before - img)[:, 0, 0].numpy(), [0.406, 0.457, 0.480], atol=1e-6)   # in-place means
+
+
+def test_decode_select_fused_equals_the_two_kernel_path(engines, cuda):
+    """Round 4 node diet: DetectionLayer decode + write_results in one launch when nobody reads the prediction tensor
+    (csrc/aux_kernels.hip yolo_decode_select_kernel).  Bit-identical select records to decode -> select, for detections at several
+    confidence thresholds and for the no-detection case (yolo/darknet.py:129-169, yolo/util.py:118-223)."""
+    det, _ = engines
+    x = torch.cat([helpers.yolo_input_from_frame(f) for f in helpers.frames(4)]).to(cuda)
+    for conf in (0.01, 0.3, 0.5, 0.999999):
+        fused = det.forward_select(x, confidence=conf)
+        two, pred = det.forward_select(x, confidence=conf, want_pred=True)
+        assert torch.equal(fused.view(torch.int32), two.view(torch.int32)), conf
+        idx = fused[:, 0].contiguous().view(torch.int32).cpu()
+        for b in range(4):
+            if int(idx[b]) >= 0:
+                assert float(pred[b, int(idx[b]), 4]) == float(fused[b, 5]) > conf

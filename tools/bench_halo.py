@@ -21,7 +21,7 @@ for (h, w_, cin, co, cnt) in SHAPES:
     res = torch.randn(BATCH, h, w_, co, generator=g).to(dev)
     line = []
     best_all = {}
-    for tile in ("bd", "halo64", "halo128"):
+    for tile in ("bd", "halo64", "halo128", "halo64k2"):
         if tile == "halo128" and ((co + 63) // 64 * 64) % 128:
             continue
         if tile != "bd" and w_ > (95 if tile == "halo128" else 79):
