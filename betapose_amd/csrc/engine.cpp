@@ -434,6 +434,14 @@ static void choose_h16(const ConvParams& c, long long M, int mode, int sk_max, i
         if (e->M == (int)M && e->CoutPad == c.CoutPad && e->nchunks == c.nchunks &&
             (!conv_tile_is_halo(e->tile) || (!halo_off && mode == PREC_BF16X3 && conv_halo_eligible(c, e->tile)))) { *tile = e->tile; *splits = e->splits; return; }
     int t = TILE_64x64_BD;   // bf16x3: the filters-direct 64x64 kernel at every batch size (profiles/r02_tune_b3_batch28.txt)
+    // ... except the 3x3 / stride-1 layers of batched runs once one slice of halo tiles fills the chip: the 64x128 halo tile is
+    // 1.2-1.5x the filters-direct kernel there (batch 28: 52x52 128 -> 256 217.6 against 319.0 us, 40x32 256 -> 512 378.8 against
+    // 545.1 us; tools/bench_halo.py --batch 28, profiles/r04_halo_kernels.txt); BP_HALO_BATCH_MIN_TILES moves the threshold (A/B runs)
+    static const int halo_min_tiles = std::getenv("BP_HALO_BATCH_MIN_TILES") ? std::atoi(std::getenv("BP_HALO_BATCH_MIN_TILES")) : 64;   // (64: batch 2 x 4 streams 1 118 -> 1 209, 4 x 3 1 274 -> 1 384, 28 x 2 1 509 -> 1 754 frames/s; 256 and 16 lose 4-8 % of that at batch 2 / 4)
+    if (mode == PREC_BF16X3 && !halo_off && c.in16 == nullptr) {
+        const int ht = conv_halo_eligible(c, TILE_HALO128) ? TILE_HALO128 : (conv_halo_eligible(c, TILE_HALO64K2) ? TILE_HALO64K2 : -1);
+        if (ht >= 0 && ((M + 63) / 64) * (c.CoutPad / conv_tile_bn(ht)) >= halo_min_tiles) { *tile = ht; *splits = 1; return; }
+    }
 #ifdef BP_EXPERIMENTAL
     const long long tiles128 = ((M + 127) / 128) * ((c.CoutPad + 127) / 128);
     if (!(mode == PREC_BF16X3 && c.w16s)) t = (c.CoutPad >= 128 && tiles128 >= 128) ? TILE_W64_2x2 : TILE_64x64;
