@@ -759,7 +759,7 @@ def main():
     # regions that START after >= 60 frames have run are "settled"; at least three of those (short regions: a few more)
     frames_before = [warmup_run * a.batch]
     n_regions = max(1, a.repeats)
-    while sum(1 for i in range(n_regions) if (warmup_run + i * a.steps) * a.batch >= 60) < 3 and n_regions < 16:
+    while a.repeats > 1 and sum(1 for i in range(n_regions) if (warmup_run + i * a.steps) * a.batch >= 60) < 3 and n_regions < 16:
         n_regions += 1
     for _ in range(n_regions - 1):
         frames_before.append(frames_before[-1] + a.steps * a.batch)

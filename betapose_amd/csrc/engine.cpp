@@ -99,6 +99,9 @@ static const SplitEntry kSplitTable[] = {
 // kernels of conv_igemm.hip win every shape of the two networks, in the bf16x3 mode its filters-direct variant; the
 // slice counts are those the whole pipeline runs fastest with, which are higher than a kernel timed alone prefers);
 // other shapes use the heuristic in choose_h16.
+// COVERAGE: the rows below are the conv shapes of the two networks at BATCH 1 (M = OH x OW of one 416x416 frame / one 320x256 crop);
+// the conv_pl tables further down also carry batch 28 (BASELINE configs[2]).  Any other batch size or input resolution takes the
+// heuristics in choose_h16 / choose_pl, which are measured at batch 2, 4 and 28 only (tools/_batch_check.sh, profiles/r04_batched.txt).
 struct PlanEntry { int M, CoutPad, nchunks, tile, splits; };
 static const PlanEntry kPlanB3[] = {
     // round 4, conv_halo.hip: the 3x3 / stride-1 layers on the tap-resident halo tile -- rows apply where conv_halo_eligible()

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of plan files in the whole pipeline (4 frames in flight), alternating
-B="python bench.py --no-cpu-baseline --no-side-runs --no-served-legs --no-flip-rate --no-roofline --other-modes= --steps 200 --warmup 60 --repeats 3"
+B="python bench.py --no-cpu-baseline --no-served-legs --no-flip-rate --no-side-runs --no-roofline --other-modes= --steps 200 --warmup 60 --repeats 3"
 for rep in 1 2; do
 for pl in none haloA haloD haloE haloF; do
   if [ $pl = none ]; then unset BP_PLAN_FILE; else export BP_PLAN_FILE=tools/plans/$pl.txt; fi

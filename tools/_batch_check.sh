@@ -1,4 +1,4 @@
-B="python bench.py --no-cpu-baseline --no-side-runs --no-served-legs --no-flip-rate --no-roofline --other-modes= --steps 300 --warmup 60 --repeats 2"
+B="python bench.py --no-cpu-baseline --no-served-legs --no-flip-rate --no-side-runs --no-roofline --other-modes= --steps 300 --warmup 60 --repeats 2"
 val() { python -c "
 import sys, json
 for l in sys.stdin:

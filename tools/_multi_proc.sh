@@ -1,5 +1,5 @@
 #!/bin/bash
-B="python bench.py --no-cpu-baseline --no-side-runs --no-served-legs --no-flip-rate --no-roofline --other-modes= --steps 3000 --warmup 200 --repeats 1"
+B="python bench.py --no-cpu-baseline --no-served-legs --no-flip-rate --no-side-runs --no-roofline --other-modes= --steps 3000 --warmup 200 --repeats 1"
 val() { python -c "
 import sys, json
 for l in sys.stdin:

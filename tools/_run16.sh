@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 timeout 900 python -m pytest tests/test_gpu_conv.py tests/test_gpu_soak.py -x -q 2>&1 | tail -4
-b() { tag=$1; shift; python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-roofline --other-modes , --no-side-runs --repeats 1 "$@" 2>&1 | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(sys.argv[1], d["value"], d["ms_per_step"])' $tag; }
+b() { tag=$1; shift; python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-served-legs --no-flip-rate --no-roofline --other-modes , --no-side-runs --repeats 1 "$@" 2>&1 | tail -1 | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(sys.argv[1], d["value"], d["ms_per_step"])' $tag; }
 e() { BP_LIB=$PWD/betapose_amd/libbetapose_hip_exp.so BP_LEGACY=1 b "$@"; }
 for r in 1 2 3; do b product-b3; done
 b product-b3-1stream --streams 1

@@ -1,7 +1,7 @@
 #!/bin/bash
 amd-smi metric -g 0 --throttle --json 2>&1 | head -80
 amd-smi metric -g 0 --energy --json 2>&1 | head -20
-(python bench.py --no-cpu-baseline --no-side-runs --no-roofline --other-modes= --steps 25000 --warmup 60 --repeats 1 > /dev/null 2>&1 &)
+(python bench.py --no-cpu-baseline --no-served-legs --no-flip-rate --no-side-runs --no-roofline --other-modes= --steps 25000 --warmup 60 --repeats 1 > /dev/null 2>&1 &)
 sleep 28
 echo "== loaded"
 amd-smi metric -g 0 --power --clock --json 2>&1 | head -60

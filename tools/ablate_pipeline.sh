@@ -11,7 +11,7 @@ for v in "${variants[@]}"; do
   BP_CFLAGS="$v" python -m betapose_amd.build --force --experimental > /dev/null 2>&1 || { echo "build failed: $v" >> $out; continue; }
   export BP_LIB=$PWD/betapose_amd/libbetapose_hip_exp.so
   for st in 4 1; do
-    line=$(timeout 300 python bench.py --steps 400 --warmup 40 --streams $st --no-side-runs --no-cpu-baseline --no-roofline --other-modes "" --repeats 1 2>/dev/null | tail -1)
+    line=$(timeout 300 python bench.py --steps 400 --warmup 40 --streams $st --no-side-runs --no-cpu-baseline --no-served-legs --no-flip-rate --no-roofline --other-modes "" --repeats 1 2>/dev/null | tail -1)
     echo "flags='$v' streams=$st $(echo "$line" | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print("fps=%.1f ms_per_step=%.3f" % (d["value"], d["ms_per_step"]))')" >> $out
   done
 done

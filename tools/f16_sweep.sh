@@ -1,6 +1,6 @@
 #!/bin/bash
 cd "$(dirname "$0")/.."
-run() { python bench.py --no-cpu-baseline --no-roofline --precision f16 "$@" 2>/dev/null | python -c "
+run() { python bench.py --no-cpu-baseline --no-served-legs --no-flip-rate --no-roofline --precision f16 "$@" 2>/dev/null | python -c "
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):

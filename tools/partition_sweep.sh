@@ -1,7 +1,7 @@
 #!/bin/bash
 # frames/s with each in-flight frame on its own CU slice: partition count x split-K target sweep
 cd "$(dirname "$0")/.."
-run() { python bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-roofline "$@" 2>/dev/null | python -c "
+run() { python bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-served-legs --no-flip-rate --no-roofline "$@" 2>/dev/null | python -c "
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):

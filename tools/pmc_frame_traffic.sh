@@ -7,7 +7,7 @@ REPO="$(cd "$(dirname "$0")/.." && pwd)"
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf $REPO/gpurun_out/pmcf_$C
-  timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $REPO/gpurun_out/pmcf_$C -o p -- python $REPO/bench.py --steps 40 --warmup 4 --no-roofline --no-cpu-baseline --other-modes "" --no-side-runs --repeats 1 --streams $ST $EXTRA > /dev/null 2>&1
+  timeout 300 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $REPO/gpurun_out/pmcf_$C -o p -- python $REPO/bench.py --steps 40 --warmup 4 --no-roofline --no-cpu-baseline --no-served-legs --no-flip-rate --other-modes "" --no-side-runs --repeats 1 --streams $ST $EXTRA > /dev/null 2>&1
 done
 python - <<PY
 import csv, glob, json, os

@@ -7,7 +7,7 @@ REPO="$(cd "$(dirname "$0")/.." && pwd)"
 cd /tmp && export TMPDIR=/tmp
 rm -rf $REPO/gpurun_out/pmc_mfma
 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $REPO/gpurun_out/pmc_mfma -o p -- \
-    python $REPO/bench.py --steps 20 --warmup 2 --no-roofline --no-cpu-baseline --other-modes "" --no-side-runs --repeats 1 --streams 1 $EXTRA > /dev/null 2>&1
+    python $REPO/bench.py --steps 20 --warmup 2 --no-roofline --no-cpu-baseline --no-served-legs --no-flip-rate --other-modes "" --no-side-runs --repeats 1 --streams 1 $EXTRA > /dev/null 2>&1
 python - <<PY
 import csv, glob, json, os
 f = glob.glob(os.path.join("$REPO/gpurun_out/pmc_mfma", "**", "*counter_collection.csv"), recursive=True)[0]

@@ -25,7 +25,7 @@ fk = sum(F[name]) / len(F[name])
 wk = sum(Wr[name]) / len(Wr[name])
 res = {"kernel": name.replace("void ", "").split("(")[0],
        "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) --kernel-trace -- python bench.py --steps 20 "
-                  "--warmup 2 --no-roofline --no-cpu-baseline --other-modes \"\" --streams 1" + (" " + os.environ.get("BP_BENCH_EXTRA", "")).rstrip(),
+                  "--warmup 2 --no-roofline --no-cpu-baseline --no-served-legs --no-flip-rate --other-modes \"\" --streams 1" + (" " + os.environ.get("BP_BENCH_EXTRA", "")).rstrip(),
        "launches": len(F[name]), "FETCH_SIZE_KB_mean_raw": fk, "WRITE_SIZE_KB_mean_raw": wk,
        "correction": "gfx950 rocprofv3 FETCH_SIZE reports half the bytes of 16-B/lane coalesced reads "
                      "(MI355X_MICROARCH.md HBM): fetch bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE taken as KB",

@@ -7,7 +7,7 @@ REPO="$(cd "$(dirname "$0")/.." && pwd)"
 cd /tmp && export TMPDIR=/tmp
 rm -rf $REPO/gpurun_out/pmc_stalls
 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM --kernel-trace --output-format csv -d $REPO/gpurun_out/pmc_stalls -o p -- \
-    python $REPO/bench.py --steps 20 --warmup 2 --no-roofline --no-cpu-baseline --other-modes "" --no-side-runs --repeats 1 --streams 1 $EXTRA > /dev/null 2>&1
+    python $REPO/bench.py --steps 20 --warmup 2 --no-roofline --no-cpu-baseline --no-served-legs --no-flip-rate --other-modes "" --no-side-runs --repeats 1 --streams 1 $EXTRA > /dev/null 2>&1
 python - <<PY
 import csv, glob, json, os
 fs = glob.glob(os.path.join("$REPO/gpurun_out/pmc_stalls", "**", "*counter_collection.csv"), recursive=True)

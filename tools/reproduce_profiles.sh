@@ -13,19 +13,19 @@ mkdir -p "$OUT"
 cd $REPO
 has() { [[ " $BLOCKS " == *" $1 "* ]]; }
 line() { python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(sys.argv[1], "frames/s", d["value"], "ms/step", d["ms_per_step"])' "$1"; }
-quick() { tag=$1; shift; python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-roofline --other-modes , --no-side-runs --repeats 1 "$@" 2>/dev/null | tail -1 | line "$tag"; }
+quick() { tag=$1; shift; python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-served-legs --no-flip-rate --no-roofline --other-modes , --no-side-runs --repeats 1 "$@" 2>/dev/null | tail -1 | line "$tag"; }
 
 if has 1; then
 # 1. headline bench line (+ repeats, other_precisions, roofline with hbm / layer classes / in-situ layer table, latency,
 #    h2d_inclusive, cpu_baseline) and the other modes alone; batched and stream-count sweeps
 python bench.py --insitu $OUT/${TAG}_insitu_layer_times.txt > $OUT/${TAG}_bench_default.json 2>/dev/null
-python bench.py --precision f32 --no-cpu-baseline --other-modes , > $OUT/${TAG}_bench_f32.json 2>/dev/null
-python bench.py --precision f16 --no-cpu-baseline --other-modes , --insitu $OUT/${TAG}_insitu_layer_times_f16.txt > $OUT/${TAG}_bench_f16.json 2>/dev/null
+python bench.py --precision f32 --no-cpu-baseline --no-served-legs --no-flip-rate --other-modes , > $OUT/${TAG}_bench_f32.json 2>/dev/null
+python bench.py --precision f16 --no-cpu-baseline --no-served-legs --no-flip-rate --other-modes , --insitu $OUT/${TAG}_insitu_layer_times_f16.txt > $OUT/${TAG}_bench_f16.json 2>/dev/null
 for cfg in "bf16x3 28 2" "f16 28 3" "f32 28 2" "bf16x3 2 4" "bf16x3 4 3"; do set -- $cfg
-  python bench.py --precision $1 --batch $2 --streams $3 --steps 60 --warmup 6 --no-cpu-baseline --other-modes , --no-roofline --no-side-runs --repeats 3 2>/dev/null
+  python bench.py --precision $1 --batch $2 --streams $3 --steps 60 --warmup 6 --no-cpu-baseline --no-served-legs --no-flip-rate --other-modes , --no-roofline --no-side-runs --repeats 3 2>/dev/null
 done > $OUT/${TAG}_bench_batched.jsonl
 for st in 1 2 3 4 5 6 8; do
-  python bench.py --streams $st --steps 300 --warmup 20 --no-cpu-baseline --other-modes , --no-roofline --no-side-runs --repeats 1 2>/dev/null
+  python bench.py --streams $st --steps 300 --warmup 20 --no-cpu-baseline --no-served-legs --no-flip-rate --other-modes , --no-roofline --no-side-runs --repeats 1 2>/dev/null
 done > $OUT/${TAG}_bench_streams.jsonl
 fi
 
@@ -94,7 +94,7 @@ fi
 if has 7; then
 # 7. what the chip does meanwhile: clocks and power by mode, first-touch fetch rates, block -> XCD map,
 #    per-layer SQ counters of the plane kernels, latency-mode A/B by frames in flight, the cache-resident-filters bound
-clk() { tag=$1; shift; python bench.py --steps 100 --warmup 20 --no-roofline --no-cpu-baseline --other-modes , --repeats 2 "$@" 2>/dev/null | python -c 'import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(sys.argv[1], d["value"], json.dumps(d.get("clocks_under_load")))' "$tag"; }
+clk() { tag=$1; shift; python bench.py --steps 100 --warmup 20 --no-roofline --no-cpu-baseline --no-served-legs --no-flip-rate --other-modes , --repeats 2 "$@" 2>/dev/null | python -c 'import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(sys.argv[1], d["value"], json.dumps(d.get("clocks_under_load")))' "$tag"; }
 {
 clk "b3 4 streams"; clk "b3 1 stream" --streams 1; clk "b3 2 streams" --streams 2; clk "b3 3 streams" --streams 3
 BP_B3_PLANES=1 clk "b3 planes 4 streams"; clk "f16 4 streams" --precision f16; clk "f32 4 streams" --precision f32

@@ -10,7 +10,7 @@ OUT=$REPO/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rm -rf $OUT/trace_headline
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_headline -o p -- \
-    python $REPO/bench.py --steps 200 --warmup 20 --no-cpu-baseline --other-modes "" --no-roofline --no-side-runs --repeats 1 > $OUT/${TAG}_bench_under_rocprof.json 2>/dev/null
+    python $REPO/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-served-legs --no-flip-rate --other-modes "" --no-roofline --no-side-runs --repeats 1 > $OUT/${TAG}_bench_under_rocprof.json 2>/dev/null
 cp $OUT/trace_headline/p_kernel_stats.csv $OUT/${TAG}_bench_kernel_stats.csv
 python - <<PY
 import csv, json
