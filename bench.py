@@ -340,6 +340,8 @@ def roofline(det, pose, batch):
             return "bp::conv_igemm_h_kernel<1, 1, 3, true>"        # filters direct
         if tile in (21, 22):
             return "bp::conv_halo_kernel<%d, *>" % (2 if tile == 21 else 4)   # tap-resident halo (conv_halo.hip); * = loader passes, by map width
+        if tile == 23:
+            return "bp::conv_halo_k2_kernel<*>"                            # ... with two K groups inside the block
         if tile in (7, 8, 9):
             return "bp::conv_kg_kernel<%d, 3>" % {7: 1, 8: 2, 9: 4}[tile]
         if tile in (10, 11):
@@ -348,7 +350,7 @@ def roofline(det, pose, batch):
             return "bp::conv_w64_kernel<%s, %d>" % (TILE_NAMES.get(tile, "?"), np_)
         return "bp::conv_igemm_h_kernel<%s, %d, false>" % (TILE_NAMES.get(tile, "?"), np_)
     name = kernel_name(key[0], mode)
-    want = name.split(">")[0].split(", *")[0]
+    want = name.split(">")[0].split(", *")[0].split("<*")[0]
     peak_of = {"f32": PEAK_FP32_MFMA_TFLOPS, "f16": PEAK_F16_MFMA_TFLOPS, "bf16x3": PEAK_BF16X3_TFLOPS}
     per_kernel = []
     for k_, g_ in sorted(groups.items(), key=lambda kv: -kv[1]["ms"]):
