@@ -84,6 +84,8 @@ struct ConvParams {
     long long out16_plane;
     int out_np;                   // planes the epilogue emits: 0 none, 1 fp16, 3 bf16x3
     int skip_f32;                 // 1: every reader of `out` takes the planes -- the fp32 store is dropped (engine.cpp plan_planes)
+    const unsigned short* res16;  // fp16 plane of the residual view `res` (same ld): the epilogue reads the residual from it instead of the
+                                  // fp32 tensor (fp16 mode with fp16 skip connections, Net::set_f16_residuals; `res` stays set: it selects the epilogue)
     int abl;                      // timing ablations, experimental builds only (-DBP_EXPERIMENTAL; tools/abl_pl.sh): 0 in the product
     const unsigned short* wbd;    // filters as stage-packed fragments in conv_pl.hip's K order (TILE_PL64BD: launch_f32_to_bf16x3_staged with Cin)
     const unsigned short* wpl;    // filters as conv_pl.hip's LDS image: [CoutPad/64][nchunks][plane][64 rows][64 B swizzled]
@@ -123,7 +125,8 @@ struct ConvParams {
 
 // tile configuration ids for launch_conv
 // arithmetic of the matrix-core operands (accumulation and activations are always fp32)
-enum Precision : int { PREC_F32 = 0, PREC_F16 = 1, PREC_BF16X3 = 2 };
+// PREC_F16_RES is an engine-level mode (Net::set_precision): the kernels see PREC_F16 plus ConvParams::res16
+enum Precision : int { PREC_F32 = 0, PREC_F16 = 1, PREC_BF16X3 = 2, PREC_F16_RES = 3 };
 
 // TILE_W64_<WM>x<WN>: conv_w64.hip, WM x WN waves of 64x64 each (16-bit precision modes only)
 // TILE_KG<G>: conv_kg.hip, 64x64 block tile, G groups of 4 waves each on its own K range (bf16x3 mode only)

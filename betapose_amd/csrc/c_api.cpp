@@ -212,7 +212,7 @@ int bp_yolo_clone(const bp_yolo* y, bp_yolo** out) {
     std::unique_ptr<bp_yolo> c(new bp_yolo);
     c->device = y->device;
     c->net.reset(y->net->clone());
-    if (y->net->precision() != bp::PREC_F32) c->net->set_precision(y->net->precision());
+    if (y->net->precision() != bp::PREC_F32) c->net->set_precision(y->net->precision_id());
     *out = c.release();
     return 0;
     BP_CATCH
@@ -286,7 +286,7 @@ int bp_kpd_clone(const bp_kpd* k, bp_kpd** out) {
     std::unique_ptr<bp_kpd> c(new bp_kpd);
     c->device = k->device;
     c->net.reset(k->net->clone());
-    if (k->net->precision() != bp::PREC_F32) c->net->set_precision(k->net->precision());
+    if (k->net->precision() != bp::PREC_F32) c->net->set_precision(k->net->precision_id());
     *out = c.release();
     return 0;
     BP_CATCH
@@ -706,13 +706,8 @@ int bp_pipeline_set_fixed_box(bp_pipeline* p, const float* box) {
     BP_CATCH
 }
 
-int bp_pipeline_run(bp_pipeline* p, int use_graph, void* stream) {
-    BP_TRY
-    hipStream_t s = (hipStream_t)stream;
-    if (!use_graph) {
-        pipeline_enqueue(p, s);
-        return 0;
-    }
+// (re)build the frame's hipGraph when the launch plan changed since the capture -- records the launches, executes nothing
+static void pipeline_capture(bp_pipeline* p) {
     if (p->exec && (p->ver_y != p->y->net->plan_version() || p->ver_k != p->k->net->plan_version())) {
         // launch policy / precision changed since the capture: the recorded kernels are stale
         (void)hipGraphExecDestroy(p->exec);
@@ -736,6 +731,24 @@ int bp_pipeline_run(bp_pipeline* p, int use_graph, void* stream) {
         BP_HIP(hipStreamEndCapture(p->cap_stream, &p->graph));
         BP_HIP(hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0));
     }
+}
+
+int bp_pipeline_prepare(bp_pipeline* p) {
+    BP_TRY
+    BP_CHECK(p, "null argument");
+    pipeline_capture(p);
+    return 0;
+    BP_CATCH
+}
+
+int bp_pipeline_run(bp_pipeline* p, int use_graph, void* stream) {
+    BP_TRY
+    hipStream_t s = (hipStream_t)stream;
+    if (!use_graph) {
+        pipeline_enqueue(p, s);
+        return 0;
+    }
+    pipeline_capture(p);
     BP_HIP(hipGraphLaunch(p->exec, s));
     return 0;
     BP_CATCH

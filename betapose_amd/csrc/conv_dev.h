@@ -180,7 +180,8 @@ __device__ __forceinline__ void epilogue_store(const ConvParams& p, int m, int n
     }
     float r = 0.f;
     if (p.res) {
-        r = p.res[(long long)m * p.res_ld + n];
+        if (p.res16) { const _Float16 h = __builtin_bit_cast(_Float16, p.res16[(long long)m * p.res_ld + n]); r = (float)h; }
+        else r = p.res[(long long)m * p.res_ld + n];
         if (p.res_scale) r *= p.res_scale[b * p.Cout + n];
     }
     if (!p.res_after_act) v += r;
@@ -240,6 +241,16 @@ __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t rsrc, unsigned
     return f32x4{__uint_as_float(t.x), __uint_as_float(t.y), __uint_as_float(t.z), __uint_as_float(t.w)};
 }
 
+// four consecutive residual channels: 16 B of the fp32 tensor, or 8 B of its fp16 plane widened (ConvParams::res16); `off` = byte offset
+// in the respective buffer
+__device__ __forceinline__ f32x4 load_res4(__amdgpu_buffer_rsrc_t rsrc, unsigned off, bool r16) {
+    if (r16) {
+        const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)off, 0, 0);
+        return __builtin_convertvector(__builtin_bit_cast(f16x4, t), f32x4);
+    }
+    return buf_load4(rsrc, off, 0);
+}
+
 // a - b as ONE v_sub_f32.  Opaque to the optimizer on purpose: hipcc packs neighbouring f32 subtractions into
 // v_pk_add_f32, which is slow beside MFMAs (MI355X_MICROARCH.md, price of fillers).  Kept in a __device__ function: an
 // asm statement with register constraints directly in a __global__ template silently drops the kernel's host stub.
@@ -269,7 +280,7 @@ template <int ACT, int RES, int PASSES, int PF>
 __device__ __forceinline__ void epilogue_rows(const float* srow, int s_step, f32x4 bias4,
                                               __amdgpu_buffer_rsrc_t rsrcO, unsigned off_o, unsigned step_o,
                                               __amdgpu_buffer_rsrc_t rsrcR, unsigned off_r, unsigned step_r, const f32x4* rpre,
-                                              const PlaneDesc& pd) {
+                                              const PlaneDesc& pd, bool r16 = false) {
     // PF: the residual rows were requested before the tile was staged (rpre[pass], registers): a cold 16-B load costs the
     // block > 1 us at the very end of the kernel otherwise
 #pragma unroll
@@ -278,7 +289,7 @@ __device__ __forceinline__ void epilogue_rows(const float* srow, int s_step, f32
         f32x4 r4 = {0.f, 0.f, 0.f, 0.f};
         if constexpr (RES != 0) {
             if constexpr (PF) r4 = rpre[pass];
-            else r4 = buf_load4(rsrcR, off_r, 0);
+            else r4 = load_res4(rsrcR, off_r, r16);
         }
         v += bias4;
         if constexpr (RES == 1) v += r4;

@@ -569,7 +569,7 @@ int Net::add_conv(const std::string& name, const Tensor& in, const Tensor& out_v
     c.tickets = nullptr;
     c.stamps = nullptr;
     c.w16 = nullptr; c.w16s = nullptr;
-    c.in16 = nullptr; c.out16 = nullptr; c.wpl = nullptr; c.wbd = nullptr; c.in16_plane = c.out16_plane = 0; c.out_np = 0; c.abl = 0; c.skip_f32 = 0;
+    c.in16 = nullptr; c.out16 = nullptr; c.wpl = nullptr; c.wbd = nullptr; c.in16_plane = c.out16_plane = 0; c.out_np = 0; c.abl = 0; c.skip_f32 = 0; c.res16 = nullptr;
     c.pool_out = nullptr; c.hy_full = c.hy_splits = c.hy_cps = 0;
     c.pf_ptr = nullptr; c.xcd_home = 0; c.xcc_of = nullptr; c.tickets_local = nullptr; c.mtiles = c.n_tiles = c.work_blocks = c.pf_first = 0;
     c.pf_ntn = c.pf_splits = c.pf_cps = c.pf_nchunks = c.pf_tile_stride = c.pf_chunk_bytes = c.pf_cap = 0;
@@ -618,7 +618,9 @@ void Net::finalize() {
 }
 
 void Net::set_precision(int prec) {
-    BP_CHECK(prec == PREC_F32 || prec == PREC_F16 || prec == PREC_BF16X3, "unknown precision");
+    BP_CHECK(prec == PREC_F32 || prec == PREC_F16 || prec == PREC_BF16X3 || prec == PREC_F16_RES, "unknown precision");
+    f16_res_ = prec == PREC_F16_RES;
+    if (f16_res_) prec = PREC_F16;
     // Two data paths for the 16-bit operand modes (A/B of the whole pipeline on one box, profiles/r03_ab_pipeline.txt):
     //   fp16   -> operand planes written by the producers, both operands by LDS-DMA (conv_pl.hip): +24 % at batch 1, +42 % at
     //             batch 28 over the round-2 kernels;
@@ -712,7 +714,7 @@ Net::ActAlloc* Net::find_act(const float* p) {
 void Net::plan_planes(int prec) {
     for (Op& op : ops_) {
         op.out16 = nullptr; op.out16_plane = 0;
-        if (op.type == OP_CONV) { op.conv.in16 = nullptr; op.conv.out16 = nullptr; op.conv.wpl = nullptr; op.conv.wbd = nullptr; op.conv.out_np = 0; op.conv.in16_plane = op.conv.out16_plane = 0; op.conv.skip_f32 = 0; }
+        if (op.type == OP_CONV) { op.conv.in16 = nullptr; op.conv.out16 = nullptr; op.conv.wpl = nullptr; op.conv.wbd = nullptr; op.conv.out_np = 0; op.conv.in16_plane = op.conv.out16_plane = 0; op.conv.skip_f32 = 0; op.conv.res16 = nullptr; }
     }
     for (ActAlloc& a : acts_) a.f32_read = true;
     if (prec == PREC_F32) return;
@@ -786,9 +788,16 @@ void Net::plan_planes(int prec) {
     static const bool keep_all = std::getenv("BP_KEEP_F32") != nullptr;
     for (ActAlloc& a : acts_) a.f32_read = keep_all || a.planes == nullptr;
     auto mark = [&](const float* q) { if (q) if (ActAlloc* a = find_act(q)) a->f32_read = true; };
+    // fp16 skip connections (PREC_F16_RES): a residual whose tensor has an fp16 plane -- some convolution reads it as input, so its
+    // producer writes the plane anyway -- is read from that plane (2 B per element instead of 4) and does not keep the fp32 tensor alive
+    if (f16_res_ && np == 1)
+        for (Op& op : ops_)
+            if (op.type == OP_CONV && op.conv.res)
+                if (ActAlloc* r = find_act(op.conv.res); r && r->planes && (op.conv.res - r->base) % 4 == 0 && (op.conv.res_ld & 3) == 0)
+                    op.conv.res16 = r->planes + (op.conv.res - r->base);
     for (const Op& op : ops_) {
         if (op.type == OP_CONV) {
-            mark(op.conv.res);
+            if (!op.conv.res16) mark(op.conv.res);
             if (!(op.conv.in16 && op.conv.wpl)) mark(op.conv.in);
         } else {
             mark(op.a); mark(op.b);

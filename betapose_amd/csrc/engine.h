@@ -92,8 +92,11 @@ public:
     void set_max_splits(int m) { sk_max_splits_ = m; ++plan_version_; }
     void set_force_tile(int t) { force_tile_ = t; ++plan_version_; }
     // PREC_F16 / PREC_BF16X3: eligible convs (Cin % 32 == 0) run on the 16-bit MFMA kernels with converted filter copies
+    // prec 3 (PREC_F16_RES): the fp16 mode with fp16 SKIP CONNECTIONS -- a residual is read from the fp16 plane its producer wrote
+    // for the next convolution, and a tensor that only convolutions and residual adds read loses its fp32 store (ConvParams::res16)
     void set_precision(int prec);
     int precision() const { return precision_; }
+    int precision_id() const { return (precision_ == PREC_F16 && f16_res_) ? PREC_F16_RES : precision_; }
     unsigned plan_version() const { return plan_version_; }
     // in-situ timing: every convolution launch whose grid has at most `slots` blocks writes 8 u64 s_memrealtime (100 MHz) marks per block
     // (entry, index math done, -, K loop done, stores done, slab parked, slices combined, -) at d_buf + (conv ordinal * slots +
@@ -145,6 +148,7 @@ protected:
     unsigned long long* stamps_ = nullptr;
     int stamp_slots_ = 0;
     bool prefetch_ = false;
+    bool f16_res_ = false;        // fp16 skip connections (set_precision(PREC_F16_RES))
     unsigned plan_version_ = 0;   // bumped whenever launches would change (captured graphs must be rebuilt)
 };
 

@@ -170,9 +170,10 @@ class Darknet:
 
     def set_precision(self, precision: str = "bf16x3"):
         """'f32' (fp32 MFMA), 'bf16x3' (fp32-accurate: exact 3-way bf16 operand split on the bf16 MFMA) or 'f16'
-        (fp16 operands, fp32 accumulate: carries fp16 rounding)."""
+        (fp16 operands, fp32 accumulate: carries fp16 rounding); 'f16r' = 'f16' with fp16 skip connections (residuals read from the fp16
+        operand planes, fp32 copies of tensors that only convolutions and residual adds read are dropped)."""
         self._ensure()
-        _lib.check(_lib.lib().bp_yolo_set_precision(self._h, {"f32": 0, "f16": 1, "bf16x3": 2}[precision]))
+        _lib.check(_lib.lib().bp_yolo_set_precision(self._h, {"f32": 0, "f16": 1, "bf16x3": 2, "f16r": 3}[precision]))
         self._precision = precision
         return self
 

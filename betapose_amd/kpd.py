@@ -145,7 +145,7 @@ class FastPoseHIP:
         """'f32' (fp32 MFMA), 'bf16x3' (fp32-accurate: exact 3-way bf16 operand split on the bf16 MFMA) or 'f16'
         (fp16 operands, fp32 accumulate: carries fp16 rounding)."""
         self._ensure()
-        _lib.check(_lib.lib().bp_kpd_set_precision(self._h, {"f32": 0, "f16": 1, "bf16x3": 2}[precision]))
+        _lib.check(_lib.lib().bp_kpd_set_precision(self._h, {"f32": 0, "f16": 1, "bf16x3": 2, "f16r": 3}[precision]))
         self._precision = precision
         return self
 

@@ -69,6 +69,12 @@ class FramePipeline:
         already hold the batch; ``self.results`` is valid once the stream reaches this point."""
         _lib.check(_lib.lib().bp_pipeline_run(self._h, int(self.use_graph), stream if stream is not None else _lib.current_stream()))
 
+    def prepare(self):
+        """Set-up: build the frame's hipGraph now (capture + instantiate, nothing executes) instead of inside the first ``enqueue``."""
+        if self.use_graph:
+            _lib.check(_lib.lib().bp_pipeline_prepare(self._h))
+        return self
+
     def kernel_count(self) -> int:
         return _lib.lib().bp_pipeline_kernel_count(self._h)
 

@@ -111,7 +111,11 @@ int bp_kpd_set_policy(bp_kpd* k, int sk_target_blocks, int sk_min_chunks, int sk
  *   0  fp32 MFMA (v_mfma_f32_32x32x2_f32);
  *   1  fp16 operands, one fp16 MFMA per product (BASELINE configs[2]; results carry fp16 rounding, ~1e-3);
  *   2  fp32-accurate on the bf16 pipe: operands split exactly into three bf16 terms, six partial products
- *      (dropped terms <= 2^-23 relative, below the fp32 accumulation rounding). */
+ *      (dropped terms <= 2^-23 relative, below the fp32 accumulation rounding);
+ *   3  mode 1 with fp16 SKIP CONNECTIONS: a residual (YOLO shortcut, ResNet bottleneck add) is read from the fp16 operand plane
+ *      its producer wrote for the next convolution, and tensors that only convolutions and residual adds read are not stored as
+ *      fp32 at all -- activations travel as fp16 between layers, accumulation stays fp32.  Same stated tolerances as mode 1
+ *      (batched fp16 runs are bound by what the layers write: +8.5 % frames/s at 28 frames per launch). */
 int bp_yolo_set_precision(bp_yolo* y, int precision);
 int bp_kpd_set_precision(bp_kpd* k, int precision);
 /* per-op static description: returns number of ops; fills up to cap entries of (flops, bytes) per image */
@@ -183,6 +187,9 @@ float* bp_pipeline_results(bp_pipeline* p);     /* device [batch][BP_RESULT_FLOA
 float* bp_pipeline_heatmaps(bp_pipeline* p);    /* device [batch][50][80][64] */
 int bp_pipeline_set_fixed_box(bp_pipeline* p, const float* box_xyxy_or_null);
 int bp_pipeline_run(bp_pipeline* p, int use_graph, void* stream);
+/* Set-up step: capture and instantiate the frame's hipGraph now (records the launches, executes nothing), so that the first
+ * bp_pipeline_run(use_graph = 1) is a plain graph launch.  Called again after a precision / policy change it rebuilds the graph. */
+int bp_pipeline_prepare(bp_pipeline* p);
 
 /* ---- host post-processing (no device work) ---- */
 /* pnp (utils/utils.py:17-41): a restatement of cv2.solvePnP's default SOLVEPNP_ITERATIVE (planar / DLT initialisation,
