@@ -12,16 +12,16 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbetapose_hip.so")
-SOURCES = ["conv_igemm.hip", "conv_pl.hip", "conv_halo.hip", "aux_kernels.hip", "engine.cpp", "host_post.cpp", "frame_io.cpp", "jpeg_bmp.cpp", "c_api.cpp", "darknet_compat.cpp"]
-HEADERS = ["bp_common.h", "engine.h", "frame_io.h", "conv_tail.inc", "conv_dev.h", os.path.join("..", "..", "include", "betapose_hip.h"),
+SOURCES = ["conv_igemm.hip", "conv_halo.hip", "conv_pl.hip", "aux_kernels.hip", "engine.cpp", "host_post.cpp", "frame_io.cpp", "jpeg_bmp.cpp", "c_api.cpp", "darknet_compat.cpp"]
+HEADERS = ["bp_common.h", "engine.h", "frame_io.h", "conv_tail.inc", "conv_dev.h", "conv_igemm.hip", "conv_halo.hip", "mega.inc", os.path.join("..", "..", "include", "betapose_hip.h"),
            os.path.join("..", "..", "include", "yolo_v2_class_compat.h")]
 # measured-and-superseded kernels (round-1/2 experiments): compiled only into libbetapose_hip_exp.so (--experimental)
 EXP_SOURCES = ["conv_w64.hip", "conv_kg.hip", "conv_rd.hip"]
 ARCH = "gfx950"
 # Host launch stubs every HIP object must export.  hipcc has been seen to drop a kernel's host stub SILENTLY (the object
 # links, the launch then fails at run time) -- DESIGN.md §3.1d -- so the build counts them.
-MIN_STUBS = {"conv_igemm.hip": 11, "conv_pl.hip": 12, "conv_halo.hip": 13, "aux_kernels.hip": 17}
-MIN_STUBS_EXP = {"conv_igemm.hip": 11, "conv_pl.hip": 12, "conv_halo.hip": 13, "conv_w64.hip": 8, "conv_kg.hip": 3, "conv_rd.hip": 2, "aux_kernels.hip": 20}
+MIN_STUBS = {"conv_igemm.hip": 11, "conv_halo.hip": 13, "conv_pl.hip": 12, "aux_kernels.hip": 17}
+MIN_STUBS_EXP = {"kernels_unity.hip": 25, "conv_pl.hip": 12, "conv_w64.hip": 8, "conv_kg.hip": 3, "conv_rd.hip": 2, "aux_kernels.hip": 20}
 
 
 def hipcc() -> str:
@@ -55,6 +55,8 @@ def _build(force: bool, verbose: bool, LIB: str, objdir: str, extra) -> str:
     os.makedirs(objdir, exist_ok=True)
     procs = []
     sources = SOURCES + (EXP_SOURCES if extra else [])
+    if extra:   # the experimental library compiles the two conv files as ONE unit with the persistent per-XCD launch (mega.inc) behind them
+        sources = ["kernels_unity.hip"] + [s_ for s_ in sources if s_ not in ("conv_igemm.hip", "conv_halo.hip")]
     for src in sources:
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         cmd = [cc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c",

@@ -193,6 +193,25 @@ void conv_prefetch_of(ConvParams& p, const ConvParams& next, int next_tile, int 
 int conv_tile_bm(int tile);
 int conv_tile_bn(int tile);
 
+// ---- the persistent per-XCD launch (mega.inc, compiled in kernels_unity.hip): one frame's launch list per XCD
+enum MegaOpType : int { MO_CONV_BD = 0, MO_CONV_K2 = 1, MO_CONV_F32V2 = 2, MO_STEM3 = 3 };
+
+struct MegaOp {
+    int type, items, npass, pad;
+    ConvParams conv;
+};
+struct MegaArgs {
+    const MegaOp* prog[8];     // launch list of the frame on XCD x
+    int n_ops[8];
+    unsigned* sync;            // [8][16] per XCD {joined, arrived, ...} then [128] = error word; zeroed before every launch
+    int nb;                    // blocks per XCD
+    unsigned long long* stamps; // debug: [8][512] s_memrealtime after every op's barrier (block of rank 0), null in production
+};
+
+size_t mega_lds_bytes(const MegaOp& o);                                  // dynamic LDS the op's body needs
+void mega_make_conv_op(const ConvParams& p, int tile, MegaOp* out);        // p as launch_conv would get it (tile, slices, workspaces set)
+void launch_mega(const MegaArgs& a, size_t lds_bytes, hipStream_t s);      // zeroes a.sync, launches 8 * a.nb blocks
+
 // ---- auxiliary kernels (aux_kernels.hip) ----
 void launch_nchw_to_nhwc(const float* in, float* out, int N, int C, int H, int W, hipStream_t s);
 void launch_nhwc_to_nchw(const float* in, int in_ld, float* out, int N, int C, int H, int W, hipStream_t s);

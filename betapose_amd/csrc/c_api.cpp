@@ -754,6 +754,89 @@ int bp_pipeline_run(bp_pipeline* p, int use_graph, void* stream) {
     BP_CATCH
 }
 
+// ------------------------------------------------------------------ xcd mode (mega.inc): prototype entry point, experimental library only
+#ifdef BP_EXPERIMENTAL
+// The convolution launch lists of up to eight detector engines (clones: own activations, shared filters), one per XCD, in ONE
+// persistent launch; `iters` launches timed with events.  The engines' inputs must already be in place (a forward pass of the
+// ordinary path leaves them there); afterwards every engine's activations hold what its own launches would have produced.
+int bp_mega_yolo_convs_stamped(bp_yolo** ys, int n, int blocks_per_xcd, int iters, float* ms_per_launch, unsigned* err_word,
+                               float* op_us, int* op_info, int cap, void* stream);
+int bp_mega_yolo_convs(bp_yolo** ys, int n, int blocks_per_xcd, int iters, float* ms_per_launch, unsigned* err_word, void* stream) {
+    return bp_mega_yolo_convs_stamped(ys, n, blocks_per_xcd, iters, ms_per_launch, err_word, nullptr, nullptr, 0, stream);
+}
+// ... with per-op marks of XCD 0's launch list: op_us[i] = duration of op i incl. its barrier, op_info[3 i] = {type, items, K slices}
+int bp_mega_yolo_convs_stamped(bp_yolo** ys, int n, int blocks_per_xcd, int iters, float* ms_per_launch, unsigned* err_word,
+                               float* op_us, int* op_info, int cap, void* stream) {
+    BP_TRY
+    BP_CHECK(ys && n >= 1 && n <= 8 && blocks_per_xcd >= 1 && blocks_per_xcd <= 256 && iters >= 1, "bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    BP_HIP(hipSetDevice(ys[0]->device));
+    bp::MegaArgs a{};
+    std::vector<void*> dev;
+    size_t lds = 0;
+    for (int k = 0; k < n; ++k) {
+        std::vector<bp::MegaOp> ops;
+        ys[k]->net->emit_conv_ops(1, ops);
+        if (const char* e = std::getenv("BP_MEGA_EXP")) {          // prototype experiments: 1 = barriers only (no work items), 2 = without the RGB stem
+            const int m = std::atoi(e);
+            for (bp::MegaOp& o : ops) {
+                if (m == 1) o.items = 0;
+                if (m == 2 && o.type == bp::MO_STEM3) o.items = 0;
+            }
+        }
+        for (const bp::MegaOp& o : ops) lds = std::max(lds, bp::mega_lds_bytes(o));
+        void* d = nullptr;
+        BP_HIP(hipMalloc(&d, ops.size() * sizeof(bp::MegaOp)));
+        dev.push_back(d);
+        BP_HIP(hipMemcpy(d, ops.data(), ops.size() * sizeof(bp::MegaOp), hipMemcpyHostToDevice));
+        a.prog[k] = (const bp::MegaOp*)d;
+        a.n_ops[k] = (int)ops.size();
+    }
+    unsigned* sync = nullptr;
+    BP_HIP(hipMalloc((void**)&sync, 129 * sizeof(unsigned)));
+    dev.push_back(sync);
+    a.sync = sync;
+    a.nb = blocks_per_xcd;
+    unsigned long long* d_st = nullptr;
+    if (op_us) {
+        BP_HIP(hipMalloc((void**)&d_st, 8 * 512 * sizeof(unsigned long long)));
+        BP_HIP(hipMemset(d_st, 0, 8 * 512 * sizeof(unsigned long long)));
+        dev.push_back(d_st);
+        a.stamps = d_st;
+    }
+    hipEvent_t e0, e1;
+    BP_HIP(hipEventCreate(&e0));
+    BP_HIP(hipEventCreate(&e1));
+    bp::launch_mega(a, lds, s);                 // warm
+    BP_HIP(hipStreamSynchronize(s));
+    BP_HIP(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) bp::launch_mega(a, lds, s);
+    BP_HIP(hipEventRecord(e1, s));
+    BP_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    BP_HIP(hipEventElapsedTime(&ms, e0, e1));
+    if (ms_per_launch) *ms_per_launch = ms / iters;
+    unsigned err = 0;
+    BP_HIP(hipMemcpy(&err, sync + 128, sizeof(unsigned), hipMemcpyDeviceToHost));
+    if (err_word) *err_word = err;
+    if (op_us) {
+        std::vector<unsigned long long> h(512);
+        BP_HIP(hipMemcpy(h.data(), d_st, 512 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        std::vector<bp::MegaOp> ops;
+        ys[0]->net->emit_conv_ops(1, ops);
+        for (int i = 0; i < (int)ops.size() && i < cap; ++i) {
+            op_us[i] = (float)((double)(h[i + 1] - h[i]) / 100.0);         // 100 MHz reference clock
+            if (op_info) { op_info[3 * i] = ops[i].type; op_info[3 * i + 1] = ops[i].items; op_info[3 * i + 2] = ops[i].conv.splits; }
+        }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    for (void* d : dev) (void)hipFree(d);
+    return 0;
+    BP_CATCH
+}
+#endif
+
 // ------------------------------------------------------------------ host post-processing
 int bp_solve_pnp(const double* pts3d, const double* pts2d, int n, const double* K, double* R, double* t) {
     BP_TRY

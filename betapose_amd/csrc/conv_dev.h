@@ -57,7 +57,9 @@ struct PlaneDesc {
     int np;
     bool f32;                            // the fp32 tensor is stored too (false: every reader takes the planes)
 };
-__device__ __forceinline__ PlaneDesc make_plane_desc(const ConvParams& p) {
+// (P = ConvParams, or the same struct in the constant address space: the persistent kernel of mega.inc reads its launch descriptors from memory)
+template <class P>
+__device__ __forceinline__ PlaneDesc make_plane_desc(const P& p) {
     PlaneDesc d;
     unsigned short* base = p.out16 ? p.out16 : reinterpret_cast<unsigned short*>(p.out);
     const int bytes = (int)min((long long)p.M * p.out_ld * 2, (long long)0x7fffff00);
@@ -85,14 +87,16 @@ __device__ __forceinline__ int xcc_id() {
 }
 // at block start: publish this slice's XCD (a write-through store nobody waits for; it is acknowledged before the block's
 // ticket, which follows an s_waitcnt vmcnt(0))
-__device__ __forceinline__ void xcd_home_mark(const ConvParams& p, int tile_id, int split) {
+template <class P>
+__device__ __forceinline__ void xcd_home_mark(const P& p, int tile_id, int split) {
     if (threadIdx.x == 0) __hip_atomic_store(&p.xcc_of[tile_id * 64 + split], xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // in the reducing block: every slice of the tile must have run on this block's XCD.  A mismatch TRAPS: the whole HIP context
 // (every stream of the process) is lost, not just this launch -- which is why the layout is used in the opt-in latency mode only,
 // on ordinary (unmasked) streams whose dispatch the one-time probe (engine.cpp xcc_base) has seen to be round robin; bench.py
 // never combines it with --partition (CU-masked queues)
-__device__ __forceinline__ void xcd_home_verify(const ConvParams& p, int tile_id) {
+template <class P>
+__device__ __forceinline__ void xcd_home_verify(const P& p, int tile_id) {
     if ((int)threadIdx.x < p.splits &&
         __hip_atomic_load(&p.xcc_of[tile_id * 64 + (int)threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != xcc_id())
         __builtin_trap();
@@ -101,13 +105,13 @@ __device__ __forceinline__ void xcd_home_verify(const ConvParams& p, int tile_id
 // A block past the work grid (ConvParams::pf_*): pull its share of the next layer's filters through the memory hierarchy.
 // The bytes are dropped into 1 KB of LDS per wave (LDS-DMA: no registers, nothing for the compiler to discard); the wave
 // ends when they have arrived.
-template <int NT>
-__device__ __forceinline__ void prefetch_block(const ConvParams& p, char* lds) {
-    const int e = (int)blockIdx.x - p.pf_first;
+template <int NT, class P>
+__device__ __forceinline__ void prefetch_block(const P& p, char* lds, const int bp_bid) {
+    const int e = bp_bid - p.pf_first;
     if (e < 0) return;                                   // padding between the work grid and the first prefetch block
     // pf_first is a multiple of 8: this block sits on the XCD of residue x, whose work blocks of the next launch read the
     // N-tiles n == x (mod g); it takes the ql-th (N-tile, K-slice) pair of those
-    const int x = (int)blockIdx.x & 7, ql = e >> 3;
+    const int x = bp_bid & 7, ql = e >> 3;
     const int g = p.pf_ntn < 8 ? p.pf_ntn : 8;
     if (ql >= (p.pf_ntn / g) * p.pf_splits) return;
     const int j = ql / p.pf_splits, split = ql - j * p.pf_splits;
@@ -143,7 +147,8 @@ __device__ __forceinline__ void emit_planes4(const PlaneDesc& d, f32x4 v, unsign
     }
 }
 // one element (store modes / alignments the 16-B path does not cover); idx = element index inside the output view
-__device__ __forceinline__ void emit_plane1(const ConvParams& p, long long idx, float v) {
+template <class P>
+__device__ __forceinline__ void emit_plane1(const P& p, long long idx, float v) {
     if (!p.out16) return;
     if (p.out_np == 1) {
         const _Float16 h = (_Float16)v;
@@ -169,7 +174,8 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // v = raw accumulator for output element (m, n); bias = p.bias[n] (loaded once per lane by the caller: the
 // epilogue's stores may alias p.bias as far as the compiler knows, so an in-loop load is re-issued and waited
 // for after every store -- 16 serialized L2 round trips per tile, measured as the dominant cost of short layers)
-__device__ __forceinline__ void epilogue_store(const ConvParams& p, int m, int n, float v, float bias) {
+template <class P>
+__device__ __forceinline__ void epilogue_store(const P& p, int m, int n, float v, float bias) {
     v += bias;
     int b = 0, pix = m;
     const int hw = p.OH * p.OW;
@@ -226,7 +232,8 @@ __device__ __forceinline__ void epilogue_store(const ConvParams& p, int m, int n
 
 // 16 accumulators of one lane: column n, rows m_base + (r&3) + 8*(r>>2) -- element-wise epilogue for the store
 // modes / alignments the staged float4 path does not cover (heads with 18 channels, upsample, PixelShuffle, NCHW)
-__device__ __forceinline__ void epilogue_tile(const ConvParams& p, const f32x16& v, int m_base, int n) {
+template <class P>
+__device__ __forceinline__ void epilogue_tile(const P& p, const f32x16& v, int m_base, int n) {
     if (n >= p.Cout) return;
     const float bias = p.bias[n];
     static_for<16>([&](auto ec) __attribute__((always_inline)) {

@@ -244,11 +244,10 @@ __global__ __launch_bounds__(64 * NW) void conv_halo_kernel(const ConvParams p) 
 // The halo stage of a K group is single-buffered (two stages = the LDS footprint of the double-buffered 64x128 tile): the next
 // channel group's halo waits in registers during the nine taps and is split / parked between two barriers.
 // =====================================================================================================================
-template <int NPASS>
-__global__ __launch_bounds__(256) void conv_halo_k2_kernel(const ConvParams p) {
+template <int NPASS, class P>
+__device__ __forceinline__ void conv_halo_k2_body(const P& p, const int bp_bid, float* const smem, int* const s_last_p) {
     constexpr int NT = 256, BM = 64, BN = 64, TM = 2, TN = 1, LDT = BN + 4;
     constexpr int RPP = 32;                      // halo rows per loader pass of a K group (128 threads, 4 per row)
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     char* const lds = reinterpret_cast<char*>(smem);
 
     const unsigned long long t_entry = p.stamps ? bp_clock() : 0ull;
@@ -257,8 +256,8 @@ __global__ __launch_bounds__(256) void conv_halo_k2_kernel(const ConvParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kg = wave >> 1, wn = wave & 1;
     const int n_tiles_n = p.CoutPad / BN;
-    const int split = (int)blockIdx.x % p.splits;
-    const int tile_id = (int)blockIdx.x / p.splits;
+    const int split = bp_bid % p.splits;
+    const int tile_id = bp_bid / p.splits;
     const int tile_n = tile_id % n_tiles_n;
     const int tile_m = tile_id / n_tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -444,9 +443,8 @@ __global__ __launch_bounds__(256) void conv_halo_k2_kernel(const ConvParams p) {
     const int w_row0 = 0, w_col0 = 32 * wn;
     const bool has_acc = kg == 0;
     // (conv_tail.inc indexes the slab by `wave`: the accumulator-owning waves are 0 and 1 = the two column halves)
-    __shared__ int s_last;
 #define BP_NT NT
-#define BP_SLAST s_last
+#define BP_SLAST (*s_last_p)
 #define BP_EARLY_BIAS bias_early
 #define BP_HAS_ACC has_acc
 #define BP_TAIL_STAMP(k_) BHK_STAMP(k_)
@@ -458,6 +456,13 @@ __global__ __launch_bounds__(256) void conv_halo_k2_kernel(const ConvParams p) {
 #undef BP_SLAST
     if (p.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); BHK_STAMP(4); }
 #undef BHK_STAMP
+}
+
+template <int NPASS>
+__global__ __launch_bounds__(256) void conv_halo_k2_kernel(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __shared__ int s_last;
+    conv_halo_k2_body<NPASS>(p, (int)blockIdx.x, smem, &s_last);
 }
 
 bool conv_tile_is_halo(int tile) { return tile == TILE_HALO64 || tile == TILE_HALO128 || tile == TILE_HALO64K2; }

@@ -42,11 +42,12 @@ namespace bp {
 //   2  Cin <= 4 with filters packed 4 channels per tap (the two RGB stems): one 16-B load per TAP -- the thread's
 //      group is tap chunk*8 + (tid & 7); with Cin = 3 the 4th float it reads is the neighbouring pixel's first channel
 //      (or 0 past the tensor), which meets a zero filter entry.
-template <int TM, int TN, int VEC>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
+// (kernel bodies are __device__ functions of (launch descriptor, block index, LDS base, LDS flag word): the __global__ kernels
+// below them are thin wrappers, and the persistent per-XCD kernel of mega.inc calls the same bodies with block indices of its own)
+template <int TM, int TN, int VEC, class P>
+__device__ __forceinline__ void conv_igemm_body(const P& p, const int bp_bid, float* const smem, int* const s_last_p) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int RA = BM / 32, RB = BN / 32;
-    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDS_LD];
     float (*As)[BM * LDS_LD] = reinterpret_cast<float (*)[BM * LDS_LD]>(smem);
     float (*Bs)[BN * LDS_LD] = reinterpret_cast<float (*)[BN * LDS_LD]>(smem + 2 * BM * LDS_LD);
     constexpr int LDT = BN + 4;                 // row stride of the output tile staged through LDS in the epilogue
@@ -60,8 +61,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     const int n_tiles_n = p.CoutPad / BN;
     // 1-D grid, K-slice fastest: consecutive block ids (= consecutive XCDs) take different K-slices of the same
     // output tile, so with 8 slices every XCD streams its own 1/8 of the filters through its private L2
-    const int split = (int)blockIdx.x % p.splits;
-    const int tile_id = (int)blockIdx.x / p.splits;
+    const int split = bp_bid % p.splits;
+    const int tile_id = bp_bid / p.splits;
     const int tile_n = tile_id % n_tiles_n;
     const int tile_m = tile_id / n_tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -253,8 +254,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         BP_MF(fa1, fb1, w);                          BP_SB();                                          \
     }
 
-#define BP_STAMP(k_) if (p.stamps && tid == 0) p.stamps[(long long)blockIdx.x * 8 + (k_)] = bp_clock();
-    if (p.stamps && tid == 0) p.stamps[(long long)blockIdx.x * 8 + 0] = t_entry;
+#define BP_STAMP(k_) if (p.stamps && tid == 0) p.stamps[(long long)bp_bid * 8 + (k_)] = bp_clock();
+    if (p.stamps && tid == 0) p.stamps[(long long)bp_bid * 8 + 0] = t_entry;
     BP_STAMP(1);   // index math done
     if (c_begin < c_end) {
         // prologue: chunks c, c+1 in flight; park c in LDS[0]; first fragments; addresses of chunk c+2
@@ -281,15 +282,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     BP_STAMP(3);   // K loop done
 
     const int w_row0 = wm * (BM / 2), w_col0 = wn * (BN / 2);
-    __shared__ int s_last;
 #define BP_NT 256
-#define BP_SLAST s_last
+#define BP_SLAST (*s_last_p)
 #define BP_TAIL_STAMP(k_) BP_STAMP(k_)
 #include "conv_tail.inc"
 #undef BP_TAIL_STAMP
 #undef BP_NT
 #undef BP_SLAST
     if (p.stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); BP_STAMP(4); }
+}
+
+template <int TM, int TN, int VEC>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * (64 * TM + 64 * TN) * LDS_LD];
+    __shared__ int s_last;
+    conv_igemm_body<TM, TN, VEC>(p, (int)blockIdx.x, smem, &s_last);
 }
 
 // The product launches ONE instantiation of the template below, <1, 1, 3, true> ("filters direct", the bf16x3 mode's planned
@@ -327,23 +334,27 @@ static constexpr bool BP_ABL_MFMA = false;
 // run into (profiles/r02_ablate_pipeline.txt: with the MFMAs AND the operand split compiled out the frame gets 10 %
 // faster, with the K loops cut to one chunk 84 %); the price is that a fragment is fetched by the two waves that share
 // its columns (32 KB instead of 20 KB per chunk through the vector-memory path, which has the room).
-template <int TM, int TN, int NP, bool BD = false>
-__global__ __launch_bounds__(256) void conv_igemm_h_kernel(const ConvParams p) {
+template <int TM, int TN, int NP, bool BD>
+struct IgemmHLds {
+    static constexpr int BM = 64 * TM, BN = 64 * TN, LDT = BN + 4;
+    static constexpr int STAGE_HALFS = NP * (BM + (BD ? 0 : BN)) * LDH;
+    static constexpr int FLOATS = (2 * STAGE_HALFS / 2 > BM * LDT) ? 2 * STAGE_HALFS / 2 : BM * LDT;
+};
+template <int TM, int TN, int NP, bool BD, class P>
+__device__ __forceinline__ void conv_igemm_h_body(const P& p, const int bp_bid, float* const smem, int* const s_last_p) {
     static_assert(!BD || (TM == 1 && TN == 1), "filters-direct variant: 64x64 tile");
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int RA = BM / 64;          // fp32 A rows per thread (8 consecutive floats each: two 16-B loads, one 16-B LDS store per plane)
     constexpr int RBH = BN / 64;         // 16-bit B rows per thread and plane (8 elements each)
     constexpr int LDT = BN + 4;
-    constexpr int STAGE_HALFS = NP * (BM + (BD ? 0 : BN)) * LDH;
-    constexpr int SMEM_FLOATS = (2 * STAGE_HALFS / 2 > BM * LDT) ? 2 * STAGE_HALFS / 2 : BM * LDT;
-    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
+    constexpr int STAGE_HALFS = IgemmHLds<TM, TN, NP, BD>::STAGE_HALFS;
     unsigned short* const sh = reinterpret_cast<unsigned short*>(smem);
     typedef typename HalfOps<NP>::frag frag_t;
     // stage s: NP planes of A rows, then NP planes of B rows
 #define BH_AS(s_, pl_) (sh + (s_) * STAGE_HALFS + (pl_) * (BM * LDH))
 #define BH_BS(s_, pl_) (sh + (s_) * STAGE_HALFS + NP * (BM * LDH) + (pl_) * (BN * LDH))
 
-    if (p.work_blocks && (int)blockIdx.x >= p.work_blocks) { prefetch_block<256>(p, reinterpret_cast<char*>(smem)); return; }
+    if (p.work_blocks && bp_bid >= p.work_blocks) { prefetch_block<256>(p, reinterpret_cast<char*>(smem), bp_bid); return; }
     const unsigned long long t_entry = p.stamps ? bp_clock() : 0ull;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -352,16 +363,16 @@ __global__ __launch_bounds__(256) void conv_igemm_h_kernel(const ConvParams p) {
     const int n_tiles_n = p.CoutPad / BN;
     int split, tile_n, tile_m;
     if (p.xcd_home) {  // all K slices of a tile on one XCD (ConvParams::xcd_home)
-        const int i = (int)blockIdx.x >> 3, tl = i / p.splits;
-        const int t = tl * 8 + ((int)blockIdx.x & 7);
+        const int i = bp_bid >> 3, tl = i / p.splits;
+        const int t = tl * 8 + (bp_bid & 7);
         if (t >= p.n_tiles) return;                      // padding of the last round of tiles
         split = i - tl * p.splits;
         tile_n = t % n_tiles_n;
         tile_m = t / n_tiles_n;
         xcd_home_mark(p, t, split);
     } else {
-        split = (int)blockIdx.x % p.splits;
-        const int t = (int)blockIdx.x / p.splits;
+        split = bp_bid % p.splits;
+        const int t = bp_bid / p.splits;
         tile_n = t % n_tiles_n;
         tile_m = t / n_tiles_n;
     }
@@ -581,9 +592,8 @@ __global__ __launch_bounds__(256) void conv_igemm_h_kernel(const ConvParams p) {
     BH_STAMP(3);   // K loop done
 
     const int w_row0 = wm * (BM / 2), w_col0 = wn * (BN / 2);
-    __shared__ int s_last;
 #define BP_NT 256
-#define BP_SLAST s_last
+#define BP_SLAST (*s_last_p)
 #define BP_EARLY_BIAS bias_early
 #define BP_TAIL_STAMP(k_) BH_STAMP(k_)
 #include "conv_tail.inc"
@@ -603,6 +613,13 @@ __global__ __launch_bounds__(256) void conv_igemm_h_kernel(const ConvParams p) {
 #undef BH_PHASE
 }
 
+template <int TM, int TN, int NP, bool BD = false>
+__global__ __launch_bounds__(256) void conv_igemm_h_kernel(const ConvParams p) {
+    __shared__ __attribute__((aligned(16))) float smem[IgemmHLds<TM, TN, NP, BD>::FLOATS];
+    __shared__ int s_last;
+    conv_igemm_h_body<TM, TN, NP, BD>(p, (int)blockIdx.x, smem, &s_last);
+}
+
 thread_local ConvProfHook* g_conv_prof = nullptr;
 
 // =====================================================================================================================
@@ -614,15 +631,15 @@ thread_local ConvProfHook* g_conv_prof = nullptr;
 // (coalesced, zero outside the image), the filters broadcast from LDS, 216 FMAs per lane, then bias / activation / store
 // (fp32 and / or the operand planes of the next layer).  Same sums as the GEMM in a fixed tap-major order.
 // =====================================================================================================================
-template <int CG>   // channel groups of 8 = waves per block
-__global__ __launch_bounds__(64 * CG) void stem3x3_kernel(const ConvParams p) {
+template <int CG, class P>   // channel groups of 8 = waves per block
+__device__ __forceinline__ void stem3x3_body(const P& p, const int bp_bid, f32x4* const tile) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int cg = __builtin_amdgcn_readfirstlane(tid >> 6);
     // the filters of the wave's 8 channels are wave-uniform: scalar loads (p.w [CoutPad][Kpad], k = tap * 4 + ci), operands of
     // the FMAs straight from scalar registers
     const float* __restrict__ wrow = p.w + (long long)(cg * 8) * p.Kpad;
-    __shared__ f32x4 tile[64 * (2 * CG + 1)];          // the block's 64 pixels x 8 CG channels (+ 16 B per row against bank conflicts)
-    const int m0 = (int)blockIdx.x * 64;
+    // tile: 64 * (2 CG + 1) x 16 B of LDS -- the block's 64 pixels x 8 CG channels (+ 16 B per row against bank conflicts)
+    const int m0 = bp_bid * 64;
     const int m = min(m0 + lane, p.M - 1);      // (rows past M compute a duplicate of the last pixel and are not stored)
     const int hw = p.OH * p.OW;
     const int b = m / hw, rem = m - b * hw;
@@ -681,6 +698,12 @@ __global__ __launch_bounds__(64 * CG) void stem3x3_kernel(const ConvParams p) {
             emit_planes4(pd, v, off >> 1);
         }
     }
+}
+
+template <int CG>
+__global__ __launch_bounds__(64 * CG) void stem3x3_kernel(const ConvParams p) {
+    __shared__ f32x4 tile[64 * (2 * CG + 1)];
+    stem3x3_body<CG>(p, (int)blockIdx.x, tile);
 }
 
 bool conv_stem3_eligible(const ConvParams& p) {

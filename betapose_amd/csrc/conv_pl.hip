@@ -81,7 +81,7 @@ __global__ __launch_bounds__(64 * (WM * WN * KG + LW)) void conv_pl_kernel(const
     __shared__ __attribute__((aligned(16))) float smem[SMEM_BYTES / 4];
     typedef typename HalfOps<NP>::frag frag_t;
 
-    if (p.work_blocks && (int)blockIdx.x >= p.work_blocks) { prefetch_block<NT>(p, reinterpret_cast<char*>(smem)); return; }
+    if (p.work_blocks && (int)blockIdx.x >= p.work_blocks) { prefetch_block<NT>(p, reinterpret_cast<char*>(smem), (int)blockIdx.x); return; }
     const unsigned long long t_entry = p.stamps ? bp_clock() : 0ull;
     const int tid = threadIdx.x;
     const int lane = tid & 63;

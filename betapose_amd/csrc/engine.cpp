@@ -906,13 +906,14 @@ bool Net::pooled_by_conv(const Op& pool, int batch) const {
     return pool_in_epilogue(prev, batch, tile);
 }
 
-void Net::run_op(const Op& op, int batch, hipStream_t s) {
-    switch (op.type) {
-        case OP_CONV: {
-            ConvParams p = op.conv;
+// the launch descriptor of convolution `op` at this batch size under the current plan: tile, K slices, workspaces, epilogue extras
+void Net::prepare_conv(const Op& op, int batch, ConvParams& p, int& tile) {
+    {
+        {
+            p = op.conv;
             p.N = batch;
             p.M = batch * p.OH * p.OW;
-            int tile, splits, cps;
+            int splits, cps;
             choose_launch(op, batch, force_tile_, sk_target_, sk_min_chunks_, sk_max_splits_, &tile, &splits, &cps);
             while (splits > 1 && (size_t)splits * conv_tiles(p, tile) * conv_tile_bm(tile) * conv_tile_bn(tile) > partial_floats_) {
                 conv_split_plan(p, tile, splits - 1, &splits, &cps);
@@ -949,6 +950,32 @@ void Net::run_op(const Op& op, int batch, hipStream_t s) {
                     break;
                 }
             }
+        }
+    }
+}
+
+#ifdef BP_EXPERIMENTAL
+// xcd mode (mega.inc): the convolution launches of one pass, in order, as descriptors for the persistent kernel
+void Net::emit_conv_ops(int batch, std::vector<MegaOp>& out) {
+    BP_CHECK(batch >= 1 && batch <= max_batch_, "batch out of range");
+    for (const Op& op : ops_) {
+        if (op.type != OP_CONV) continue;
+        ConvParams p;
+        int tile;
+        prepare_conv(op, batch, p, tile);
+        MegaOp o;
+        mega_make_conv_op(p, tile, &o);
+        out.push_back(o);
+    }
+}
+#endif
+
+void Net::run_op(const Op& op, int batch, hipStream_t s) {
+    switch (op.type) {
+        case OP_CONV: {
+            ConvParams p;
+            int tile;
+            prepare_conv(op, batch, p, tile);
             launch_conv(p, tile, s);
         } break;
         // (producers that are not convolutions: the pooling / shuffle kernels write their operand planes themselves; the

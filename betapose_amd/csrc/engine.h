@@ -78,6 +78,10 @@ public:
     int max_batch() const { return max_batch_; }
     void run_ops(int batch, hipStream_t s);
     void run_op(const Op& op, int batch, hipStream_t s);
+    void prepare_conv(const Op& op, int batch, ConvParams& p, int& tile);
+#ifdef BP_EXPERIMENTAL
+    void emit_conv_ops(int batch, std::vector<MegaOp>& out);   // xcd-mode prototype (mega.inc): the pass's convolution launches as descriptors
+#endif
     // eager profiling pass: mean device ms per op; info[i] = {is_conv, tile, kernel (0 scalar-gather fp32, 1 vector
     // fp32, 2 fp16-MFMA, 3 bf16x3), splits}
     int profile(int batch, int iters, float* ms, int* info, int cap, hipStream_t s);
