@@ -79,7 +79,7 @@ static std::string read_text(const char* path) {
 }
 
 // Built-in default of newly created engines: bf16x3 = fp32-accurate convolution on the bf16 matrix pipe (exact 3-way
-// operand split, passes the whole parity suite at the fp32 bars).  BP_PRECISION=f32|bf16x3|f16 overrides
+// operand split, passes the whole parity suite at the fp32 bars).  BP_PRECISION=f32|bf16x3|f16|f16r overrides
 // it (bp_*_set_precision still wins).
 static int default_precision() {
     const char* e = std::getenv("BP_PRECISION");
@@ -87,8 +87,9 @@ static int default_precision() {
     const std::string v(e);
     if (v == "f32") return bp::PREC_F32;
     if (v == "f16") return bp::PREC_F16;
+    if (v == "f16r") return bp::PREC_F16_RES;
     if (v == "bf16x3") return bp::PREC_BF16X3;
-    throw bp::Error("BP_PRECISION must be f32, bf16x3 or f16, not '" + v + "'");
+    throw bp::Error("BP_PRECISION must be f32, bf16x3, f16 or f16r, not '" + v + "'");
 }
 
 extern "C" {
