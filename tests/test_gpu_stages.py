@@ -330,3 +330,18 @@ def test_decode_select_fused_equals_the_two_kernel_path(engines, cuda):
         for b in range(4):
             if int(idx[b]) >= 0:
                 assert float(pred[b, int(idx[b]), 4]) == float(fused[b, 5]) > conf
+
+
+def test_pipeline_prepare_builds_the_graph_without_running(engines, cuda):
+    """bp_pipeline_prepare (set-up step: capture + instantiate, nothing executes): results untouched until the first run, which is then
+    a plain graph launch with the same record as an unprepared pipeline's."""
+    det, pose = engines
+    fr = helpers.frames(1)[0]
+    plain = FramePipeline(det, pose, 480, 640, batch=1, use_graph=True)
+    rec0 = plain.run(fr)[0].copy()
+    fp = FramePipeline(det, pose, 480, 640, batch=1, use_graph=True)
+    fp.prepare()
+    assert float(fp.results.abs().sum()) == 0.0 and fp.kernel_count() > 100       # graph built, nothing ran
+    assert np.array_equal(fp.run(fr)[0].view(np.int32), rec0.view(np.int32))
+    fp.prepare()                                                                  # idempotent
+    assert np.array_equal(fp.run(fr)[0].view(np.int32), rec0.view(np.int32))

@@ -14,7 +14,7 @@ from betapose_amd.pipeline import FramePipeline
 ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=3000)
 ap.add_argument("--streams", type=int, default=4)
-ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3", "f16"])
+ap.add_argument("--precision", default="bf16x3", choices=["f32", "bf16x3", "f16", "f16r"])
 ap.add_argument("--latency-mode", action="store_true",
                 help="bp_*_set_prefetch: split-K hand-off inside one XCD's L2 + filter prefetch blocks; the reference pass is taken WITHOUT it, "
                      "so the soak also proves the mode bit-identical to the default under load")

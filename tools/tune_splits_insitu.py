@@ -25,7 +25,7 @@ def fps(p, steps=400):
             f.write("%d %d %d 12 %d\n" % (M, cp, n, s))
     env = dict(os.environ, BP_PLAN_FILE=f.name)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "40", "--no-side-runs",
-                          "--no-cpu-baseline --no-served-legs --no-flip-rate", "--no-roofline", "--other-modes", ""], capture_output=True, text=True, env=env).stdout
+                          "--no-cpu-baseline", "--no-served-legs", "--no-flip-rate", "--no-roofline", "--other-modes", ""], capture_output=True, text=True, env=env).stdout
     os.unlink(f.name)
     return json.loads(out.strip().splitlines()[-1])["value"]
 
