@@ -62,7 +62,7 @@ template <class P>
 __device__ __forceinline__ PlaneDesc make_plane_desc(const P& p) {
     PlaneDesc d;
     unsigned short* base = p.out16 ? p.out16 : reinterpret_cast<unsigned short*>(p.out);
-    const int bytes = (int)min((long long)p.M * p.out_ld * 2, (long long)0x7fffff00);
+    const int bytes = (int)min((long long)p.M * p.out_ld * (p.store_mode == ST_PIXSHUF ? 8 : 2), (long long)0x7fffff00);   // (a PixelShuffle output has 4 M pixels of out_ld channels)
     d.np = p.out16 ? p.out_np : 0;
     d.f32 = !(p.out16 && p.skip_f32);
     d.r0 = __builtin_amdgcn_make_buffer_rsrc(base, 0, bytes, 0x00020000);
@@ -287,7 +287,8 @@ template <int ACT, int RES, int PASSES, int PF>
 __device__ __forceinline__ void epilogue_rows(const float* srow, int s_step, f32x4 bias4,
                                               __amdgpu_buffer_rsrc_t rsrcO, unsigned off_o, unsigned step_o,
                                               __amdgpu_buffer_rsrc_t rsrcR, unsigned off_r, unsigned step_r, const f32x4* rpre,
-                                              const PlaneDesc& pd, bool r16 = false) {
+                                              const PlaneDesc& pd, bool r16 = false, const unsigned* off_tab = nullptr) {
+    // off_tab (PixelShuffle stores, conv_tail.inc): the output byte offset of every pass instead of off_o + pass * step_o
     // PF: the residual rows were requested before the tile was staged (rpre[pass], registers): a cold 16-B load costs the
     // block > 1 us at the very end of the kernel otherwise
 #pragma unroll
@@ -309,6 +310,7 @@ __device__ __forceinline__ void epilogue_rows(const float* srow, int s_step, f32
         }
         if constexpr (RES == 2) v += r4;
         const u32x4 o = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+        if (off_tab) off_o = off_tab[pass];
         if (pd.f32) __builtin_amdgcn_raw_buffer_store_b128(o, rsrcO, (int)off_o, 0, 0);
         emit_planes4(pd, v, off_o >> 1);      // the planes mirror the fp32 view: same element index, half the bytes
         srow += s_step;
