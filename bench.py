@@ -342,6 +342,8 @@ def roofline(det, pose, batch):
             return "bp::conv_halo_kernel<%d, *>" % (2 if tile == 21 else 4)   # tap-resident halo (conv_halo.hip); * = loader passes, by map width
         if tile == 23:
             return "bp::conv_halo_k2_kernel<*>"                            # ... with two K groups inside the block
+        if tile == 24:
+            return "bp::conv_igemm_bdk2_kernel"                            # filters direct, two K groups inside an eight-wave block
         if tile in (7, 8, 9):
             return "bp::conv_kg_kernel<%d, 3>" % {7: 1, 8: 2, 9: 4}[tile]
         if tile in (10, 11):

@@ -150,7 +150,8 @@ enum ConvTile : int { TILE_64x64 = 0, TILE_128x64 = 1, TILE_W64_1x1 = 2, TILE_W6
                       TILE_HALO64 = 21,     // 64x64 block, 2 waves
                       TILE_HALO128 = 22,    // 64x128 block, 4 waves
                       TILE_HALO64K2 = 23,   // 64x64 block, 4 waves = 2 K groups x 2 column halves: the K split inside the block (no slabs)
-                      TILE_LAST = 23 };
+                      TILE_BD_K2 = 24,      // the filters-direct 64x64 tile with 8 waves = 2 K groups of 2x2 waves (conv_igemm.hip, any kernel size / stride)
+                      TILE_LAST = 24 };
 
 // when non-null, launch_conv brackets the implicit-GEMM kernel itself (not the split-K reduce) with these events
 struct ConvProfHook { hipEvent_t e0, e1; };

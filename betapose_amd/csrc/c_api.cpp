@@ -496,7 +496,7 @@ int bp_conv2d_planes(const float* d_in, int N, int H, int W, int Cin, const floa
         net.set_precision(prec);
         net.ops_[0].conv.mfma_mode = prec;
 #ifndef BP_EXPERIMENTAL
-        BP_CHECK(bp::conv_tile_is_pl(t) || ((t == bp::TILE_64x64_BD || bp::conv_tile_is_halo(t)) && prec == bp::PREC_BF16X3),
+        BP_CHECK(bp::conv_tile_is_pl(t) || ((t == bp::TILE_64x64_BD || t == bp::TILE_BD_K2 || bp::conv_tile_is_halo(t)) && prec == bp::PREC_BF16X3),
                  "this kernel id exists only in the experimental library (python -m betapose_amd.build --experimental, BP_LIB)");
 #endif
     } else {

@@ -278,6 +278,25 @@ __device__ __forceinline__ int fast_div(int m, int d, float rcp) {
 }
 
 
+// PixelShuffle(2) stores through the staged epilogue: tile row -> byte offset of the thread's four channels in the [2 OH][2 OW][Cout / 4]
+// output (filters pre-permuted: column n' = (i 2 + j) (Cout / 4) + c).  Computed per pass (two exact divisions) rather than kept as a
+// table: four more live registers cost the 64x64 filters-direct kernel its fourth wave per SIMD (132 against 128 VGPRs).
+struct PixShufRows {
+    int m_first, m_step, M, hw, OW, OH, out_ld;
+    unsigned sub;             // ((i 2 OW + j) out_ld + c) 4: the sub-pixel and channel part
+    float rcp_hw, rcp_ow;
+    __device__ __forceinline__ unsigned offset(int pass) const {
+        const int m = m_first + pass * m_step;
+        if (m >= M) return OOB;
+        const int q = (int)((float)m * rcp_hw);
+        int b = q; { const int r = m - q * hw; if (r < 0) --b; else if (r >= hw) ++b; }
+        const int rem = m - b * hw;
+        int oy = (int)((float)rem * rcp_ow); { const int r = rem - oy * OW; if (r < 0) --oy; else if (r >= OW) ++oy; }
+        const int ox = rem - oy * OW;
+        return (unsigned)((((b * 2 * OH + 2 * oy) * (2 * OW) + 2 * ox) * out_ld) * 4) + sub;
+    }
+};
+
 // Row loop of the staged (16-B per lane) epilogue: each pass reads 4 consecutive channels of one tile row from the
 // LDS staging tile, applies bias / residual / activation and stores 16 B.  ACT and RES are compile-time (the caller
 // switches once per block): RES 0 none, 1 add before the activation (ResNet), 2 add after it (YOLO shortcut).
@@ -287,8 +306,8 @@ template <int ACT, int RES, int PASSES, int PF>
 __device__ __forceinline__ void epilogue_rows(const float* srow, int s_step, f32x4 bias4,
                                               __amdgpu_buffer_rsrc_t rsrcO, unsigned off_o, unsigned step_o,
                                               __amdgpu_buffer_rsrc_t rsrcR, unsigned off_r, unsigned step_r, const f32x4* rpre,
-                                              const PlaneDesc& pd, bool r16 = false, const unsigned* off_tab = nullptr) {
-    // off_tab (PixelShuffle stores, conv_tail.inc): the output byte offset of every pass instead of off_o + pass * step_o
+                                              const PlaneDesc& pd, bool r16 = false, const PixShufRows* ps = nullptr) {
+    // ps (PixelShuffle stores, conv_tail.inc): the output byte offset of a pass comes from its row's pixel instead of off_o + pass * step_o
     // PF: the residual rows were requested before the tile was staged (rpre[pass], registers): a cold 16-B load costs the
     // block > 1 us at the very end of the kernel otherwise
 #pragma unroll
@@ -310,7 +329,7 @@ __device__ __forceinline__ void epilogue_rows(const float* srow, int s_step, f32
         }
         if constexpr (RES == 2) v += r4;
         const u32x4 o = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-        if (off_tab) off_o = off_tab[pass];
+        if (ps) off_o = ps->offset(pass);
         if (pd.f32) __builtin_amdgcn_raw_buffer_store_b128(o, rsrcO, (int)off_o, 0, 0);
         emit_planes4(pd, v, off_o >> 1);      // the planes mirror the fp32 view: same element index, half the bytes
         srow += s_step;

@@ -223,9 +223,11 @@ __global__ __launch_bounds__(64 * NW) void conv_halo_kernel(const ConvParams p) 
 #define BP_SLAST s_last
 #define BP_EARLY_BIAS bias_early
 #define BP_EP_PF_MAX 8
+#define BP_EP_PIXSHUF
 #define BP_TAIL_STAMP(k_) BHL_STAMP(k_)
 #include "conv_tail.inc"
 #undef BP_EP_PF_MAX
+#undef BP_EP_PIXSHUF
 #undef BP_EARLY_BIAS
 #undef BP_TAIL_STAMP
 #undef BP_NT
@@ -447,8 +449,10 @@ __device__ __forceinline__ void conv_halo_k2_body(const P& p, const int bp_bid, 
 #define BP_SLAST (*s_last_p)
 #define BP_EARLY_BIAS bias_early
 #define BP_HAS_ACC has_acc
+#define BP_EP_PIXSHUF
 #define BP_TAIL_STAMP(k_) BHK_STAMP(k_)
 #include "conv_tail.inc"
+#undef BP_EP_PIXSHUF
 #undef BP_HAS_ACC
 #undef BP_EARLY_BIAS
 #undef BP_TAIL_STAMP

@@ -340,26 +340,33 @@ struct IgemmHLds {
     static constexpr int STAGE_HALFS = NP * (BM + (BD ? 0 : BN)) * LDH;
     static constexpr int FLOATS = (2 * STAGE_HALFS / 2 > BM * LDT) ? 2 * STAGE_HALFS / 2 : BM * LDT;
 };
-template <int TM, int TN, int NP, bool BD, class P>
+// KG = 2 (filters-direct variant only, round 4): the block is EIGHT waves = two K groups of the 2x2 waves described above; group g
+// walks the g-th half of the block's chunk range with its own LDS stages and its own filter prefetch, the two partial sums meet in
+// LDS behind the K loops (fixed order: deterministic), one tail per tile.  A launch is a latency chain (K loop ~ chunks x memory
+// latency / prefetch depth): two groups halve it without a slab hand-off, or halve the K slices between blocks where slices remain.
+template <int TM, int TN, int NP, bool BD, class P, int KG = 1>
 __device__ __forceinline__ void conv_igemm_h_body(const P& p, const int bp_bid, float* const smem, int* const s_last_p) {
+    static_assert(KG == 1 || (KG == 2 && BD), "K groups: filters-direct variant");
     static_assert(!BD || (TM == 1 && TN == 1), "filters-direct variant: 64x64 tile");
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int RA = BM / 64;          // fp32 A rows per thread (8 consecutive floats each: two 16-B loads, one 16-B LDS store per plane)
     constexpr int RBH = BN / 64;         // 16-bit B rows per thread and plane (8 elements each)
     constexpr int LDT = BN + 4;
     constexpr int STAGE_HALFS = IgemmHLds<TM, TN, NP, BD>::STAGE_HALFS;
-    unsigned short* const sh = reinterpret_cast<unsigned short*>(smem);
+    unsigned short* const sh = reinterpret_cast<unsigned short*>(smem) + (KG > 1 ? ((int)threadIdx.x >> 8) * (2 * STAGE_HALFS) : 0);   // the K group's stages
     typedef typename HalfOps<NP>::frag frag_t;
     // stage s: NP planes of A rows, then NP planes of B rows
 #define BH_AS(s_, pl_) (sh + (s_) * STAGE_HALFS + (pl_) * (BM * LDH))
 #define BH_BS(s_, pl_) (sh + (s_) * STAGE_HALFS + NP * (BM * LDH) + (pl_) * (BN * LDH))
 
-    if (p.work_blocks && bp_bid >= p.work_blocks) { prefetch_block<256>(p, reinterpret_cast<char*>(smem), bp_bid); return; }
+    if (p.work_blocks && bp_bid >= p.work_blocks) { prefetch_block<256 * KG>(p, reinterpret_cast<char*>(smem), bp_bid); return; }
     const unsigned long long t_entry = p.stamps ? bp_clock() : 0ull;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int kgrp = KG > 1 ? __builtin_amdgcn_readfirstlane(wave >> 2) : 0;     // K group of the wave
+    const int tq = KG > 1 ? (tid & 255) : tid;                                   // thread inside its K group
+    const int wm = KG > 1 ? ((wave >> 1) & 1) : (wave >> 1), wn = wave & 1;
     const int n_tiles_n = p.CoutPad / BN;
     int split, tile_n, tile_m;
     if (p.xcd_home) {  // all K slices of a tile on one XCD (ConvParams::xcd_home)
@@ -378,15 +385,20 @@ __device__ __forceinline__ void conv_igemm_h_body(const P& p, const int bp_bid, 
     }
     const int tile_id = tile_m * n_tiles_n + tile_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int c_begin = split * p.chunks_per_split;
+    const int cb_blk = split * p.chunks_per_split;
 #ifdef BP_ABLATE_KLOOP   // timing experiment only (wrong results): one chunk per block, i.e. the fixed cost of the launch chain
-    const int c_end = min(p.nchunks, c_begin + 1);
+    const int ce_blk = min(p.nchunks, cb_blk + 1);
 #else
-    const int c_end = min(p.nchunks, c_begin + p.chunks_per_split);
+    const int ce_blk = min(p.nchunks, cb_blk + p.chunks_per_split);
 #endif
+    // K groups: group g takes chunks [cb_blk + g per, ...) of the block's range; every group makes the same number of trips (`nch`
+    // below): past its own range a group multiplies zero filter fragments (out-of-range loads)
+    const int kg_per = (ce_blk - cb_blk + KG - 1) / KG;
+    const int c_begin = KG > 1 ? min(cb_blk + kgrp * kg_per, ce_blk) : cb_blk;
+    const int c_end = KG > 1 ? min(c_begin + kg_per, ce_blk) : ce_blk;
 
-    const int lr = tid >> 2, a8 = (tid & 3) * 8; // A: row lr (+64i), floats a8..a8+7
-    const int br = tid >> 2, b8 = (tid & 3) * 8; // B: row br (+64i), elements b8..+7
+    const int lr = tq >> 2, a8 = (tq & 3) * 8; // A: row lr (+64i), floats a8..a8+7
+    const int br = tq >> 2, b8 = (tq & 3) * 8; // B: row br (+64i), elements b8..+7
     const int hw = p.OH * p.OW;
     const int plane_bytes = p.CoutPad * p.Kpad * 2;
 
@@ -526,8 +538,8 @@ __device__ __forceinline__ void conv_igemm_h_body(const P& p, const int bp_bid, 
 
     // swizzled element offsets inside a row (all row bases used below are multiples of 32 rows, so (row >> 1) & 3
     // depends on the thread's own row index only)
-    const int a_st_off = ((tid & 3) ^ ((lr >> 1) & 3)) << 3;
-    const int b_st_off = ((tid & 3) ^ ((br >> 1) & 3)) << 3;
+    const int a_st_off = ((tq & 3) ^ ((lr >> 1) & 3)) << 3;
+    const int b_st_off = ((tq & 3) ^ ((br >> 1) & 3)) << 3;
     const int frow = lane & 31, fsw = (frow >> 1) & 3;
     const int frag_ks0 = frow * LDH + (((lane >> 5)) ^ fsw) * 8;          // logical granule (lane>>5)     (k-step 0)
     const int frag_ks1 = frow * LDH + ((2 + (lane >> 5)) ^ fsw) * 8;      // logical granule 2 + (lane>>5) (k-step 1)
@@ -571,7 +583,7 @@ __device__ __forceinline__ void conv_igemm_h_body(const P& p, const int bp_bid, 
 #define BH_PARKED(rn_, rf_) rn_
 #endif
 
-    if (c_begin < c_end) {
+    if (KG > 1 ? cb_blk < ce_blk : c_begin < c_end) {
         BH_ADDR(); BH_LOAD(ra0, rb0);
 #ifndef BP_ABLATE_PREFETCH
         BH_ADDR(); BH_LOAD(ra1, rb1);
@@ -579,7 +591,7 @@ __device__ __forceinline__ void conv_igemm_h_body(const P& p, const int bp_bid, 
         BH_ADDR();
         BH_STORE(0, ra0, rb0);
         __syncthreads();
-        const int nch = c_end - c_begin;
+        const int nch = KG > 1 ? kg_per : c_end - c_begin;
         for (int it = 0; it < (nch >> 1); ++it) {
             BH_PHASE(0, ra1, rb1, ra0, rb0);
             BH_PHASE(1, ra0, rb0, ra1, rb1);
@@ -587,16 +599,37 @@ __device__ __forceinline__ void conv_igemm_h_body(const P& p, const int bp_bid, 
         if (nch & 1) BH_PHASE(0, ra1, rb1, ra0, rb0);
     }
     __syncthreads();
+    if constexpr (KG > 1) {
+        // the groups' partial sums meet in LDS: group 1 parks its accumulators in fragment order (16 B per lane and store), group 0 adds
+        float* const xch = smem + (wave & 3) * 1024 + lane * 4;
+        if (kgrp == 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<f32x4*>(xch + q * 256) = f32x4{acc[0][0][4 * q], acc[0][0][4 * q + 1], acc[0][0][4 * q + 2], acc[0][0][4 * q + 3]};
+        }
+        __syncthreads();
+        if (kgrp == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(xch + q * 256);
+                acc[0][0][4 * q] += v.x; acc[0][0][4 * q + 1] += v.y; acc[0][0][4 * q + 2] += v.z; acc[0][0][4 * q + 3] += v.w;
+            }
+        }
+        __syncthreads();
+    }
 #define BH_STAMP(k_) if (p.stamps && tid == 0) p.stamps[(long long)(tile_id * p.splits + split) * 8 + (k_)] = bp_clock();
     if (p.stamps && tid == 0) p.stamps[(long long)(tile_id * p.splits + split) * 8 + 0] = t_entry;
     BH_STAMP(3);   // K loop done
 
     const int w_row0 = wm * (BM / 2), w_col0 = wn * (BN / 2);
-#define BP_NT 256
+    const bool kg_has_acc = KG == 1 || kgrp == 0;        // (the slab offsets of conv_tail.inc use `wave`: group 0's waves are 0..3)
+#define BP_NT (256 * KG)
 #define BP_SLAST (*s_last_p)
 #define BP_EARLY_BIAS bias_early
+#define BP_HAS_ACC kg_has_acc
 #define BP_TAIL_STAMP(k_) BH_STAMP(k_)
 #include "conv_tail.inc"
+#undef BP_HAS_ACC
 #undef BP_EARLY_BIAS
 #undef BP_TAIL_STAMP
 #undef BP_NT
@@ -618,6 +651,12 @@ __global__ __launch_bounds__(256) void conv_igemm_h_kernel(const ConvParams p) {
     __shared__ __attribute__((aligned(16))) float smem[IgemmHLds<TM, TN, NP, BD>::FLOATS];
     __shared__ int s_last;
     conv_igemm_h_body<TM, TN, NP, BD>(p, (int)blockIdx.x, smem, &s_last);
+}
+// TILE_BD_K2: the filters-direct 64x64 tile with two K groups inside the block (eight waves)
+__global__ __launch_bounds__(512) void conv_igemm_bdk2_kernel(const ConvParams p) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * IgemmHLds<1, 1, 3, true>::FLOATS];
+    __shared__ int s_last;
+    conv_igemm_h_body<1, 1, 3, true, ConvParams, 2>(p, (int)blockIdx.x, smem, &s_last);
 }
 
 thread_local ConvProfHook* g_conv_prof = nullptr;
@@ -836,6 +875,14 @@ void launch_conv(const ConvParams& p, int tile, hipStream_t s) {
         BP_CHECK(conv_h16_eligible(p) && p.w16s != nullptr, "filters-direct tile needs the stage-packed filter copy and Cin % 32 == 0");
         BP_CHECK((long long)3 * p.CoutPad * p.Kpad * 2 < (long long)OOB, "filter planes too large for 32-bit offsets");
         launch_h_t<1, 1, 3, true>(p, s);
+    } else if (tile == TILE_BD_K2) {
+        BP_CHECK(p.mfma_mode == PREC_BF16X3 && conv_h16_eligible(p) && p.w16s != nullptr, "filters-direct K2 tile: bf16x3 mode, stage-packed filter copy, Cin % 32 == 0");
+        BP_CHECK((long long)3 * p.CoutPad * p.Kpad * 2 < (long long)OOB, "filter planes too large for 32-bit offsets");
+        BP_CHECK(!p.xcd_home && !p.pf_ptr, "filters-direct K2 tile: no latency-mode layouts");
+        ConvParams q = p;
+        conv_grid_setup(q, 64, 64);
+        if (g_conv_prof) hipExtLaunchKernelGGL(conv_igemm_bdk2_kernel, dim3(conv_grid_blocks(q)), dim3(512), 0, s, g_conv_prof->e0, g_conv_prof->e1, 0, q);
+        else hipLaunchKernelGGL(conv_igemm_bdk2_kernel, dim3(conv_grid_blocks(q)), dim3(512), 0, s, q);
 #ifdef BP_EXPERIMENTAL
     } else if (conv_tile_is_w64(tile)) {
         launch_conv_w64(p, tile, s);

@@ -104,6 +104,10 @@ static const SplitEntry kSplitTable[] = {
 // heuristics in choose_h16 / choose_pl, which are measured at batch 2, 4 and 28 only (tools/_batch_check.sh, profiles/r04_batched.txt).
 struct PlanEntry { int M, CoutPad, nchunks, tile, splits; };
 static const PlanEntry kPlanB3[] = {
+    // (round 4, TILE_BD_K2 rows: the filters-direct tile with two K groups inside an eight-wave block and about half the K slices
+    // between blocks -- alone it is no faster than the four-wave tile on any shape (tools/bench_bdk2.py, profiles/r04_bdk2_kernels.txt),
+    // in the pipeline the plan with these rows is +2-2.8 % on three boxes (tools/plans/bdk2*.txt, profiles/r04_ab_bdk2.txt): fewer
+    // blocks and slabs for the same work)
     // round 4, conv_halo.hip: the 3x3 / stride-1 layers on the tap-resident halo tile -- rows apply where conv_halo_eligible()
     // holds (a stride-2 layer of the same {M, CoutPad, K-chunks} falls through to its filters-direct row below).  Slice counts from
     // A/B runs of the whole pipeline, four frames in flight (profiles/r04_halo_ab.txt)
@@ -114,6 +118,51 @@ static const PlanEntry kPlanB3[] = {
     {   676,   512,   72, TILE_HALO64K2,  2},
     {  1280,   512,   72, TILE_HALO64K2,  2},
     {  2704,   256,   36, TILE_HALO64K2,  1},
+    {    80,   512,   64, TILE_BD_K2,  4},
+    {    80,   512,  144, TILE_BD_K2,  6},
+    {    80,  2048,   16, TILE_BD_K2,  2},
+    {    80,  2048,   32, TILE_BD_K2,  2},
+    {   169,    64,   32, TILE_BD_K2,  6},
+    {   169,   256,   16, TILE_BD_K2,  3},
+    {   169,   512,   32, TILE_BD_K2,  6},
+    {   169,  1024,  144, TILE_64x64_BD,  5},
+    {   320,   256,   32, TILE_BD_K2,  6},
+    {   320,   256,   72, TILE_BD_K2,  6},
+    {   320,   512,   32, TILE_BD_K2,  3},
+    {   320,  1024,    8, TILE_BD_K2,  1},
+    {   320,  1024,   16, TILE_BD_K2,  2},
+    {   320,  1024,  144, TILE_64x64_BD,  6},
+    {   676,    64,   16, TILE_BD_K2,  3},
+    {   676,   128,    8, TILE_BD_K2,  1},
+    {   676,   256,   16, TILE_BD_K2,  3},
+    {   676,   256,   24, TILE_BD_K2,  3},
+    {   676,   512,   72, TILE_64x64_BD,  5},
+    {  1280,   128,   16, TILE_BD_K2,  3},
+    {  1280,   128,   36, TILE_BD_K2,  3},
+    {  1280,   256,   16, TILE_BD_K2,  2},
+    {  1280,   512,    4, TILE_64x64_BD,  1},
+    {  1280,   512,    8, TILE_BD_K2,  1},
+    {  1280,   512,   72, TILE_64x64_BD,  3},
+    {  2704,    64,    8, TILE_BD_K2,  1},
+    {  2704,   128,    8, TILE_BD_K2,  1},
+    {  2704,   128,   12, TILE_BD_K2,  1},
+    {  2704,   256,   36, TILE_64x64_BD,  2},   // in the pipeline: 2 slices 933, 3: 929, 4: 921, 5+: 910 frames/s (tools/tune_splits_insitu.py)
+    {  5120,    64,    2, TILE_64x64_BD,  1},
+    {  5120,    64,    8, TILE_BD_K2,  1},
+    {  5120,    64,   18, TILE_BD_K2,  2},
+    {  5120,    64,   36, TILE_BD_K2,  2},
+    {  5120,   128,    8, TILE_BD_K2,  1},
+    {  5120,   256,    2, TILE_64x64_BD,  1},
+    { 10816,    64,    4, TILE_BD_K2,  1},
+    { 10816,   128,   18, TILE_BD_K2,  1},
+    { 43264,    64,    2, TILE_64x64_BD,  1},
+    { 43264,    64,    9, TILE_64x64_BD,  1},
+    {0, 0, 0, 0, 0},
+};
+// The lone-frame latency mode (Net::set_prefetch) keeps the four-wave filters-direct tile on the rows the table above gives to TILE_BD_K2:
+// its XCD-local hand-off and filter prefetch blocks exist for that tile (conv_home_layout, conv_prefetch_of), and one frame at a time
+// they are worth more than the K groups (2.46 against 2.56 ms per frame).  Slice counts: the round-3 table.
+static const PlanEntry kPlanB3Lone[] = {
     {    80,   512,   64, TILE_64x64_BD,  6},
     {    80,   512,  144, TILE_64x64_BD, 10},
     {    80,  2048,   16, TILE_64x64_BD,  3},
@@ -121,38 +170,28 @@ static const PlanEntry kPlanB3[] = {
     {   169,    64,   32, TILE_64x64_BD, 10},
     {   169,   256,   16, TILE_64x64_BD,  5},
     {   169,   512,   32, TILE_64x64_BD,  5},
-    {   169,  1024,  144, TILE_64x64_BD,  5},
     {   320,   256,   32, TILE_64x64_BD,  5},
     {   320,   256,   72, TILE_64x64_BD,  8},
     {   320,   512,   32, TILE_64x64_BD,  5},
     {   320,  1024,    8, TILE_64x64_BD,  1},
     {   320,  1024,   16, TILE_64x64_BD,  3},
-    {   320,  1024,  144, TILE_64x64_BD,  6},
     {   676,    64,   16, TILE_64x64_BD,  5},
     {   676,   128,    8, TILE_64x64_BD,  1},
     {   676,   256,   16, TILE_64x64_BD,  3},
     {   676,   256,   24, TILE_64x64_BD,  5},
-    {   676,   512,   72, TILE_64x64_BD,  5},
     {  1280,   128,   16, TILE_64x64_BD,  3},
     {  1280,   128,   36, TILE_64x64_BD,  5},
     {  1280,   256,   16, TILE_64x64_BD,  3},
-    {  1280,   512,    4, TILE_64x64_BD,  1},
     {  1280,   512,    8, TILE_64x64_BD,  1},
-    {  1280,   512,   72, TILE_64x64_BD,  3},
     {  2704,    64,    8, TILE_64x64_BD,  1},
     {  2704,   128,    8, TILE_64x64_BD,  1},
     {  2704,   128,   12, TILE_64x64_BD,  1},
-    {  2704,   256,   36, TILE_64x64_BD,  2},   // in the pipeline: 2 slices 933, 3: 929, 4: 921, 5+: 910 frames/s (tools/tune_splits_insitu.py)
-    {  5120,    64,    2, TILE_64x64_BD,  1},
     {  5120,    64,    8, TILE_64x64_BD,  1},
     {  5120,    64,   18, TILE_64x64_BD,  3},
     {  5120,    64,   36, TILE_64x64_BD,  3},
     {  5120,   128,    8, TILE_64x64_BD,  1},
-    {  5120,   256,    2, TILE_64x64_BD,  1},
     { 10816,    64,    4, TILE_64x64_BD,  1},
     { 10816,   128,   18, TILE_64x64_BD,  2},
-    { 43264,    64,    2, TILE_64x64_BD,  1},
-    { 43264,    64,    9, TILE_64x64_BD,  1},
     {0, 0, 0, 0, 0},
 };
 #ifdef BP_EXPERIMENTAL
@@ -416,7 +455,7 @@ static void pl64_form(const ConvParams& c, int mode, int* tile) {
 static void pl64_form(const ConvParams&, int, int*) {}
 #endif
 
-static void choose_h16(const ConvParams& c, long long M, int mode, int sk_max, int* tile, int* splits) {
+static void choose_h16(const ConvParams& c, long long M, int mode, int sk_max, int* tile, int* splits, bool lone = false) {
     // layers with operand planes (the fp16 mode; bf16x3 under BP_B3_PLANES) run on conv_pl.hip
 #ifdef BP_EXPERIMENTAL   // BP_LEGACY=1: the fp32-activation kernels in every mode (A/B runs of the whole pipeline)
     static const bool legacy = std::getenv("BP_LEGACY") != nullptr;
@@ -435,7 +474,13 @@ static void choose_h16(const ConvParams& c, long long M, int mode, int sk_max, i
     for (const PlanEntry* e = kPlanB3; e->M != 0; ++e)
 #endif
         if (e->M == (int)M && e->CoutPad == c.CoutPad && e->nchunks == c.nchunks &&
-            (!conv_tile_is_halo(e->tile) || (!halo_off && mode == PREC_BF16X3 && conv_halo_eligible(c, e->tile)))) { *tile = e->tile; *splits = e->splits; return; }
+            (!conv_tile_is_halo(e->tile) || (!halo_off && mode == PREC_BF16X3 && conv_halo_eligible(c, e->tile)))) {
+            *tile = e->tile; *splits = e->splits;
+            if (lone && e->tile == TILE_BD_K2)
+                for (const PlanEntry* l = kPlanB3Lone; l->M != 0; ++l)
+                    if (l->M == e->M && l->CoutPad == e->CoutPad && l->nchunks == e->nchunks) { *tile = l->tile; *splits = l->splits; break; }
+            return;
+        }
     int t = TILE_64x64_BD;   // bf16x3: the filters-direct 64x64 kernel at every batch size (profiles/r02_tune_b3_batch28.txt)
     // ... except the 3x3 / stride-1 layers of batched runs once one slice of halo tiles fills the chip: the 64x128 halo tile is
     // 1.2-1.5x the filters-direct kernel there (batch 28: 52x52 128 -> 256 217.6 against 319.0 us, 40x32 256 -> 512 378.8 against
@@ -467,7 +512,7 @@ static bool tile_runs(int tile, const ConvParams& c) {
     const bool on_planes = c.in16 != nullptr && c.wpl != nullptr;
     if (tile == TILE_64x64 || tile == TILE_128x64) return !on_planes;
     if (conv_tile_is_pl(tile)) return c.mfma_mode != PREC_F32 && conv_pl_eligible(c);
-    if (tile == TILE_64x64_BD) return c.mfma_mode == PREC_BF16X3 && conv_h16_eligible(c) && c.w16s != nullptr && !on_planes;
+    if (tile == TILE_64x64_BD || tile == TILE_BD_K2) return c.mfma_mode == PREC_BF16X3 && conv_h16_eligible(c) && c.w16s != nullptr && !on_planes;
     if (conv_tile_is_halo(tile)) return c.mfma_mode == PREC_BF16X3 && c.in16 == nullptr && conv_halo_eligible(c, tile);
 #ifdef BP_EXPERIMENTAL
     if (tile >= 0 && tile <= TILE_LAST) return c.mfma_mode != PREC_F32 && conv_h16_eligible(c);
@@ -483,14 +528,14 @@ static bool stem3_wanted(const ConvParams& c, int force_tile) {
 }
 
 static void choose_launch(const Op& op, int batch, int force_tile, int sk_target, int sk_min_chunks, int sk_max,
-                          int* tile, int* splits, int* cps) {
+                          int* tile, int* splits, int* cps, bool lone = false) {
     const int mode = op.conv.mfma_mode;
     const ConvParams& c = op.conv;
     const long long M = (long long)batch * c.OH * c.OW;
     int t = TILE_64x64;   // fp32 MFMA kernel: 128x64 measured slower on every layer of both networks (tools/bench_conv.py)
     int s = 1;
     if (mode != PREC_F32) {
-        choose_h16(c, M, mode, sk_max, &t, &s);
+        choose_h16(c, M, mode, sk_max, &t, &s, lone);
         if (force_tile >= 0 && tile_runs(force_tile, c)) t = force_tile;
         if (!(sk_target == 512 && sk_min_chunks == 4 && sk_max == 8)) {   // explicit policy (tests, sweeps)
             const long long blocks = ((M + conv_tile_bm(t) - 1) / conv_tile_bm(t)) *
@@ -586,9 +631,11 @@ size_t Net::workspace_need() const {
     size_t need = 0;
     for (const Op& op : ops_) {
         if (op.type != OP_CONV) continue;
-        for (int b = 1; b <= max_batch_; ++b) {
+        for (int b = 1; b <= 2 * max_batch_; ++b) {      // (every batch size under the throughput plan, then under the lone-frame plan)
             int tile, splits, cps;
-            choose_launch(op, b, force_tile_, sk_target_, sk_min_chunks_, 64, &tile, &splits, &cps);
+            const bool lone = b > max_batch_;
+            if (lone) b -= max_batch_;
+            choose_launch(op, b, force_tile_, sk_target_, sk_min_chunks_, 64, &tile, &splits, &cps, lone);
             // worst case over policies that may be set later: allow up to 64 splits at batch 1
             ConvParams q = op.conv; q.N = b; q.M = b * q.OH * q.OW; q.splits = splits;
             if (splits > 1) {
@@ -598,6 +645,7 @@ size_t Net::workspace_need() const {
                 if (conv_hybrid_plan(q, tile, (size_t)-1, &full, &hs, &hcps))
                     need = std::max(need, (size_t)hs * (conv_tiles(q, tile) - full) * conv_tile_bm(tile) * conv_tile_bn(tile));
             }
+            if (lone) b += max_batch_;
         }
     }
     return std::max(need, (size_t)4 << 20);   // headroom so a later policy change can still split small layers
@@ -902,7 +950,7 @@ bool Net::pooled_by_conv(const Op& pool, int batch) const {
     const Op& prev = *(&pool - 1);
     if (prev.type != OP_CONV || prev.pool_out != pool.out) return false;
     int tile, splits, cps;
-    choose_launch(prev, batch, force_tile_, sk_target_, sk_min_chunks_, sk_max_splits_, &tile, &splits, &cps);
+    choose_launch(prev, batch, force_tile_, sk_target_, sk_min_chunks_, sk_max_splits_, &tile, &splits, &cps, prefetch_);
     return pool_in_epilogue(prev, batch, tile);
 }
 
@@ -914,7 +962,7 @@ void Net::prepare_conv(const Op& op, int batch, ConvParams& p, int& tile) {
             p.N = batch;
             p.M = batch * p.OH * p.OW;
             int splits, cps;
-            choose_launch(op, batch, force_tile_, sk_target_, sk_min_chunks_, sk_max_splits_, &tile, &splits, &cps);
+            choose_launch(op, batch, force_tile_, sk_target_, sk_min_chunks_, sk_max_splits_, &tile, &splits, &cps, prefetch_);
             while (splits > 1 && (size_t)splits * conv_tiles(p, tile) * conv_tile_bm(tile) * conv_tile_bn(tile) > partial_floats_) {
                 conv_split_plan(p, tile, splits - 1, &splits, &cps);
             }
@@ -945,7 +993,7 @@ void Net::prepare_conv(const Op& op, int batch, ConvParams& p, int& tile) {
                     ConvParams n = q->conv;
                     n.N = batch; n.M = batch * n.OH * n.OW;
                     int nt, ns, nc;
-                    choose_launch(*q, batch, force_tile_, sk_target_, sk_min_chunks_, sk_max_splits_, &nt, &ns, &nc);
+                    choose_launch(*q, batch, force_tile_, sk_target_, sk_min_chunks_, sk_max_splits_, &nt, &ns, &nc, prefetch_);
                     conv_prefetch_of(p, n, nt, ns, nc);
                     break;
                 }
@@ -1056,7 +1104,7 @@ int Net::profile(int batch, int iters, float* ms, int* info, int cap, hipStream_
         if (info) {
             int tile = 0, splits = 1, cps = 0, vec = 0, conv = ops_[i].type == OP_CONV;
             if (conv) {
-                choose_launch(ops_[i], batch, force_tile_, sk_target_, sk_min_chunks_, sk_max_splits_, &tile, &splits, &cps);
+                choose_launch(ops_[i], batch, force_tile_, sk_target_, sk_min_chunks_, sk_max_splits_, &tile, &splits, &cps, prefetch_);
                 vec = conv_vec_mode(ops_[i].conv) ? 1 : 0;
                 if (ops_[i].conv.mfma_mode != PREC_F32 && tile != TILE_64x64 && tile != TILE_128x64)
                     vec = 1 + ops_[i].conv.mfma_mode;   // 2 fp16 operands, 3 bf16x3 operands

@@ -278,7 +278,8 @@ def test_conv_pl_full_size_layers(cuda):
 # than the fp32-MFMA kernel; bit-reproducible; every epilogue / store mode.
 @pytest.mark.parametrize("case", F16_CASES)
 @pytest.mark.parametrize("splits", [1, 3])
-def test_conv_filters_direct_bf16x3_is_fp32_accurate(cuda, case, splits):
+@pytest.mark.parametrize("bd", ["bd_b3", "bdk2_b3"])      # bdk2: the same tile with two K groups inside an eight-wave block (round 4)
+def test_conv_filters_direct_bf16x3_is_fp32_accurate(cuda, case, splits, bd):
     N, H, W, Cin, Cout, k, st, pad, act = case
     g = torch.Generator().manual_seed(1900 + CASES.index(case))
     x = torch.randn(N, H, W, Cin, generator=g) * torch.exp(2 * torch.randn(N, H, W, 1, generator=g))   # wide dynamic range
@@ -291,9 +292,9 @@ def test_conv_filters_direct_bf16x3_is_fp32_accurate(cuda, case, splits):
     for after in (False, True):
         ref64 = _ref(x.double(), w.double(), b.double(), st, pad, act, res.double(), after)
         kw = dict(stride=st, pad=pad, act=act, res=res.to(cuda), res_after_act=after, splits=splits)
-        out3 = ops.conv2d_nhwc(x.to(cuda), w, b, tile="bd_b3", **kw)
+        out3 = ops.conv2d_nhwc(x.to(cuda), w, b, tile=bd, **kw)
         out32 = ops.conv2d_nhwc(x.to(cuda), w, b, tile="64x64", **kw)
-        assert torch.equal(out3, ops.conv2d_nhwc(x.to(cuda), w, b, tile="bd_b3", **kw))     # fixed summation order
+        assert torch.equal(out3, ops.conv2d_nhwc(x.to(cuda), w, b, tile=bd, **kw))     # fixed summation order
         out3, out32 = out3.cpu().permute(0, 3, 1, 2), out32.cpu().permute(0, 3, 1, 2)
         scale = float(ref64.abs().mean())
         e3 = float((out3.double() - ref64).abs().max()) / scale
@@ -302,22 +303,23 @@ def test_conv_filters_direct_bf16x3_is_fp32_accurate(cuda, case, splits):
         _check(out3, ref64.float(), tol=2e-5 * max(1.0, scale))
 
 
-def test_conv_filters_direct_store_modes(cuda):
+@pytest.mark.parametrize("bd", ["bd_b3", "bdk2_b3"])
+def test_conv_filters_direct_store_modes(cuda, bd):
     g = torch.Generator().manual_seed(18)
     x = torch.randn(2, 10, 8, 64, generator=g)
     w = torch.randn(128, 64, 3, 3, generator=g) / 24
     b = torch.randn(128, generator=g)
     ref = _ref(x, w, b, 1, 1, "relu", None, False)
     xd = x.to(cuda)
-    up = ops.conv2d_nhwc(xd, w, b, pad=1, act="relu", store="up2", tile="bd_b3").cpu().permute(0, 3, 1, 2)
+    up = ops.conv2d_nhwc(xd, w, b, pad=1, act="relu", store="up2", tile=bd).cpu().permute(0, 3, 1, 2)
     _check(up, F.interpolate(ref, scale_factor=2, mode="nearest"))
-    ps = ops.conv2d_nhwc(xd, w, b, pad=1, act="relu", store="pixshuf", tile="bd_b3").cpu().permute(0, 3, 1, 2)
+    ps = ops.conv2d_nhwc(xd, w, b, pad=1, act="relu", store="pixshuf", tile=bd).cpu().permute(0, 3, 1, 2)
     _check(ps, F.pixel_shuffle(ref, 2))
-    nc = ops.conv2d_nhwc(xd, w, b, pad=1, act="relu", store="nchw", tile="bd_b3", splits=2).cpu()
+    nc = ops.conv2d_nhwc(xd, w, b, pad=1, act="relu", store="nchw", tile=bd, splits=2).cpu()
     _check(nc, ref)
     w18 = torch.randn(18, 64, 1, 1, generator=g) / 8
     b18 = torch.randn(18, generator=g)
-    hd = ops.conv2d_nhwc(xd, w18, b18, tile="bd_b3").cpu().permute(0, 3, 1, 2)
+    hd = ops.conv2d_nhwc(xd, w18, b18, tile=bd).cpu().permute(0, 3, 1, 2)
     _check(hd, _ref(x, w18, b18, 1, 0, "linear", None, False))
 
 
