@@ -578,7 +578,7 @@ def served_leg(ys, ks, local, batch, streams, precision, steps, kp3d, cam_K, lab
     S = len(streams)
     dets = [det] + [det.clone() for _ in range(S - 1)]
     poses = [pose] + [pose.clone() for _ in range(S - 1)]
-    pipes = [FramePipeline(dets[k], poses[k], 480, 640, batch=batch, confidence=0.01, num_classes=80, use_graph=True).prepare() for k in range(S)]
+    pipes = [FramePipeline(dets[k], poses[k], 480, 640, batch=batch, confidence=0.01, num_classes=80, use_graph=True) for k in range(S)]
     pool = [torch.from_numpy(np.stack(synth.synth_frames(batch, 4321 + 37 * j))).to(dev) for j in range(4)]
     NS = 2 * S
     pinned = [torch.empty((batch, pipes[0].results.shape[1]), dtype=torch.float32).pin_memory() for _ in range(NS)]
@@ -686,8 +686,8 @@ def main():
     if a.fixed_box:
         for p_ in pipes:
             p_.set_fixed_box([220, 140, 420, 340])
-    for p_ in pipes:
-        p_.prepare()               # set-up: every stream's hipGraph captured and instantiated here (nothing executes), not inside the first frames
+    # (FramePipeline.prepare() -- graph capture as a set-up step -- is NOT used here: it buys the first region nothing (measured) and, called
+    # before the streams' first launches, it left two frames in flight on ONE hardware queue: 392 against 659 frames/s at --streams 2)
     kp3d, cam_K = synth.synth_kp3d(50), synth.CAM_K
 
     # ---- inputs resident in HBM: a pool of distinct frames per rank

@@ -188,7 +188,9 @@ float* bp_pipeline_heatmaps(bp_pipeline* p);    /* device [batch][50][80][64] */
 int bp_pipeline_set_fixed_box(bp_pipeline* p, const float* box_xyxy_or_null);
 int bp_pipeline_run(bp_pipeline* p, int use_graph, void* stream);
 /* Set-up step: capture and instantiate the frame's hipGraph now (records the launches, executes nothing), so that the first
- * bp_pipeline_run(use_graph = 1) is a plain graph launch.  Called again after a precision / policy change it rebuilds the graph. */
+ * bp_pipeline_run(use_graph = 1) is a plain graph launch.  Called again after a precision / policy change it rebuilds the graph.
+ * (It creates the pipeline's capture stream: call it AFTER the caller's own streams have launched something -- HIP binds streams to
+ * its four hardware queues as they are first used, and two pipelines prepared first were seen to share one queue.) */
 int bp_pipeline_prepare(bp_pipeline* p);
 
 /* ---- host post-processing (no device work) ---- */

@@ -3,7 +3,7 @@
 # dominant conv kernels and per frame, matrix-pipe occupancy, wave stall breakdown, the halo kernels alone, in-situ layer table
 REPO="$(cd "$(dirname "$0")/.." && pwd)"; OUT=$REPO/gpurun_out; cd $REPO
 tools/trace_headline.sh r04 > $OUT/r04_trace_summary_stdout.txt 2>&1
-tools/pmc_traffic.sh > /dev/null 2>&1 && cp $OUT/pmc_traffic.json $OUT/r04_pmc_traffic.json
+BP_PMC_KERNEL=conv_igemm_bdk2 tools/pmc_traffic.sh > /dev/null 2>&1 && cp $OUT/pmc_traffic.json $OUT/r04_pmc_traffic.json
 BP_PMC_KERNEL=conv_halo tools/pmc_traffic.sh > /dev/null 2>&1 && cp $OUT/pmc_traffic.json $OUT/r04_pmc_traffic_halo.json
 tools/pmc_frame_traffic.sh 1 > $OUT/r04_pmc_frame_traffic.json 2>/dev/null
 tools/pmc_mfma_busy.sh > /dev/null 2>&1 && cp $OUT/pmc_mfma_busy.json $OUT/r04_pmc_mfma_busy.json
