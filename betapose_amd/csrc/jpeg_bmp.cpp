@@ -1,4 +1,4 @@
-// JPEG (baseline sequential, Huffman, 8-bit) and BMP (uncompressed) decoding to interleaved RGB u8 for the
+// JPEG (baseline sequential and progressive, Huffman, 8-bit) and BMP (uncompressed) decoding to interleaved RGB u8 for the
 // Darknet-API-compatible detector: the reference's Detector::detect(image file) loads images through Darknet's
 // load_image_color -> stb_image v2.16 (train_YOLO/src/image.c:1820-1875, the vendored stb_image.h), and a detector fed
 // different pixels is a different detector, so the arithmetic that decides the pixels follows stb_image's published
@@ -11,8 +11,10 @@
 //     upper 16 bits.
 // Own structure (bit reader, canonical-code tables indexed by length, MCU walk); pinned bit-for-bit against the
 // reference's compiled Darknet-C (oracle/_ref, load_image_color) in tests/test_image_codecs.py.
-// Progressive, arithmetic-coded, 12-bit and CMYK files are rejected with a clear error (stb decodes progressive; the
-// reference's LineMod frames are PNG).
+// Progressive frames (SOF2) keep every component's coefficients across the scans -- DC first / refinement, AC spectral
+// bands with successive approximation and end-of-band runs -- and are de-quantised (in 16-bit arithmetic, as stb does)
+// and inverse-transformed once, when the stream ends.
+// Arithmetic-coded, 12-bit and CMYK files are rejected with a clear error (the reference's LineMod frames are PNG).
 #include <cstdint>
 #include <cstring>
 #include <stdexcept>
@@ -35,6 +37,7 @@ struct Component {
     int w2 = 0, h2 = 0;          // plane size padded to whole MCUs
     int dc_pred = 0;
     std::vector<uint8_t> plane;
+    std::vector<short> coeff;    // progressive only: [block row][block column][64], natural order, not yet de-quantised
 };
 
 struct BitReader {
@@ -103,14 +106,16 @@ struct Islow8 {
             for (int j = 0; j < 4; ++j) odd[i][j] = o[i][j];
     }
     // y[0..7] (before the caller's rounding shift); `bias` is added to the even half (rounding term / level shift)
+    // (unsigned arithmetic: a corrupt stream can push the sums past 32 bits, and wrapping must stay defined)
     void apply(const int s[8], int bias, int y[8]) const {
-        const int sum = (s[0] + s[4]) * 4096 + bias, dif = (s[0] - s[4]) * 4096 + bias;
-        const int base[4] = {sum, dif, dif, sum};
+        typedef unsigned U;
+        const U sum = ((U)s[0] + (U)s[4]) * 4096u + (U)bias, dif = ((U)s[0] - (U)s[4]) * 4096u + (U)bias;
+        const U base[4] = {sum, dif, dif, sum};
         for (int i = 0; i < 4; ++i) {
-            const int E = base[i] + s[2] * even26[i][0] + s[6] * even26[i][1];
-            const int O = s[1] * odd[i][0] + s[3] * odd[i][1] + s[5] * odd[i][2] + s[7] * odd[i][3];
-            y[i] = E + O;
-            y[7 - i] = E - O;
+            const U E = base[i] + (U)s[2] * (U)even26[i][0] + (U)s[6] * (U)even26[i][1];
+            const U O = (U)s[1] * (U)odd[i][0] + (U)s[3] * (U)odd[i][1] + (U)s[5] * (U)odd[i][2] + (U)s[7] * (U)odd[i][3];
+            y[i] = (int)(E + O);
+            y[7 - i] = (int)(E - O);
         }
     }
 };
@@ -124,7 +129,7 @@ void idct_block(uint8_t* out, int stride, const short* d) {
         int s[8], ac = 0;
         for (int r = 0; r < 8; ++r) { s[r] = d[8 * r + col]; if (r) ac |= s[r]; }
         if (ac == 0) {
-            for (int r = 0; r < 8; ++r) mid[r][col] = s[0] * 4;
+            for (int r = 0; r < 8; ++r) mid[r][col] = (int)((unsigned)s[0] * 4u);
             continue;
         }
         int y[8];
@@ -155,6 +160,9 @@ struct Decoder {
     const uint8_t* data;
     size_t size;
     int W = 0, H = 0, ncomp = 0, hmax = 1, vmax = 1, restart = 0;
+    bool progressive = false;
+    int ss = 0, se = 63, ah = 0, al = 0;     // the current scan's spectral band and successive-approximation bits
+    int eob_run = 0;                          // blocks still covered by the last end-of-band run
     uint16_t quant[4][64];
     bool have_q[4] = {false, false, false, false};
     HuffTable dc[4], ac[4];
@@ -244,19 +252,106 @@ struct Decoder {
         }
     }
 
+    // ---- progressive scans (ITU T.81 annex G, in the form stb_image decodes them) ----
+    // DC: the first scan carries the predicted difference, scaled by 2^Al; a refinement scan adds one bit per block
+    void prog_dc(BitReader& br, Component& c, short* d) {
+        if (se != 0) throw std::runtime_error("JPEG: corrupt progressive scan (DC scan with an AC band)");
+        if (ah == 0) {
+            std::memset(d, 0, 64 * sizeof(short));
+            if (!dc[c.td].present) throw std::runtime_error("JPEG: scan refers to a missing table");
+            const int t = huff_decode(br, dc[c.td]);
+            if (t > 15) throw std::runtime_error("JPEG: corrupt block (DC category)");
+            const int diff = t ? extend(br.bits(t), t) : 0;
+            c.dc_pred += diff;
+            d[0] = (short)(c.dc_pred * (1 << al));
+        } else if (br.bits(1)) {
+            d[0] = (short)(d[0] + (short)(1 << al));
+        }
+    }
+    // one correction bit for a coefficient that is already non-zero: move it away from zero by `bit` unless it has it
+    static void refine(BitReader& br, short* p, short bit) {
+        if (br.bits(1) && (*p & bit) == 0) *p = (short)(*p > 0 ? *p + bit : *p - bit);
+    }
+    // AC band ss..se of one block
+    void prog_ac(BitReader& br, Component& c, short* d) {
+        if (ss == 0) throw std::runtime_error("JPEG: corrupt progressive scan (AC scan starting at DC)");
+        if (!ac[c.ta].present) throw std::runtime_error("JPEG: scan refers to a missing table");
+        const HuffTable& ha = ac[c.ta];
+        if (ah == 0) {
+            if (eob_run) { --eob_run; return; }
+            int k = ss;
+            do {
+                const int rs = huff_decode(br, ha);
+                const int r = rs >> 4, s = rs & 15;
+                if (s == 0) {
+                    if (r < 15) {                          // end of band for 2^r (+ r more bits) blocks, this one included
+                        eob_run = 1 << r;
+                        if (r) eob_run += br.bits(r);
+                        --eob_run;
+                        break;
+                    }
+                    k += 16;
+                } else {
+                    k += r;
+                    if (k > 63) throw std::runtime_error("JPEG: corrupt block");
+                    d[kZigzag[k++]] = (short)(extend(br.bits(s), s) * (1 << al));
+                }
+            } while (k <= se);
+            return;
+        }
+        const short bit = (short)(1 << al);
+        if (eob_run) {
+            --eob_run;
+            for (int k = ss; k <= se; ++k) {
+                short* p = d + kZigzag[k];
+                if (*p != 0) refine(br, p, bit);
+            }
+            return;
+        }
+        int k = ss;
+        do {
+            const int rs = huff_decode(br, ha);
+            int r = rs >> 4, s = rs & 15;
+            if (s == 0) {
+                if (r < 15) {
+                    eob_run = (1 << r) - 1;
+                    if (r) eob_run += br.bits(r);
+                    r = 64;                                // nothing new in this block: only corrections to the end of the band
+                }                                          // r == 15: sixteen zero-history coefficients to skip
+            } else {
+                if (s != 1) throw std::runtime_error("JPEG: corrupt block (refinement)");
+                s = br.bits(1) ? bit : -bit;
+            }
+            while (k <= se) {
+                short* p = d + kZigzag[k++];
+                if (*p != 0) refine(br, p, bit);
+                else {
+                    if (r == 0) { *p = (short)s; break; }
+                    --r;
+                }
+            }
+        } while (k <= se);
+    }
+
     void decode_scan(const uint8_t* p, const uint8_t* end, int ns, const int* order) {
         BitReader br{p, end};
         const int mcux = (W + 8 * hmax - 1) / (8 * hmax), mcuy = (H + 8 * vmax - 1) / (8 * vmax);
         short blk[64];
         int todo = restart ? restart : 0x7fffffff;
+        eob_run = 0;
         if (ns == 1) {
             // non-interleaved: the component's own 8x8 blocks in raster order
             Component& c = comp[order[0]];
             const int bw = (((W * c.h + hmax - 1) / hmax) + 7) / 8, bh = (((H * c.v + vmax - 1) / vmax) + 7) / 8;
             for (int by = 0; by < bh; ++by)
                 for (int bx = 0; bx < bw; ++bx) {
-                    decode_block(br, c, blk);
-                    idct_block(c.plane.data() + (size_t)by * 8 * c.w2 + bx * 8, c.w2, blk);
+                    if (progressive) {
+                        short* d = c.coeff.data() + 64 * ((size_t)by * (c.w2 / 8) + bx);
+                        if (ss == 0) prog_dc(br, c, d); else prog_ac(br, c, d);
+                    } else {
+                        decode_block(br, c, blk);
+                        idct_block(c.plane.data() + (size_t)by * 8 * c.w2 + bx * 8, c.w2, blk);
+                    }
                     if (--todo <= 0) { next_restart(br); todo = restart; }
                 }
             return;
@@ -267,12 +362,32 @@ struct Decoder {
                     Component& c = comp[order[k]];
                     for (int y = 0; y < c.v; ++y)
                         for (int x = 0; x < c.h; ++x) {
+                            if (progressive) {             // interleaved progressive scans carry DC only
+                                prog_dc(br, c, c.coeff.data() + 64 * ((size_t)(my * c.v + y) * (c.w2 / 8) + mx * c.h + x));
+                                continue;
+                            }
                             decode_block(br, c, blk);
                             idct_block(c.plane.data() + (size_t)(my * c.v + y) * 8 * c.w2 + (mx * c.h + x) * 8, c.w2, blk);
                         }
                 }
                 if (--todo <= 0) { next_restart(br); todo = restart; }
             }
+    }
+    // progressive: every scan has been merged into the coefficients -- de-quantise (16-bit products, as the reference's
+    // loader does) and inverse-transform the blocks that carry image data
+    void finish_progressive() {
+        for (int i = 0; i < ncomp; ++i) {
+            Component& c = comp[i];
+            if (!have_q[c.tq]) throw std::runtime_error("JPEG: scan refers to a missing table");
+            const uint16_t* q = quant[c.tq];
+            const int bw = (((W * c.h + hmax - 1) / hmax) + 7) / 8, bh = (((H * c.v + vmax - 1) / vmax) + 7) / 8;
+            for (int by = 0; by < bh; ++by)
+                for (int bx = 0; bx < bw; ++bx) {
+                    short* d = c.coeff.data() + 64 * ((size_t)by * (c.w2 / 8) + bx);
+                    for (int k = 0; k < 64; ++k) d[k] = (short)(d[k] * q[k]);
+                    idct_block(c.plane.data() + (size_t)by * 8 * c.w2 + bx * 8, c.w2, d);
+                }
+        }
     }
     void next_restart(BitReader& br) {
         // byte-align, expect RSTn, reset predictors
@@ -284,6 +399,7 @@ struct Decoder {
         if (p + 1 >= br.end) return;
         br.p = p + 2;
         br.reset();
+        eob_run = 0;
         for (int i = 0; i < ncomp; ++i) comp[i].dc_pred = 0;
     }
 
@@ -307,18 +423,20 @@ struct Decoder {
                 if (len < 4) throw std::runtime_error("JPEG: truncated segment (DRI)");
                 restart = be16(body);
             }
-            else if (m == 0xC0 || m == 0xC1) {
+            else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {
+                if (have_sof) throw std::runtime_error("JPEG: more than one frame header");
                 parse_sof(body, len - 2);
                 have_sof = true;
+                progressive = m == 0xC2;
                 for (int i = 0; i < ncomp; ++i) {
                     Component& c = comp[i];
                     const int mcux = (W + 8 * hmax - 1) / (8 * hmax), mcuy = (H + 8 * vmax - 1) / (8 * vmax);
                     c.w2 = mcux * c.h * 8;
                     c.h2 = mcuy * c.v * 8;
                     c.plane.assign((size_t)c.w2 * c.h2, 0);
+                    if (progressive) c.coeff.assign((size_t)c.w2 * c.h2, 0);
                 }
-            } else if (m == 0xC2) throw std::runtime_error("JPEG: progressive files are not supported (baseline only)");
-            else if (m == 0xC9 || m == 0xCA || m == 0xCB) throw std::runtime_error("JPEG: arithmetic coding is not supported");
+            } else if (m == 0xC9 || m == 0xCA || m == 0xCB) throw std::runtime_error("JPEG: arithmetic coding is not supported");
             else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) throw std::runtime_error("JPEG: unsupported frame type");
             else if (m == 0xDA) {
                 if (!have_sof) throw std::runtime_error("JPEG: scan before frame header");
@@ -333,11 +451,20 @@ struct Decoder {
                     if (ci < 0) throw std::runtime_error("JPEG: bad SOS component");
                     comp[ci].td = body[2 + 2 * k] >> 4;
                     comp[ci].ta = body[2 + 2 * k] & 15;
-                    if (comp[ci].td > 3 || comp[ci].ta > 3 || !dc[comp[ci].td].present || !ac[comp[ci].ta].present || !have_q[comp[ci].tq])
+                    if (comp[ci].td > 3 || comp[ci].ta > 3) throw std::runtime_error("JPEG: bad SOS");
+                    // a progressive scan needs only the table of its own band (checked where it is used); the
+                    // quantisation tables are needed when the coefficients are finished
+                    if (!progressive && (!dc[comp[ci].td].present || !ac[comp[ci].ta].present || !have_q[comp[ci].tq]))
                         throw std::runtime_error("JPEG: scan refers to a missing table");
                     comp[ci].dc_pred = 0;
                     order[k] = ci;
                 }
+                ss = body[1 + 2 * ns]; se = body[2 + 2 * ns];
+                ah = body[3 + 2 * ns] >> 4; al = body[3 + 2 * ns] & 15;
+                if (progressive) {
+                    if (ss > 63 || se > 63 || ss > se || ah > 13 || al > 13) throw std::runtime_error("JPEG: bad SOS");
+                    if (ns > 1 && ss != 0) throw std::runtime_error("JPEG: corrupt progressive scan (interleaved AC scan)");
+                } else if (ss != 0 || ah != 0 || al != 0) throw std::runtime_error("JPEG: bad SOS");
                 const uint8_t* sp = p + 2 + len;
                 decode_scan(sp, end, ns, order);
                 scanned = true;
@@ -350,6 +477,7 @@ struct Decoder {
             p += 2 + len;
         }
         if (!have_sof || !scanned) throw std::runtime_error("JPEG: no image data");
+        if (progressive) finish_progressive();
         assemble(rgb);
         *oh = H; *ow = W;
     }

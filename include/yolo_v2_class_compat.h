@@ -3,8 +3,8 @@
  * Same names, argument meaning and return conventions: init -> 1; detect_* -> number of detections (at most
  * C_SHARP_MAX_OBJECTS are written), negative on error (the reference's detect_mat returns -1 when built without
  * OpenCV); dispose -> 1; get_device_name -> 1 on success.  Detection threshold 0.2 and NMS 0.4 as in the reference's
- * Detector.  Differences: image files are PNG, baseline JPEG or uncompressed BMP (progressive JPEG is rejected with an
- * error; the reference's stb_image decodes it); the network input must be square.  C++ header (the
+ * Detector.  Differences: image files are PNG, baseline / progressive JPEG or uncompressed BMP (the formats the
+ * reference's stb_image loads that this library does not: GIF, TGA, PSD, HDR, PIC, PNM); the network input must be square.  C++ header (the
  * container is passed by reference, as in the reference). */
 #ifndef YOLO_V2_CLASS_COMPAT_H
 #define YOLO_V2_CLASS_COMPAT_H
