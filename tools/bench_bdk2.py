@@ -14,7 +14,9 @@ SHAPES = [(52, 52, 256, 128, 1, 1, 10), (26, 26, 512, 256, 1, 1, 10), (13, 13, 1
           (52, 52, 256, 512, 3, 2, 1), (26, 26, 512, 1024, 3, 2, 1), (26, 26, 768, 256, 1, 1, 1), (52, 52, 384, 128, 1, 1, 1)]
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
-tot = {"bd": 0.0, "bdk2": 0.0, "best": 0.0}
+TILES = sys.argv[1].split(",") if len(sys.argv) > 1 else ["bd", "bdk2"]      # e.g. bd,bdk2,bdk2d2,bdk2d3,bdk2d4
+tot = {t: 0.0 for t in TILES}
+tot["best"] = 0.0
 for (h, w_, cin, co, k, st, cnt) in SHAPES:
     x = torch.randn(1, h, w_, cin, generator=g).to(dev)
     wt = torch.randn(co, cin, k, k, generator=g) / np.sqrt(cin * k * k)
@@ -22,7 +24,7 @@ for (h, w_, cin, co, k, st, cnt) in SHAPES:
     res = torch.randn(1, oh, ow, co, generator=g).to(dev)
     nch = cin * k * k // 32
     best = {}
-    for tile in ("bd", "bdk2"):
+    for tile in TILES:
         tb = (1e9, None)
         for sp in (1, 2, 3, 4, 5, 6, 8, 10, 12):
             if sp > 1 and nch // sp < (2 if tile == "bd" else 4):
@@ -31,7 +33,9 @@ for (h, w_, cin, co, k, st, cnt) in SHAPES:
             if ms * 1e3 < tb[0]:
                 tb = (ms * 1e3, sp)
         best[tile] = tb
-    tot["bd"] += best["bd"][0] * cnt; tot["bdk2"] += best["bdk2"][0] * cnt; tot["best"] += min(best["bd"][0], best["bdk2"][0]) * cnt
+    for t in TILES:
+        tot[t] += best[t][0] * cnt
+    tot["best"] += min(best[t][0] for t in TILES) * cnt
     M = oh * ow; cpad = (co + 63) // 64 * 64
-    print("{%6d, %5d, %4d}  k%d s%d %dx%d %d->%d x%d | bd %d:%.1f  bdk2 %d:%.1f" % (M, cpad, nch, k, st, h, w_, cin, co, cnt, best["bd"][1], best["bd"][0], best["bdk2"][1], best["bdk2"][0]), flush=True)
-print("sum per frame: bd %.1f us, bdk2 %.1f us, best-of %.1f us" % (tot["bd"], tot["bdk2"], tot["best"]))
+    print("{%6d, %5d, %4d}  k%d s%d %dx%d %d->%d x%d | " % (M, cpad, nch, k, st, h, w_, cin, co, cnt) + "  ".join("%s %d:%.1f" % (t, best[t][1], best[t][0]) for t in TILES), flush=True)
+print("sum per frame (us): " + ", ".join("%s %.1f" % (t, tot[t]) for t in TILES) + ", best-of %.1f" % tot["best"])
