@@ -151,7 +151,8 @@ enum ConvTile : int { TILE_64x64 = 0, TILE_128x64 = 1, TILE_W64_1x1 = 2, TILE_W6
                       TILE_HALO128 = 22,    // 64x128 block, 4 waves
                       TILE_HALO64K2 = 23,   // 64x64 block, 4 waves = 2 K groups x 2 column halves: the K split inside the block (no slabs)
                       TILE_BD_K2 = 24,      // the filters-direct 64x64 tile with 8 waves = 2 K groups of 2x2 waves (conv_igemm.hip, any kernel size / stride)
-                      TILE_LAST = 24 };
+                      TILE_PLH128 = 25,     // conv_pl.hip 128x128 with the activations of a 3x3 / stride-1 layer from an LDS-resident halo (fp16; round 4)
+                      TILE_LAST = 25 };
 
 // when non-null, launch_conv brackets the implicit-GEMM kernel itself (not the split-K reduce) with these events
 struct ConvProfHook { hipEvent_t e0, e1; };
@@ -174,6 +175,8 @@ bool conv_halo_eligible(const ConvParams& p, int tile);   // 3x3 / stride 1 / pa
 // K slices of a launch: `want` slices asked for -> slices and chunks per slice the kernel `tile` runs (the halo tiles cut K
 // by whole 32-channel groups = 9 chunks)
 void conv_split_plan(const ConvParams& p, int tile, int want, int* splits, int* cps);
+inline bool conv_tile_is_plh(int tile) { return tile == TILE_PLH128; }
+bool conv_plh_eligible(const ConvParams& p);  // TILE_PLH128 can run the layer (fp16, 3x3 / stride 1 / pad 1, W <= 63, whole channel groups per K slice)
 bool conv_pl_eligible(const ConvParams& p);   // planes + wpl present, Cin % 32 == 0, taps fit the 32-bit mask
 // filters [CoutPad][Kpad] fp32 -> conv_pl.hip's LDS image, np = 1 (fp16) or 3 (exact bf16 split)
 void launch_pack_wpl(const float* in, unsigned short* out, int CoutPad, int Kpad, int Cin, int ksize, int np, hipStream_t s);

@@ -786,14 +786,14 @@ int conv_grid_blocks(const ConvParams& q) {
 
 int conv_tile_bm(int tile) {
     switch (tile) {
-        case TILE_128x64: case TILE_W64_2x1: case TILE_W64_2x2: case TILE_PL128: case TILE_PL128x64: case TILE_PL128S: return 128;
+        case TILE_128x64: case TILE_W64_2x1: case TILE_W64_2x2: case TILE_PL128: case TILE_PL128x64: case TILE_PL128S: case TILE_PLH128: return 128;
         case TILE_PL256x128: return 256;
         default: return 64;
     }
 }
 int conv_tile_bn(int tile) {
     switch (tile) {
-        case TILE_W64_1x2: case TILE_W64_2x2: case TILE_PL128: case TILE_PL256x128: case TILE_PL128S: case TILE_HALO128: return 128;
+        case TILE_W64_1x2: case TILE_W64_2x2: case TILE_PL128: case TILE_PL256x128: case TILE_PL128S: case TILE_HALO128: case TILE_PLH128: return 128;
         default: return 64;
     }
 }
@@ -845,7 +845,7 @@ bool conv_h16_eligible(const ConvParams& p) {   // the fp32-activation 16-bit ke
 }
 
 void conv_split_plan(const ConvParams& p, int tile, int want, int* splits, int* cps) {
-    const int unit = (conv_tile_is_halo(tile) && p.nchunks % 9 == 0 && p.nchunks >= 9) ? 9 : 1;          // chunks that stay together (a layer the halo tiles cannot run is refused by the launcher)
+    const int unit = ((conv_tile_is_halo(tile) || conv_tile_is_plh(tile)) && p.nchunks % 9 == 0 && p.nchunks >= 9) ? 9 : 1;          // chunks that stay together (a layer the halo tiles cannot run is refused by the launcher)
     const int units = p.nchunks / unit;
     int s = want < 1 ? 1 : (want > units ? units : want);
     const int per = (units + s - 1) / s;

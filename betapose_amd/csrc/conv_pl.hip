@@ -59,8 +59,19 @@ namespace bp {
 // neither the in-kernel fp32 -> 3 x bf16 conversion of the round-2 kernel (44 vector instructions per thread and chunk
 // beside 12 MFMAs per wave: it is what the shader clock gives way to) nor the filter DMAs of the plain
 // plane kernel.  64x64 tile, one chunk per stage.
-template <int NP, int WM, int WN, int TM, int TN, int NST, int CPS, int LW = 0, int KG = 1, bool BDIR = false>
+//
+// HRT > 0 (round 4; 3x3 / stride 1 / pad 1, fp16): the ACTIVATIONS come from an LDS-resident halo instead of one DMA'd tile per tap.
+// BM consecutive output pixels (flattened over the batch) read input pixels m - W - 1 .. m + W + 1: BM + 2 W + 2 consecutive
+// pixels, i.e. HRT >= BM + 2 W + 2 rows of 64 B per 32-channel group, fetched ONCE per group (HRT / 16 DMA instructions instead of
+// 9 BM / 16) into one of two buffers behind the filter ring, spread over the stages of the previous group; the nine taps read
+// their fragments from it at per-lane row addresses (row + ky W + kx; the source-side swizzle keyed on (row >> 2) & 3 is
+// conflict-free for any 16 consecutive rows, so for any tap shift), a tap outside the image reads a zero row.  The ring
+// carries the filters only.  L2 -> LDS bytes per group at 128x128: 88 KB instead of 144 KB -- the fp16 K loop is bound by exactly
+// that.  K slices are cut by whole groups (nine chunks).
+template <int NP, int WM, int WN, int TM, int TN, int NST, int CPS, int LW = 0, int KG = 1, bool BDIR = false, int HRT = 0>
 __global__ __launch_bounds__(64 * (WM * WN * KG + LW)) void conv_pl_kernel(const ConvParams p) {
+    constexpr bool HALO = HRT > 0;
+    static_assert(!HALO || (NP == 1 && CPS == 1 && LW == 0 && KG == 1 && !BDIR && HRT % (16 * WM * WN) == 0), "halo form: fp16, one chunk per stage");
     static_assert(LW == 0 || KG == 1, "loader waves and K groups are alternatives");
     static_assert(!BDIR || (TM == 1 && TN == 1 && CPS == 1 && LW == 0 && KG == 1 && WM == 2 && WN == 2), "filters-direct form: 64x64 tile, 2x2 waves");
     constexpr int NWC = WM * WN;                  // compute waves (per K group)
@@ -68,7 +79,8 @@ __global__ __launch_bounds__(64 * (WM * WN * KG + LW)) void conv_pl_kernel(const
     constexpr int NT = 64 * (NWC * KG + LW);
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int LDT = BN + 4;
-    constexpr int A_PLANE = BM * 64, B_PLANE = BDIR ? 0 : BN * 64;        // LDS bytes per plane and chunk
+    constexpr int A_PLANE = HALO ? 0 : BM * 64, B_PLANE = BDIR ? 0 : BN * 64;        // LDS bytes per plane and chunk
+    constexpr int HALO_BYTES = HALO ? (HRT + 1) * 64 : 0;                 // one halo buffer: HRT rows + the zero row
     constexpr int CHUNK = NP * (A_PLANE + B_PLANE);
     constexpr int STAGE = CPS * CHUNK;
     constexpr int EP_SLABS_ = BM > 128 ? BM / 64 : 1;       // epilogue staging in 64-row slabs on the big tiles (conv_tail.inc)
@@ -76,7 +88,7 @@ __global__ __launch_bounds__(64 * (WM * WN * KG + LW)) void conv_pl_kernel(const
     constexpr int RING = NST * STAGE;
     constexpr int KGSUM_BYTES = (KG - 1) * NWC * TM * TN * 4096;      // the other groups' accumulators, fragment order
     static_assert(KGSUM_BYTES <= KG * RING, "");
-    constexpr int SMEM_BYTES = (KG * RING > EPI_BYTES ? KG * RING : EPI_BYTES) + 16;
+    constexpr int SMEM_BYTES = (KG * RING + 2 * HALO_BYTES > EPI_BYTES ? KG * RING + 2 * HALO_BYTES : EPI_BYTES) + 16;
     // the ONE LDS object of the kernel (a second one makes hipcc drain vmcnt before every fragment read)
     __shared__ __attribute__((aligned(16))) float smem[SMEM_BYTES / 4];
     typedef typename HalfOps<NP>::frag frag_t;
@@ -193,6 +205,42 @@ __global__ __launch_bounds__(64 * (WM * WN * KG + LW)) void conv_pl_kernel(const
     const int b_lds0 = NP * A_PLANE + wave * 1024;                      // + pl * B_PLANE + k * NW * 1024
     const unsigned b_voff = (unsigned)(lane * 16);
     constexpr int IPW = CPS * NP * (GA + KB);     // DMA instructions per wave and stage
+    // ---- halo form: wave w fetches the 16-row pieces w, w + NW, ... of the halo (HPW per wave and group); lane -> row (lane >> 2)
+    // of the piece, granule (lane & 3) ^ ((row >> 2) & 3) of input pixel m0 - W - 1 + row (outside the tensor: out of range, zeros)
+    constexpr int HPW = HALO ? HRT / (16 * NW) : 1;
+    static_assert(!HALO || 9 - HPW >= NST - 1, "the prologue's stages carry no halo pieces");
+    char* const hal = reinterpret_cast<char*>(smem) + KG * RING;
+    unsigned h_va[HPW];
+    unsigned fa_off[9][TM];
+    if constexpr (HALO) {
+        const int gsw = (lane & 3) ^ ((lane >> 4) & 3);
+        const long long npix = (long long)p.N * p.H * p.W;
+#pragma unroll
+        for (int k = 0; k < HPW; ++k) {
+            const long long pix = (long long)m0 - p.W - 1 + 16 * (wave + NW * k) + (lane >> 2);
+            h_va[k] = (pix >= 0 && pix < npix) ? (unsigned)((pix * p.in_ld + gsw * 8) * 2) : OOB;
+        }
+        const int hw = p.OH * p.OW;
+#pragma unroll
+        for (int e = 0; e < TM; ++e) {
+            const int lm = wm * (32 * TM) + e * 32 + (lane & 31);
+            const int m = m0 + lm;
+            const bool ok = m < p.M;
+            const int mm = ok ? m : 0;
+            const int rem = mm % hw;
+            const int oy = rem / p.OW, ox = rem - oy * p.OW;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int ky = t / 3, kx = t - 3 * ky;
+                const int iy = oy + ky - 1, ix = ox + kx - 1;
+                const bool in_img = ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                const int r = lm + ky * p.W + kx;
+                fa_off[t][e] = in_img ? (unsigned)(r * 64 + (((lane >> 5) ^ ((r >> 2) & 3)) << 4)) : (unsigned)(HRT * 64 + ((lane >> 5) << 4));
+            }
+        }
+        if (tid < 8) *reinterpret_cast<u32x4*>(hal + (tid >> 2) * HALO_BYTES + HRT * 64 + (tid & 3) * 16) = u32x4{0u, 0u, 0u, 0u};   // the zero rows
+        __syncthreads();
+    }
 
     // ---- wave-uniform walk over K in 32-k chunks.  K ORDER: (32-channel group, ky, kx, channel) -- the filter taps are
     // the INNER loop.  A 3x3 layer re-reads every activation row once per tap; tap-major order (the order of the round-1/2
@@ -342,6 +390,84 @@ __global__ __launch_bounds__(64 * (WM * WN * KG + LW)) void conv_pl_kernel(const
     constexpr int N0 = IPW < 2 ? IPW : 2;
     constexpr int DREM = IPW - N0;
     constexpr int HALF = NMF / 2 > 0 ? NMF / 2 : 1;
+    if constexpr (HALO) {
+        // bundle of the stage with tap t = its KB filter pieces + (t >= 9 - HPW) one piece of the NEXT group's halo; issued NST - 1
+        // stages ahead like every stage's DMAs, so the counted wait that covers a stage covers the halo pieces issued with it
+        auto hp_of = [](int t) constexpr { return t >= 9 - HPW ? 1 : 0; };
+        unsigned h_ndelta = (unsigned)((c_begin / 9) * 64);      // byte offset of the 32-channel group whose halo is fetched next
+        int h_nbuf = 0, h_cur = 0;                                // buffer that receives it / buffer the current group reads
+        int h_left = (c_end - c_begin) / 9;                       // groups of this block's K range not yet fetched
+        unsigned hst_vb; int hst_bs;
+        auto stage_addr_b = [&]() __attribute__((always_inline)) {
+            hst_vb = b_voff | (w_left > 0 ? 0u : OOB);
+            hst_bs = b_src0 + w_bsrc;
+            --w_left;
+            w_bsrc += NP * 4096;
+        };
+        auto dma_piece_h = [&](int so, auto tisc, auto dc) __attribute__((always_inline)) {
+            constexpr int tis = decltype(tisc)::value, d = decltype(dc)::value;
+            if constexpr (d < KB) {
+                dma16(rsrcB, sb + so + b_lds0 + d * (NW * 1024), hst_vb, hst_bs + d * b_srck);
+            } else {
+                constexpr int kk = tis - (9 - HPW);
+                dma16(rsrcA, hal + h_nbuf + (wave + NW * kk) * 1024, h_left > 0 ? h_va[kk] + h_ndelta : OOB, 0);
+            }
+        };
+        auto read_frag_h = [&](int so, auto tapc, auto sc, auto rc) __attribute__((always_inline)) {
+            constexpr int tap = decltype(tapc)::value, s_ = decltype(sc)::value, r = decltype(rc)::value, fs = s_ & 1, ks = s_ & 1;
+            if constexpr (r < TM) {
+                const unsigned o = ks ? (fa_off[tap][r] ^ 32u) : fa_off[tap][r];
+                fa[fs][0][r] = *reinterpret_cast<const frag_t*>(hal + h_cur + o);
+            } else {
+                fb[fs][0][r - TM] = *reinterpret_cast<const frag_t*>(sb + so + (r - TM) * (32 * 64) + (ks ? (b_rd ^ 32) : b_rd));
+            }
+        };
+        // prologue: the first group's halo, then NST - 1 stages of filters
+        static_for<HPW>([&](auto kc) __attribute__((always_inline)) {
+            dma16(rsrcA, hal + (wave + NW * decltype(kc)::value) * 1024, h_va[decltype(kc)::value] + h_ndelta, 0);
+        });
+        h_ndelta += 64; h_nbuf = HALO_BYTES; --h_left;
+        static_for<NST - 1>([&](auto sc) __attribute__((always_inline)) {
+            stage_addr_b();
+            static_for<KB>([&](auto dc) __attribute__((always_inline)) { dma_piece_h(decltype(sc)::value * STAGE, sc, dc); });
+        });
+        int rd_off = 0, wr_off = (NST - 1) * STAGE;
+        auto stage_body_h = [&](auto tapc) __attribute__((always_inline)) {
+            constexpr int tap = decltype(tapc)::value;
+            constexpr int tis = (tap + NST - 1) % 9;                    // tap of the stage whose bundle is issued here
+            constexpr int IPWT = KB + hp_of(tis);
+            constexpr int N0T = IPWT < 2 ? IPWT : 2, DREMT = IPWT - N0T;
+            constexpr int WAITN = [&]() constexpr { int n = 0; for (int k = 1; k <= NST - 2; ++k) n += KB + hp_of((tap + k) % 9); return n; }();
+            stage_addr_b();
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(WAITN) : "memory");
+            static_for<NRD>([&](auto rc) __attribute__((always_inline)) { read_frag_h(rd_off, tapc, std::integral_constant<int, 0>{}, rc); });
+            PL_SB();
+            static_for<N0T>([&](auto dc) __attribute__((always_inline)) { dma_piece_h(wr_off, std::integral_constant<int, tis>{}, dc); });
+            PL_SB();
+            static_for<SLOTS>([&](auto gc) __attribute__((always_inline)) {
+                constexpr int g = decltype(gc)::value, s_ = g / NMF, m = g % NMF;
+                mfma_one(std::integral_constant<int, s_>{}, std::integral_constant<int, m>{}, std::integral_constant<int, 0>{});
+                constexpr int d_lo = N0T + (g * DREMT + SLOTS - 1) / SLOTS, d_hi = N0T + ((g + 1) * DREMT + SLOTS - 1) / SLOTS;
+                static_for<d_hi - d_lo>([&](auto k) __attribute__((always_inline)) {
+                    dma_piece_h(wr_off, std::integral_constant<int, tis>{}, std::integral_constant<int, d_lo + decltype(k)::value>{});
+                });
+                if constexpr (s_ + 1 < NSTEP && m < HALF) {
+                    constexpr int r_lo = (m * NRD + HALF - 1) / HALF, r_hi = ((m + 1) * NRD + HALF - 1) / HALF;
+                    static_for<r_hi - r_lo>([&](auto k) __attribute__((always_inline)) {
+                        read_frag_h(rd_off, tapc, std::integral_constant<int, s_ + 1>{}, std::integral_constant<int, r_lo + decltype(k)::value>{});
+                    });
+                }
+                PL_SB();
+            });
+            wr_off = (wr_off + STAGE == NST * STAGE) ? 0 : wr_off + STAGE;
+            rd_off = (rd_off + STAGE == NST * STAGE) ? 0 : rd_off + STAGE;
+            if constexpr (tis == 8) { h_ndelta += 64; h_nbuf ^= HALO_BYTES; --h_left; }     // the next group's halo is on its way
+            if constexpr (tap == 8) h_cur ^= HALO_BYTES;                                      // this group is done
+        };
+        const int n_grp = (n_it + 8) / 9;
+        for (int gi = 0; gi < n_grp; ++gi)
+            static_for<9>([&](auto tapc) __attribute__((always_inline)) { stage_body_h(tapc); });
+    } else
     {   // (launches give every K slice at least one chunk)
         // prologue: NST - 1 stages in flight
         static_for<NST - 1>([&](auto sc) __attribute__((always_inline)) {
@@ -480,7 +606,12 @@ bool conv_tile_is_pl(int tile) {
 #ifdef BP_EXPERIMENTAL
     if (tile == TILE_PL128S || tile == TILE_PL64K2 || tile == TILE_PL64BD) return true;
 #endif
-    return tile == TILE_PL64 || tile == TILE_PL128 || tile == TILE_PL128x64 || tile == TILE_PL256x128;
+    return tile == TILE_PL64 || tile == TILE_PL128 || tile == TILE_PL128x64 || tile == TILE_PL256x128 || tile == TILE_PLH128;
+}
+
+bool conv_plh_eligible(const ConvParams& p) {
+    return conv_pl_eligible(p) && p.mfma_mode == PREC_F16 && p.ksize == 3 && p.stride == 1 && p.pad == 1 && p.OH == p.H && p.OW == p.W &&
+           p.W <= 63 && p.nchunks % 9 == 0 && p.Kpad == 9 * p.Cin;
 }
 
 bool conv_pl_eligible(const ConvParams& p) {
@@ -488,7 +619,7 @@ bool conv_pl_eligible(const ConvParams& p) {
            ((reinterpret_cast<uintptr_t>(p.in16) & 15) == 0) && (p.in16_plane % 8 == 0);
 }
 
-template <int NP, int WM, int WN, int TM, int TN, int NST, int CPS, int LW = 0, int KG = 1, bool BDIR = false>
+template <int NP, int WM, int WN, int TM, int TN, int NST, int CPS, int LW = 0, int KG = 1, bool BDIR = false, int HRT = 0>
 static void launch_pl_t(const ConvParams& p, hipStream_t s) {
     BP_CHECK(BDIR ? p.wbd != nullptr : p.wpl != nullptr, "conv_pl: the filter image of this tile is missing");
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -500,9 +631,9 @@ static void launch_pl_t(const ConvParams& p, hipStream_t s) {
     BP_CHECK(q.hy_splits == 0 || (q.hy_full >= 0 && q.hy_full < q.n_tiles), "hybrid grid: whole tiles out of range");
     dim3 grid(conv_grid_blocks(q));
     if (g_conv_prof)
-        hipExtLaunchKernelGGL((conv_pl_kernel<NP, WM, WN, TM, TN, NST, CPS, LW, KG, BDIR>), grid, dim3(64 * (WM * WN * KG + LW)), 0, s, g_conv_prof->e0, g_conv_prof->e1, 0, q);
+        hipExtLaunchKernelGGL((conv_pl_kernel<NP, WM, WN, TM, TN, NST, CPS, LW, KG, BDIR, HRT>), grid, dim3(64 * (WM * WN * KG + LW)), 0, s, g_conv_prof->e0, g_conv_prof->e1, 0, q);
     else
-        hipLaunchKernelGGL((conv_pl_kernel<NP, WM, WN, TM, TN, NST, CPS, LW, KG, BDIR>), grid, dim3(64 * (WM * WN * KG + LW)), 0, s, q);
+        hipLaunchKernelGGL((conv_pl_kernel<NP, WM, WN, TM, TN, NST, CPS, LW, KG, BDIR, HRT>), grid, dim3(64 * (WM * WN * KG + LW)), 0, s, q);
 }
 
 template <int NP>
@@ -512,6 +643,14 @@ static void launch_pl_np(const ConvParams& p, int tile, hipStream_t s) {
         case TILE_PL128: launch_pl_t<NP, 2, 2, 2, 2, NP == 1 ? 4 : 3, 1>(p, s); break;
         case TILE_PL128x64: launch_pl_t<NP, 2, 2, 2, 1, 3, NP == 1 ? 2 : 1>(p, s); break;
         case TILE_PL256x128: launch_pl_t<NP, 4, 2, 2, 2, NP == 1 ? 3 : 2, 1>(p, s); break;
+        case TILE_PLH128:     // 128x128 with the activations from an LDS-resident halo (fp16, 3x3 / stride 1 / pad 1, W <= 63)
+            if constexpr (NP == 1) {
+                BP_CHECK(conv_plh_eligible(p) && (p.splits == 1 || p.chunks_per_split % 9 == 0) && !p.xcd_home && p.hy_splits == 0,
+                         "halo plane tile: fp16 mode, 3x3 / stride 1 / pad 1, W <= 63, K slices of whole channel groups, plain grid");
+                if (p.W <= 31) launch_pl_t<1, 2, 2, 2, 2, 4, 1, 0, 1, false, 192>(p, s);
+                else launch_pl_t<1, 2, 2, 2, 2, 4, 1, 0, 1, false, 256>(p, s);
+            } else throw Error("the halo plane tile is an fp16 tile");
+            break;
 #ifdef BP_EXPERIMENTAL   // two round-3 forms that are parity-green and bring nothing:
         // planes for the activations + filter fragments direct from global memory (BDIR): 4 blocks per CU and no in-kernel
         // operand split, but both waves of a column pair pull the same fragments through the vector-memory path -- alone

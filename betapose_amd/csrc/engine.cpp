@@ -384,6 +384,14 @@ static const PlanEntry kPlanPL1[] = {
     { 43264,    64,    2, TILE_PL64,  1},
     { 43264,    64,    9, TILE_PL64,  1},
     // batch 28 (BASELINE configs[2]; tools/tune_conv.py --pl --f16 --big --batch 28, profiles/r03_tune_pl_f16_batch28.txt)
+    // round 4: the 3x3 / stride-1 layers on the halo form of the 128x128 tile (TILE_PLH128; tools/bench_plh.py, profiles/r04_plh_kernels.txt:
+    // 7-10 % faster alone than the best all-DMA tile, +1.7-2.6 % on configs[2]).  A row is taken only by layers the tile can run
+    // (choose_pl checks conv_plh_eligible): the stride-2 layers that share a row's key fall through to the row below it
+    {   4732,  1024,  144, TILE_PLH128,  1},
+    {   8960,   256,   72, TILE_PLH128,  1},
+    {  18928,   512,   72, TILE_PLH128,  1},
+    {  35840,   128,   36, TILE_PLH128,  1},
+    {  75712,   256,   36, TILE_PLH128,  1},
     {   2240,   512,   64, TILE_PL64,  1},
     {   2240,   512,  144, TILE_PL64,  1},
     {   2240,  2048,   16, TILE_PL64,  1},
@@ -429,15 +437,18 @@ static const PlanEntry kPlanPL1[] = {
 // conv_pl.hip (operand planes + LDS-DMA): which block tile, how many K slices
 static void choose_pl(const ConvParams& c, long long M, int mode, int sk_max, int* tile, int* splits) {
     for (const PlanEntry& e : plan_file_entries())
-        if (e.M == (int)M && e.CoutPad == c.CoutPad && e.nchunks == c.nchunks && conv_tile_is_pl(e.tile)) { *tile = e.tile; *splits = e.splits; return; }
+        if (e.M == (int)M && e.CoutPad == c.CoutPad && e.nchunks == c.nchunks && conv_tile_is_pl(e.tile) &&
+            (!conv_tile_is_plh(e.tile) || conv_plh_eligible(c))) { *tile = e.tile; *splits = e.splits; return; }
     for (const PlanEntry* e = (mode == PREC_F16 ? kPlanPL1 : kPlanPL3); e->M != 0; ++e)   // tables end with a zero row
-        if (e->M == (int)M && e->CoutPad == c.CoutPad && e->nchunks == c.nchunks) { *tile = e->tile; *splits = e->splits; return; }
+        if (e->M == (int)M && e->CoutPad == c.CoutPad && e->nchunks == c.nchunks &&
+            (!conv_tile_is_plh(e->tile) || conv_plh_eligible(c))) { *tile = e->tile; *splits = e->splits; return; }     // (a 3x3 row also matches stride-2 / 1x1 layers of the same K)
     // other shapes (batched runs): the 128x128 block once its grid covers the chip (half the operand bytes per FLOP of the
     // 64x64 block: profiles/r03_bench_pl_batch28.txt), else the 64x64 block with enough K slices to fill it
     // (short K loops -- the 1x1 layers of the bottlenecks -- stay on the 64x64 block even then: a 128x128 block runs one per
     // CU and its prologue / epilogue are not covered by a neighbour's K loop; profiles/r03_tune_pl_f16_batch28.txt)
     const long long tiles128 = ((M + 127) / 128) * ((c.CoutPad + 127) / 128);
     int t = (c.CoutPad >= 128 && tiles128 >= 192 && c.nchunks >= 32) ? TILE_PL128 : TILE_PL64;
+    if (t == TILE_PL128 && mode == PREC_F16 && conv_plh_eligible(c)) t = TILE_PLH128;     // 3x3 / stride 1: the halo form beats the all-DMA tile wherever both run
     int s = 1;
     if (t == TILE_PL64) {
         const long long blocks = ((M + 63) / 64) * (c.CoutPad / 64);
@@ -511,7 +522,7 @@ static bool tile_runs(int tile, const ConvParams& c) {
     // (round-3 advisor finding: a forced tile 0 / 1 in the fp16 mode read tensors nobody stored)
     const bool on_planes = c.in16 != nullptr && c.wpl != nullptr;
     if (tile == TILE_64x64 || tile == TILE_128x64) return !on_planes;
-    if (conv_tile_is_pl(tile)) return c.mfma_mode != PREC_F32 && conv_pl_eligible(c);
+    if (conv_tile_is_pl(tile)) return c.mfma_mode != PREC_F32 && conv_pl_eligible(c) && (!conv_tile_is_plh(tile) || conv_plh_eligible(c));
     if (tile == TILE_64x64_BD || tile == TILE_BD_K2) return c.mfma_mode == PREC_BF16X3 && conv_h16_eligible(c) && c.w16s != nullptr && !on_planes;
     if (conv_tile_is_halo(tile)) return c.mfma_mode == PREC_BF16X3 && c.in16 == nullptr && conv_halo_eligible(c, tile);
 #ifdef BP_EXPERIMENTAL
@@ -919,7 +930,7 @@ bool conv_hybrid_plan(const ConvParams& p, int tile, size_t partial_floats, int*
 }
 
 bool conv_home_layout(int tile, int splits) {
-    return splits > 1 && splits <= 64 && xcc_base() >= 0 && (tile == TILE_64x64_BD || conv_tile_is_pl(tile));
+    return splits > 1 && splits <= 64 && xcc_base() >= 0 && (tile == TILE_64x64_BD || (conv_tile_is_pl(tile) && !conv_tile_is_plh(tile)));
 }
 void conv_prefetch_of(ConvParams& p, const ConvParams& next, int nt, int ns, int nc) {
     p.pf_ptr = nullptr;

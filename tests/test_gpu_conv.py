@@ -255,6 +255,31 @@ def test_conv_planes_from_the_fp32_kernels(cuda):
     # ... and through an engine they arrive: covered by tests/test_gpu_nets.py (every layer of both networks in both modes)
 
 
+@pytest.mark.parametrize("shape", [(1, 13, 13, 64, 128, 1), (2, 26, 26, 64, 192, 1), (1, 52, 52, 128, 256, 2), (3, 20, 16, 96, 128, 3),
+                                   (5, 10, 8, 64, 64, 1), (1, 40, 32, 32, 128, 1), (2, 7, 63, 32, 64, 1), (1, 3, 2, 64, 64, 2)])
+@pytest.mark.parametrize("tile", ["plh128"])
+def test_conv_pl_halo_tile_f16(cuda, shape, tile):
+    """TILE_PLH128 / TILE_PLH256 (round 4): the 128x128 / 256x128 fp16 plane tiles with the activations of a 3x3 / stride-1 layer read from an LDS-resident
+    halo (one fetch per 32-channel group instead of one per tap).  Same operands and the same fp32 sums per tap as the all-DMA
+    128x128 tile: against torch on the fp16-rounded operands, against that tile, bit-reproducible, planes = RNE of the output;
+    images whose rows wrap inside a tile, tiles spanning images, M far below the tile, W up to 63, K slices of whole groups."""
+    N, H, W, Cin, Cout, splits = shape
+    g = torch.Generator().manual_seed(8800 + H * W + Cin)
+    x = (torch.randn(N, H, W, Cin, generator=g) * torch.exp(torch.randn(N, H, W, 1, generator=g))).half().float()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / np.sqrt(Cin * 9)).half().float()
+    b = torch.randn(Cout, generator=g)
+    res = torch.randn(N, H, W, Cout, generator=g)
+    ref = _ref(x, w, b, 1, 1, "leaky", res, True)
+    kw = dict(pad=1, act="leaky", res=res.to(cuda), res_after_act=True, splits=splits)
+    out, pl = ops.conv2d_nhwc(x.to(cuda), w, b, tile=tile + "_f16", planes=True, **kw)
+    assert torch.equal(out, ops.conv2d_nhwc(x.to(cuda), w, b, tile=tile + "_f16", **kw))
+    assert torch.equal(_planes_to_f32(pl, "f16"), out.half().float())
+    base = ops.conv2d_nhwc(x.to(cuda), w, b, tile="pl128_f16", **kw)
+    scale = max(1.0, float(ref.abs().mean()))
+    _check(out.cpu().permute(0, 3, 1, 2), ref, tol=2e-5 * scale)
+    _check(out.cpu().permute(0, 3, 1, 2), base.cpu().permute(0, 3, 1, 2), tol=2e-5 * scale)
+
+
 def test_conv_pl_full_size_layers(cuda):
     """Full-size layers of both networks: against the definition (fp64) and the size-independent linearity property."""
     g = torch.Generator().manual_seed(23)
