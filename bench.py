@@ -336,6 +336,8 @@ def roofline(det, pose, batch):
         np_ = 1 if mode == "f16" else 3
         if tile in PL_TILE_ARGS:
             return "bp::conv_pl_kernel<%d, %s>" % (np_, PL_TILE_ARGS[tile][np_])
+        if tile == 25:
+            return "bp::conv_pl_kernel<1, 2, 2, 2, 2, 4, 1, 0, 1, false, *>"       # halo form of the 128x128 fp16 plane tile (* = halo rows, by map width)
         if tile == 12:
             return "bp::conv_igemm_h_kernel<1, 1, 3, true>"        # filters direct
         if tile in (21, 22):
