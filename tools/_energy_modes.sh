@@ -17,3 +17,4 @@ $B --streams 1 2>/dev/null | val "bf16x3, one frame at a time"
 $B --streams 2 2>/dev/null | val "bf16x3, 2 in flight"
 $B --batch 28 --streams 2 --steps 60 2>/dev/null | val "bf16x3, batch 28 x 2 streams"
 $B --batch 28 --streams 3 --steps 60 --precision f16 2>/dev/null | val "fp16, batch 28 x 3 streams"
+$B --batch 28 --streams 3 --steps 60 --precision f16r 2>/dev/null | val "fp16 with fp16 skip connections (f16r), batch 28 x 3 streams"
