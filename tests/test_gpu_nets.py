@@ -233,6 +233,33 @@ def test_f16_mode_yolo(cuda, pipe_gold):
         assert int(p16[b, :, 4].argmax()) == int(p32[b, :, 4].argmax()) == int(pipe_gold["f%d_obj_argmax" % b])
 
 
+def test_f16_modes_yolo_batch28(cuda, pipe_gold):
+    """BASELINE configs[2]'s shape for the detector: 28 frames per launch in the fp16 modes.  At this batch the 3x3 / stride-1 layers
+    run on the halo form of the 128x128 plane tile (TILE_PLH128, engine.cpp kPlanPL1) whose tiles span image rows and images: same
+    stated tolerances against the fp32 plan as the batch-2 test above, per-frame results equal to a batch-1 launch within fp16
+    rounding, box index identical on the golden frames."""
+    net = Darknet("yolo/cfg/yolov3-single.cfg", reso=416, max_batch=28).load_stream(helpers.yolo_stream()).cuda().eval()
+    x = torch.cat([helpers.yolo_input_from_frame(f) for f in helpers.frames(28)])
+    net.set_precision("f32")
+    p32 = net(x.to(cuda)).cpu()
+    for mode in ("f16", "f16r"):
+        net.set_precision(mode)
+        p16 = net(x.to(cuda)).cpu()
+        assert torch.equal(net(x.to(cuda)).cpu(), p16)                  # bit-reproducible
+        d = (p16 - p32).abs()
+        assert float(d.max()) > 1e-6
+        assert float(d[..., :2].max()) < 0.25, mode
+        assert bool((d[..., 2:4] <= 0.05 + 2e-2 * p32[..., 2:4].abs()).all()), mode
+        assert float(d[..., 4:].max()) < 5e-3, mode
+        same = sum(int(p16[b, :, 4].argmax()) == int(p32[b, :, 4].argmax()) for b in range(28))
+        assert same >= 27, (mode, same)                                  # (a frame whose two best boxes are closer than the fp16 rounding may swap)
+        for b in range(2):
+            assert int(p16[b, :, 4].argmax()) == int(pipe_gold["f%d_obj_argmax" % b])
+        one = torch.cat([net(x[i:i + 1].to(cuda)).cpu() for i in (0, 13, 27)])
+        d1 = (one - p16[[0, 13, 27]]).abs()
+        assert float(d1[..., :2].max()) < 0.25 and float(d1[..., 4:].max()) < 5e-3, mode
+
+
 def test_f16r_mode_fp16_skip_connections(cuda, pipe_gold):
     """Round 4: the fp16 mode with fp16 SKIP CONNECTIONS ('f16r', Net::set_precision(PREC_F16_RES)) -- residuals are read from the
     fp16 operand plane the producer wrote for the next convolution, and tensors that only convolutions and residual adds read lose
