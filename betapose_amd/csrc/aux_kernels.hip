@@ -606,22 +606,27 @@ void launch_crop(const uint8_t* frames, int batch, int H, int W, const float* se
 // Pillow's ImagingResample for 8-bit: per output pixel a window [xmin, xmin+xsize) with integer
 // coefficients (PRECISION_BITS = 22), accumulate ss = 1<<21 + sum(pix*k), result = clip8(ss >> 22);
 // horizontal pass first, then vertical, each rounding to u8.
+// (one thread per output PIXEL: the window and its coefficients are fetched once for the three channels, three independent sums)
 __global__ void resize_h_kernel(const uint8_t* __restrict__ in, int H, int W, uint8_t* __restrict__ tmp, int ow,
                                 const int* __restrict__ hb, const int* __restrict__ hk, int ks) {
     in += (long long)blockIdx.y * H * W * 3;
     tmp += (long long)blockIdx.y * H * ow * 3;
-    const int total = H * ow * 3;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-        const int ch = e % 3;
-        const int t = e / 3;
+    const int total = H * ow;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
         const int ox = t % ow, y = t / ow;
         const int xmin = hb[2 * ox], n = hb[2 * ox + 1];
         const int* k = hk + ox * ks;
-        int ss = 1 << 21;
-        const uint8_t* row = in + ((long long)y * W + xmin) * 3 + ch;
-        for (int i = 0; i < n; ++i) ss += (int)row[i * 3] * k[i];
-        ss >>= 22;
-        tmp[e] = (uint8_t)(ss < 0 ? 0 : (ss > 255 ? 255 : ss));
+        int s0 = 1 << 21, s1 = 1 << 21, s2 = 1 << 21;
+        const uint8_t* row = in + ((long long)y * W + xmin) * 3;
+        for (int i = 0; i < n; ++i) {
+            const int c = k[i];
+            s0 += (int)row[i * 3] * c; s1 += (int)row[i * 3 + 1] * c; s2 += (int)row[i * 3 + 2] * c;
+        }
+        s0 >>= 22; s1 >>= 22; s2 >>= 22;
+        uint8_t* o = tmp + (long long)t * 3;
+        o[0] = (uint8_t)(s0 < 0 ? 0 : (s0 > 255 ? 255 : s0));
+        o[1] = (uint8_t)(s1 < 0 ? 0 : (s1 > 255 ? 255 : s1));
+        o[2] = (uint8_t)(s2 < 0 ? 0 : (s2 > 255 ? 255 : s2));
     }
 }
 __global__ void resize_v_kernel(const uint8_t* __restrict__ tmp, int H, int ow, float* __restrict__ out_nhwc,
@@ -630,28 +635,32 @@ __global__ void resize_v_kernel(const uint8_t* __restrict__ tmp, int H, int ow, 
     tmp += (long long)blockIdx.y * H * ow * 3;
     if (out_nhwc) out_nhwc += (long long)blockIdx.y * oh * ow * 3;
     if (out_u8) out_u8 += (long long)blockIdx.y * oh * ow * 3;
-    const int total = oh * ow * 3;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-        const int ch = e % 3;
-        const int t = e / 3;
+    const int total = oh * ow;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
         const int ox = t % ow, oy = t / ow;
         const int ymin = vb[2 * oy], n = vb[2 * oy + 1];
         const int* k = vk + oy * ks;
-        int ss = 1 << 21;
-        const int src_ch = swap_rb ? 2 - ch : ch;
-        const uint8_t* col = tmp + ((long long)ymin * ow + ox) * 3 + src_ch;
-        for (int i = 0; i < n; ++i) ss += (int)col[(long long)i * ow * 3] * k[i];
-        ss >>= 22;
-        const int v = ss < 0 ? 0 : (ss > 255 ? 255 : ss);
-        if (out_u8) out_u8[e] = (uint8_t)v;
-        if (out_nhwc) out_nhwc[e] = (float)v / 255.f;
+        int ss[3] = {1 << 21, 1 << 21, 1 << 21};
+        const uint8_t* col = tmp + ((long long)ymin * ow + ox) * 3;
+        for (int i = 0; i < n; ++i) {
+            const int c = k[i];
+            const uint8_t* q = col + (long long)i * ow * 3;
+            ss[0] += (int)q[0] * c; ss[1] += (int)q[1] * c; ss[2] += (int)q[2] * c;
+        }
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const int r = ss[swap_rb ? 2 - ch : ch] >> 22;
+            const int v = r < 0 ? 0 : (r > 255 ? 255 : r);
+            if (out_u8) out_u8[(long long)t * 3 + ch] = (uint8_t)v;
+            if (out_nhwc) out_nhwc[(long long)t * 3 + ch] = (float)v / 255.f;
+        }
     }
 }
 void launch_resize_bicubic(const uint8_t* in, int batch, int H, int W, uint8_t* tmp, float* out_nhwc, uint8_t* out_u8,
                            int oh, int ow, const ResizeTables& t, int swap_rb, hipStream_t s) {
-    hipLaunchKernelGGL(resize_h_kernel, dim3(grid_for((long long)H * ow * 3), batch), dim3(256), 0, s, in, H, W, tmp, ow,
+    hipLaunchKernelGGL(resize_h_kernel, dim3(grid_for((long long)H * ow), batch), dim3(256), 0, s, in, H, W, tmp, ow,
                        t.hb, t.hk, t.ksize_h);
-    hipLaunchKernelGGL(resize_v_kernel, dim3(grid_for((long long)oh * ow * 3), batch), dim3(256), 0, s, tmp, H, ow,
+    hipLaunchKernelGGL(resize_v_kernel, dim3(grid_for((long long)oh * ow), batch), dim3(256), 0, s, tmp, H, ow,
                        out_nhwc, out_u8, oh, t.vb, t.vk, t.ksize_v, swap_rb);
 }
 
