@@ -33,9 +33,33 @@ static void run(int grid, unsigned* d, hipStream_t s) {
     printf("\n");
 }
 
+// four launches alive at once on four streams (the batch-1 pipeline's situation): blocks per CU over all four
+template <int NT, int LDSKB>
+static void run4(int grid, unsigned** d, hipStream_t* st) {
+    for (int k = 0; k < 4; ++k) hipLaunchKernelGGL((probe<NT, LDSKB>), dim3(grid), dim3(NT), 0, st[k], d[k], 6000);
+    hipDeviceSynchronize();
+    std::map<unsigned, int> per;
+    for (int k = 0; k < 4; ++k) {
+        std::vector<unsigned> h(grid);
+        hipMemcpy(h.data(), d[k], grid * 4, hipMemcpyDeviceToHost);
+        for (unsigned v : h) ++per[v];
+    }
+    int mx = 0; std::map<int, int> hist;
+    for (auto& kv : per) { mx = kv.second > mx ? kv.second : mx; ++hist[kv.second]; }
+    printf("4 streams x grid %4d (threads %d, LDS %d KB): %3zu distinct CUs, max %d blocks on one CU; CUs by block count:", grid, NT, LDSKB, per.size(), mx);
+    for (auto& kv : hist) printf(" %dx%d", kv.second, kv.first);
+    printf("\n");
+}
+
 int main() {
     hipStream_t s; hipStreamCreate(&s);
     unsigned* d; hipMalloc(&d, 8192 * 4);
+    {
+        hipStream_t st[4]; unsigned* dd[4];
+        for (int k = 0; k < 4; ++k) { hipStreamCreate(&st[k]); hipMalloc(&dd[k], 8192 * 4); }
+        for (int rep = 0; rep < 2; ++rep)
+            for (int grid : {64, 86, 144, 192, 240}) { run4<512, 50>(grid, dd, st); run4<256, 24>(grid, dd, st); }
+    }
     for (int grid : {86, 144, 192, 240, 256, 344, 512}) {
         run<256, 24>(grid, d, s);
         run<512, 50>(grid, d, s);
