@@ -260,6 +260,43 @@ def test_f16_modes_yolo_batch28(cuda, pipe_gold):
         assert float(d1[..., :2].max()) < 0.25 and float(d1[..., 4:].max()) < 5e-3, mode
 
 
+@pytest.mark.parametrize("batch,mode", [(5, "bf16x3"), (8, "f16"), (12, "f16r"), (7, "bf16x3")])
+def test_unplanned_batch_sizes_take_the_heuristics(cuda, pipe_gold, batch, mode):
+    """Batch sizes no plan table lists (engine.cpp: the tables hold batch 1 and 28) run on the choose_h16 / choose_pl heuristics -- halo
+    tiles once 64 tiles exist, the halo plane tile where the 128x128 plane tile would run: every frame of the batch equals its own
+    batch-1 launch at the mode's bar (bf16x3: the fp32 bar, box index identical; fp16 modes: the stated fp16 tolerances)."""
+    net = Darknet("yolo/cfg/yolov3-single.cfg", reso=416, max_batch=batch).load_stream(helpers.yolo_stream()).cuda().eval()
+    net.set_precision(mode)
+    x = torch.cat([helpers.yolo_input_from_frame(f) for f in helpers.frames(batch)])
+    pb = net(x.to(cuda)).cpu()
+    assert torch.equal(net(x.to(cuda)).cpu(), pb)
+    for i in (0, batch // 2, batch - 1):
+        p1 = net(x[i:i + 1].to(cuda)).cpu()
+        if mode == "bf16x3":
+            assert _box_ok(p1[0, :, :4].numpy(), pb[i, :, :4].numpy())
+            assert float((p1[0, :, 4:] - pb[i, :, 4:]).abs().max()) <= PROB_TOL
+            assert int(p1[0, :, 4].argmax()) == int(pb[i, :, 4].argmax())
+        else:
+            d = (p1[0] - pb[i]).abs()
+            assert float(d[:, :2].max()) < 0.25 and float(d[:, 4:].max()) < 5e-3
+            assert bool((d[:, 2:4] <= 0.05 + 2e-2 * pb[i, :, 2:4].abs()).all())
+    kpd = FastPoseHIP(helpers.kpd_state_dict(), n_classes=50, max_batch=batch).cuda().eval()
+    kpd.set_precision(mode)
+    g = torch.Generator().manual_seed(100 + batch)
+    crops = torch.cat(_crops_from_golden(pipe_gold, 2) + [torch.rand(batch - 2, 3, 320, 256, generator=g) - 0.45])
+    hb = kpd(crops.to(cuda)).cpu()
+    flips = 0
+    for i in (0, 1, batch - 1):
+        h1 = kpd(crops[i:i + 1].to(cuda)).cpu()
+        if mode == "bf16x3":
+            assert float((h1[0] - hb[i]).abs().max()) <= 1e-4
+            assert torch.equal(h1[0].view(50, -1).argmax(1), hb[i].view(50, -1).argmax(1))
+        else:
+            assert float((h1[0] - hb[i]).abs().max()) < 1e-2
+            flips += int((h1[0].view(50, -1).argmax(1) != hb[i].view(50, -1).argmax(1)).sum())
+    assert flips <= 3                                   # <= 2 % of 150 key points (the bar of test_f16_mode_kpd_batch28)
+
+
 def test_f16r_mode_fp16_skip_connections(cuda, pipe_gold):
     """Round 4: the fp16 mode with fp16 SKIP CONNECTIONS ('f16r', Net::set_precision(PREC_F16_RES)) -- residuals are read from the
     fp16 operand plane the producer wrote for the next convolution, and tensors that only convolutions and residual adds read lose
