@@ -690,15 +690,23 @@ __device__ __forceinline__ void stem3x3_body(const P& p, const int bp_bid, f32x4
     // meets no multiply); outside the image the offset is out of range: zeros
     const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.in), 0, (int)min((long long)p.N * p.H * p.W * p.in_ld * 4, (long long)OOB), 0x00020000);
-    // a REAL loop over the taps (unrolled, hipcc loads all 72 filter quads up front whatever the source order: 288 registers --
-    // scalar ones spilled lane by lane into vector registers, or 256 vector registers at one wave per SIMD; both measured
-    // slower than the MFMA kernel).  Eight waves per SIMD cover the per-tap load latency instead.
+    // the CG waves of a block need the same nine taps of the same 64 pixels: each tap is fetched by ONE wave (wave cg takes taps cg,
+    // cg + CG, ...) and shared through LDS (xs [tap][lane], behind the output tile) -- 9 instead of 9 CG 16-B requests per pixel
+    f32x4* const xs = tile + 64 * (2 * CG + 1);
 #pragma unroll 1
-    for (int t = 0; t < 9; ++t) {
+    for (int t = cg; t < 9; t += CG) {
         const int ky = (t * 11) >> 5, kx = t - 3 * ky;          // t / 3 for t < 9
         const int iy = oy + ky - 1, ix = ox + kx - 1;
         const bool in_img = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        const f32x4 x = buf_load4(rsrcA, in_img ? (unsigned)((((b * p.H + iy) * p.W + ix) * p.in_ld) * 4) : OOB, 0);
+        xs[t * 64 + lane] = buf_load4(rsrcA, in_img ? (unsigned)((((b * p.H + iy) * p.W + ix) * p.in_ld) * 4) : OOB, 0);
+    }
+    __syncthreads();
+    // a REAL loop over the taps (unrolled, hipcc loads all 72 filter quads up front whatever the source order: 288 registers --
+    // scalar ones spilled lane by lane into vector registers, or 256 vector registers at one wave per SIMD; both measured
+    // slower than the MFMA kernel).  Eight waves per SIMD cover the per-tap latency instead.
+#pragma unroll 1
+    for (int t = 0; t < 9; ++t) {
+        const f32x4 x = xs[t * 64 + lane];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const f32x4 w = *reinterpret_cast<const f32x4*>(wrow + c * p.Kpad + t * 4);
@@ -741,7 +749,7 @@ __device__ __forceinline__ void stem3x3_body(const P& p, const int bp_bid, f32x4
 
 template <int CG>
 __global__ __launch_bounds__(64 * CG) void stem3x3_kernel(const ConvParams p) {
-    __shared__ f32x4 tile[64 * (2 * CG + 1)];
+    __shared__ f32x4 tile[64 * (2 * CG + 1) + 9 * 64];       // the output tile + the nine taps of the block's pixels
     stem3x3_body<CG>(p, (int)blockIdx.x, tile);
 }
 
