@@ -13,10 +13,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbetapose_hip.so")
 SOURCES = ["conv_igemm.hip", "conv_halo.hip", "conv_pl.hip", "aux_kernels.hip", "engine.cpp", "host_post.cpp", "frame_io.cpp", "jpeg_bmp.cpp", "c_api.cpp", "darknet_compat.cpp"]
-HEADERS = ["bp_common.h", "engine.h", "frame_io.h", "conv_tail.inc", "conv_dev.h", "conv_igemm.hip", "conv_halo.hip", "mega.inc", os.path.join("..", "..", "include", "betapose_hip.h"),
+HEADERS = ["bp_common.h", "engine.h", "frame_io.h", "conv_tail.inc", "conv_dev.h", os.path.join("..", "..", "include", "betapose_hip.h"),
            os.path.join("..", "..", "include", "yolo_v2_class_compat.h")]
 # measured-and-superseded kernels (round-1/2 experiments): compiled only into libbetapose_hip_exp.so (--experimental)
 EXP_SOURCES = ["conv_w64.hip", "conv_kg.hip", "conv_rd.hip"]
+# ... and what only the experimental library includes (the persistent per-XCD launch and the unit that compiles it)
+EXP_HEADERS = ["mega.inc", "kernels_unity.hip"]
 ARCH = "gfx950"
 # Host launch stubs every HIP object must export.  hipcc has been seen to drop a kernel's host stub SILENTLY (the object
 # links, the launch then fails at run time) -- DESIGN.md §3.1d -- so the build counts them.
@@ -35,7 +37,7 @@ def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + EXP_SOURCES + HEADERS]
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]   # (product library: the experimental sources are not its inputs)
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 

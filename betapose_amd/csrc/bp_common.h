@@ -3,8 +3,11 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <mutex>
+#include <set>
 #include <stdexcept>
 #include <string>
+#include <utility>
 
 namespace bp {
 
@@ -25,6 +28,20 @@ struct Error : std::runtime_error {
         if (!(cond)) throw ::bp::Error(std::string(msg) + " (" #cond ") @" + __FILE__ +   \
                                        ":" + std::to_string(__LINE__));                   \
     } while (0)
+
+// More than 64 KB of dynamic LDS needs an opt-in that belongs to the DEVICE's loaded function, not to the process: engines on a second
+// GPU of the same process (the C API takes a device per engine) must set it again, and two host threads may make their first launch
+// together (round-4 advisor finding: a function-local `static bool` covered neither).  One entry per (device, kernel).
+inline void allow_big_lds(const void* kernel) {
+    static std::mutex mu;
+    static std::set<std::pair<int, const void*>> done;
+    int dev = 0;
+    BP_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.count({dev, kernel})) return;
+    BP_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+    done.insert({dev, kernel});
+}
 
 // The clock of the kernels' debug / in-situ stamps (ConvParams::stamps): s_memrealtime, the constant 100 MHz reference clock
 // that is ONE counter for the whole device.  (s_memtime, the shader-cycle counter, is per XCD: marks of blocks on different
@@ -95,7 +112,8 @@ struct ConvParams {
     //    t % 8), so the slab hand-off never leaves that XCD's L2: workgroup-scope (sc0) slab stores and loads, an L2-local
     //    ticket -- instead of write-through to the memory side and back (conv_tail.inc).  Correctness then rests on the
     //    round-robin dispatch.  It is CHECKED in every launch: each slice publishes its XCC_ID (agent scope, xcc_of), the
-    //    reducing block compares them with its own before it stores anything and TRAPS on a mismatch (the stream fails).
+    //    reducing block compares them with its own before it stores anything and on a mismatch raises err_word and skips the tile
+    //    (the host re-runs the frame without the layout; round 4 trapped, which cost the process its whole HIP context).
     //  * filter prefetch for the NEXT convolution on the stream (lone-frame latency mode, Net::set_prefetch): the launch
     //    carries extra blocks past its work grid that pull the head of the next layer's filters into the L2 of the XCD whose
     //    blocks will read them, while this layer computes.  At batch 1 every layer's filters come cold from HBM (730 MB per
@@ -113,6 +131,7 @@ struct ConvParams {
     int hy_full, hy_splits, hy_cps;   // hy_splits == 0: off
     int xcd_home;                 // 1: block b -> x = b % 8, i = b / 8: tile (i / splits) * 8 + x, K slice i % splits
     int* xcc_of;                  // [tiles][64] XCC_ID of every K slice of the running launch
+    int* err_word;                // raised (bit 0) by a reducing block whose slices did not all run on its XCD: the tile is NOT stored (conv_dev.h xcd_home_verify)
     int* tickets_local;           // [tiles] arrival counters of the xcd_home launches (touched by L2-local atomics only)
     int mtiles, n_tiles;          // M-tiles, output tiles of the launch (set by the launchers)
     int work_blocks;              // blocks of the work grid incl. padding (set by the launchers; 0 = the whole grid)

@@ -396,6 +396,20 @@ int bp_calibrate_ticks(long long ticks, float* ms, void* stream) {
 }
 int bp_yolo_set_prefetch(bp_yolo* y, int on) { y->net->set_prefetch(on != 0); return 0; }
 int bp_kpd_set_prefetch(bp_kpd* k, int on) { k->net->set_prefetch(on != 0); return 0; }
+int bp_yolo_xcd_errors(bp_yolo* y, int* count, void* stream) {
+    BP_TRY
+    BP_CHECK(y && count, "null argument");
+    *count = y->net->take_xcd_errors((hipStream_t)stream);
+    return 0;
+    BP_CATCH
+}
+int bp_kpd_xcd_errors(bp_kpd* k, int* count, void* stream) {
+    BP_TRY
+    BP_CHECK(k && count, "null argument");
+    *count = k->net->take_xcd_errors((hipStream_t)stream);
+    return 0;
+    BP_CATCH
+}
 int bp_yolo_set_stamps(bp_yolo* y, unsigned long long* d_buf, int slots) { y->net->set_stamps(d_buf, slots); return 0; }
 int bp_kpd_set_stamps(bp_kpd* k, unsigned long long* d_buf, int slots) { k->net->set_stamps(d_buf, slots); return 0; }
 static int op_name(const bp::Net& net, int i, char* out, int cap) {

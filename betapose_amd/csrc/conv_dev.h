@@ -78,8 +78,8 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds, un
 }
 
 // xcd_home launches keep their split-K hand-off inside one XCD's L2: the block must really sit on the XCD its index says
-// (round-robin dispatch).  A violation would mean partial sums read from the wrong L2 -- silently wrong numbers -- so it
-// aborts the launch instead (the host sees a failed stream).
+// (round-robin dispatch).  A violation would mean partial sums read from the wrong L2 -- silently wrong numbers -- so every
+// launch checks it and reports through an error word (xcd_home_verify below).
 __device__ __forceinline__ int xcc_id() {
     unsigned id;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
@@ -89,17 +89,21 @@ __device__ __forceinline__ int xcc_id() {
 // ticket, which follows an s_waitcnt vmcnt(0))
 template <class P>
 __device__ __forceinline__ void xcd_home_mark(const P& p, int tile_id, int split) {
-    if (threadIdx.x == 0) __hip_atomic_store(&p.xcc_of[tile_id * 64 + split], xcc_id(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (xcd_home == 3: fault injection for the tests of the error path -- slice 0 publishes a wrong XCD)
+    if (threadIdx.x == 0) __hip_atomic_store(&p.xcc_of[tile_id * 64 + split], xcc_id() ^ ((p.xcd_home >> 1) & (split == 0)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// in the reducing block: every slice of the tile must have run on this block's XCD.  A mismatch TRAPS: the whole HIP context
-// (every stream of the process) is lost, not just this launch -- which is why the layout is used in the opt-in latency mode only,
-// on ordinary (unmasked) streams whose dispatch the one-time probe (engine.cpp xcc_base) has seen to be round robin; bench.py
-// never combines it with --partition (CU-masked queues)
+// in the reducing block: every slice of the tile must have run on this block's XCD.  A mismatch means the partial sums this block
+// is about to read may still sit in ANOTHER XCD's L2: the block raises the engine's error word (ConvParams::err_word, agent scope) and
+// stores nothing for the tile -- no trap (round 4 killed the whole HIP context, every stream of the process, on a mismatch): the host
+// reads the word behind the frame (Net::take_xcd_errors; FramePipeline.run), switches the latency mode off and runs the frame again on
+// the ordinary hand-off.  Returns false on a mismatch (block-uniform).
 template <class P>
-__device__ __forceinline__ void xcd_home_verify(const P& p, int tile_id) {
-    if ((int)threadIdx.x < p.splits &&
-        __hip_atomic_load(&p.xcc_of[tile_id * 64 + (int)threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != xcc_id())
-        __builtin_trap();
+__device__ __forceinline__ bool xcd_home_verify(const P& p, int tile_id) {
+    const bool bad = (int)threadIdx.x < p.splits &&
+        __hip_atomic_load(&p.xcc_of[tile_id * 64 + (int)threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != xcc_id();
+    const bool any_bad = __syncthreads_or(bad ? 1 : 0) != 0;
+    if (any_bad && threadIdx.x == 0 && p.err_word) __hip_atomic_fetch_or(p.err_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return !any_bad;
 }
 
 // A block past the work grid (ConvParams::pf_*): pull its share of the next layer's filters through the memory hierarchy.

@@ -494,11 +494,7 @@ static void launch_halo_t(const ConvParams& p, int tile, hipStream_t s) {
     ConvParams q = p;
     conv_grid_setup(q, 64, 32 * NW);
     const size_t lds = conv_halo_lds_bytes(p, tile);
-    static bool attr_set = false;   // (> 64 KB of dynamic LDS needs the attribute once per kernel)
-    if (!attr_set) {
-        BP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<NW, NPASS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-        attr_set = true;
-    }
+    allow_big_lds(reinterpret_cast<const void*>(&conv_halo_kernel<NW, NPASS>));   // (> 64 KB of dynamic LDS: once per device and kernel)
     dim3 grid(q.n_tiles * q.splits);
     if (g_conv_prof)
         hipExtLaunchKernelGGL((conv_halo_kernel<NW, NPASS>), grid, dim3(64 * NW), lds, s, g_conv_prof->e0, g_conv_prof->e1, 0, q);
@@ -511,11 +507,7 @@ static void launch_halo_k2_t(const ConvParams& p, int tile, hipStream_t s) {
     ConvParams q = p;
     conv_grid_setup(q, 64, 64);
     const size_t lds = conv_halo_lds_bytes(p, tile);
-    static bool attr_set = false;
-    if (!attr_set) {
-        BP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_k2_kernel<NPASS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-        attr_set = true;
-    }
+    allow_big_lds(reinterpret_cast<const void*>(&conv_halo_k2_kernel<NPASS>));
     dim3 grid(q.n_tiles * q.splits);
     if (g_conv_prof)
         hipExtLaunchKernelGGL((conv_halo_k2_kernel<NPASS>), grid, dim3(256), lds, s, g_conv_prof->e0, g_conv_prof->e1, 0, q);

@@ -101,7 +101,7 @@ static const SplitEntry kSplitTable[] = {
 // other shapes use the heuristic in choose_h16.
 // COVERAGE: the rows below are the conv shapes of the two networks at BATCH 1 (M = OH x OW of one 416x416 frame / one 320x256 crop);
 // the conv_pl tables further down also carry batch 28 (BASELINE configs[2]).  Any other batch size or input resolution takes the
-// heuristics in choose_h16 / choose_pl, which are measured at batch 2, 4 and 28 only (tools/_batch_check.sh, profiles/r04_batched.txt).
+// heuristics in choose_h16 / choose_pl, which are measured at batch 2, 4 and 28 only (tools/batch_check.sh, profiles/r04_batched.txt).
 struct PlanEntry { int M, CoutPad, nchunks, tile, splits; };
 static const PlanEntry kPlanB3[] = {
     // (round 4, TILE_BD_K2 rows: the filters-direct tile with two K groups inside an eight-wave block and about half the K slices
@@ -627,7 +627,7 @@ int Net::add_conv(const std::string& name, const Tensor& in, const Tensor& out_v
     c.w16 = nullptr; c.w16s = nullptr;
     c.in16 = nullptr; c.out16 = nullptr; c.wpl = nullptr; c.wbd = nullptr; c.in16_plane = c.out16_plane = 0; c.out_np = 0; c.abl = 0; c.skip_f32 = 0; c.res16 = nullptr;
     c.pool_out = nullptr; c.hy_full = c.hy_splits = c.hy_cps = 0;
-    c.pf_ptr = nullptr; c.xcd_home = 0; c.xcc_of = nullptr; c.tickets_local = nullptr; c.mtiles = c.n_tiles = c.work_blocks = c.pf_first = 0;
+    c.pf_ptr = nullptr; c.xcd_home = 0; c.xcc_of = nullptr; c.err_word = nullptr; c.tickets_local = nullptr; c.mtiles = c.n_tiles = c.work_blocks = c.pf_first = 0;
     c.pf_ntn = c.pf_splits = c.pf_cps = c.pf_nchunks = c.pf_tile_stride = c.pf_chunk_bytes = c.pf_cap = 0;
     c.CoutPad = CoutPad;
     const double Kalg = (double)k * k * Cin;   // algorithmic K (the packing pad is not work)
@@ -642,22 +642,20 @@ size_t Net::workspace_need() const {
     size_t need = 0;
     for (const Op& op : ops_) {
         if (op.type != OP_CONV) continue;
-        for (int b = 1; b <= 2 * max_batch_; ++b) {      // (every batch size under the throughput plan, then under the lone-frame plan)
-            int tile, splits, cps;
-            const bool lone = b > max_batch_;
-            if (lone) b -= max_batch_;
-            choose_launch(op, b, force_tile_, sk_target_, sk_min_chunks_, 64, &tile, &splits, &cps, lone);
-            // worst case over policies that may be set later: allow up to 64 splits at batch 1
-            ConvParams q = op.conv; q.N = b; q.M = b * q.OH * q.OW; q.splits = splits;
-            if (splits > 1) {
-                need = std::max(need, (size_t)splits * conv_tiles(q, tile) * conv_tile_bm(tile) * conv_tile_bn(tile));
-            } else {   // a hybrid grid parks the slices of its last tiles (ConvParams::hy_*)
-                int full = 0, hs = 0, hcps = 0;
-                if (conv_hybrid_plan(q, tile, (size_t)-1, &full, &hs, &hcps))
-                    need = std::max(need, (size_t)hs * (conv_tiles(q, tile) - full) * conv_tile_bm(tile) * conv_tile_bn(tile));
+        for (int lone = 0; lone < 2; ++lone)      // every batch size under the throughput plan, then under the lone-frame plan
+            for (int b = 1; b <= max_batch_; ++b) {
+                int tile, splits, cps;
+                choose_launch(op, b, force_tile_, sk_target_, sk_min_chunks_, 64, &tile, &splits, &cps, lone != 0);
+                // worst case over policies that may be set later: allow up to 64 splits at batch 1
+                ConvParams q = op.conv; q.N = b; q.M = b * q.OH * q.OW; q.splits = splits;
+                if (splits > 1) {
+                    need = std::max(need, (size_t)splits * conv_tiles(q, tile) * conv_tile_bm(tile) * conv_tile_bn(tile));
+                } else {   // a hybrid grid parks the slices of its last tiles (ConvParams::hy_*)
+                    int full = 0, hs = 0, hcps = 0;
+                    if (conv_hybrid_plan(q, tile, (size_t)-1, &full, &hs, &hcps))
+                        need = std::max(need, (size_t)hs * (conv_tiles(q, tile) - full) * conv_tile_bm(tile) * conv_tile_bn(tile));
+                }
             }
-            if (lone) b += max_batch_;
-        }
     }
     return std::max(need, (size_t)4 << 20);   // headroom so a later policy change can still split small layers
 }
@@ -672,8 +670,24 @@ void Net::finalize() {
         if (op.type == OP_CONV)
             tiles = std::max(tiles, (size_t)(((size_t)max_batch_ * op.conv.OH * op.conv.OW + 63) / 64) * (op.conv.CoutPad / 64));
     tickets_count_ = tiles;
-    tickets_ = (int*)arena_.alloc_bytes((2 + 64) * tiles * sizeof(int));      // [agent-scope counters | L2-local counters (xcd_home) | xcc_of]
-    BP_HIP(hipMemset(tickets_, 0, (2 + 64) * tiles * sizeof(int)));
+    tickets_ = (int*)arena_.alloc_bytes(((2 + 64) * tiles + 1) * sizeof(int));      // [agent-scope counters | L2-local counters (xcd_home) | xcc_of | error word]
+    BP_HIP(hipMemset(tickets_, 0, ((2 + 64) * tiles + 1) * sizeof(int)));
+}
+
+// The latency mode's XCD check (conv_dev.h xcd_home_verify): how many launches since the last call found a K slice on the wrong XCD
+// (their tiles were NOT stored: the frame must be run again, without the mode).  Waits for `s`; clears the word.
+int Net::take_xcd_errors(hipStream_t s) {
+    if (!tickets_) return 0;
+    int* w = tickets_ + (2 + 64) * tickets_count_;
+    int v = 0;
+    BP_HIP(hipMemcpyAsync(&v, w, sizeof(int), hipMemcpyDeviceToHost, s));
+    BP_HIP(hipStreamSynchronize(s));
+    if (v) {
+        BP_HIP(hipMemsetAsync(w, 0, sizeof(int), s));
+        BP_HIP(hipMemsetAsync(tickets_ + tickets_count_, 0, tickets_count_ * sizeof(int), s));   // (a skipped reducer re-armed its counter already; belt and braces)
+        BP_HIP(hipStreamSynchronize(s));
+    }
+    return v;
 }
 
 void Net::set_precision(int prec) {
@@ -974,12 +988,22 @@ void Net::prepare_conv(const Op& op, int batch, ConvParams& p, int& tile) {
             p.M = batch * p.OH * p.OW;
             int splits, cps;
             choose_launch(op, batch, force_tile_, sk_target_, sk_min_chunks_, sk_max_splits_, &tile, &splits, &cps, prefetch_);
+            const int planned = splits;
             while (splits > 1 && (size_t)splits * conv_tiles(p, tile) * conv_tile_bm(tile) * conv_tile_bn(tile) > partial_floats_) {
                 conv_split_plan(p, tile, splits - 1, &splits, &cps);
+            }
+            if (splits != planned) {   // (a policy / plan file set after finalize() may ask for more slab space than the workspace holds: say so once)
+                static bool warned = false;
+                if (!warned) {
+                    warned = true;
+                    std::fprintf(stderr, "betapose_hip: %s planned with %d K slices runs with %d (split-K workspace of %zu floats)\n",
+                                 op.name.c_str(), planned, splits, partial_floats_);
+                }
             }
             p.splits = splits; p.chunks_per_split = cps; p.partial = partial_; p.tickets = tickets_;
             p.tickets_local = tickets_ + tickets_count_;
             p.xcc_of = tickets_ + 2 * tickets_count_;
+            p.err_word = tickets_ + (2 + 64) * tickets_count_;
             p.stamps = nullptr;
             if (stamps_) {   // in-situ timing (set_stamps): this conv's region of the stamp buffer, when its grid fits
                 int ord = 0;
@@ -991,7 +1015,7 @@ void Net::prepare_conv(const Op& op, int batch, ConvParams& p, int& tile) {
             // will read them (pf_*; a hint: a wrong guess about the next launch costs bandwidth, not correctness).  One frame
             // at a time: 377 -> 384 -> 395 frames/s (fp16 533 -> 545 -> 558); with four in flight 916 -> 908 -> 895, so it is
             // a mode, not the default (profiles/r03_prefetch_ab.txt)
-            p.xcd_home = (prefetch_ && conv_home_layout(tile, splits)) ? 1 : 0;   // (with four frames in flight it gains nothing even on launches whose tiles divide evenly over the XCDs: 898 against 896)
+            p.xcd_home = (prefetch_ && conv_home_layout(tile, splits)) ? (std::getenv("BP_XCD_FAULT") ? 3 : 1) : 0;   // (3: the tests' fault injection, conv_dev.h xcd_home_mark)   // (with four frames in flight it gains nothing even on launches whose tiles divide evenly over the XCDs: 898 against 896)
             p.pool_out = pool_in_epilogue(op, batch, tile) ? op.pool_out : nullptr;
             p.hy_splits = 0;
             if (splits == 1 && !p.pool_out && conv_hybrid_plan(p, tile, partial_floats_, &p.hy_full, &p.hy_splits, &p.hy_cps)) {

@@ -110,6 +110,7 @@ public:
     // that will read them (bp_common.h ConvParams::xcd_home / pf_*).  Off by default: +4.7 % one frame at a time, -1 .. -2 %
     // with two to four in flight
     void set_prefetch(bool on) { prefetch_ = on; ++plan_version_; }
+    int take_xcd_errors(hipStream_t s);   // non-zero: some launch of the latency mode found a K slice on the wrong XCD and skipped its tile -- run the frame again without the mode
     bool pool_in_epilogue(const Op& conv, int batch, int tile) const;
     bool pooled_by_conv(const Op& pool, int batch) const;
     bool prefetch() const { return prefetch_; }

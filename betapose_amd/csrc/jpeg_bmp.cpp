@@ -235,8 +235,10 @@ struct Decoder {
         const int t = huff_decode(br, hd);
         if (t > 11) throw std::runtime_error("JPEG: corrupt block (DC category)");   // 8-bit baseline: at most 11 bits
         const int diff = t ? extend(br.bits(t), t) : 0;
-        c.dc_pred += diff;
-        blk[0] = (short)(c.dc_pred * q[0]);
+        // (unsigned arithmetic: a corrupt stream can run the predictor up block after block; it then wraps instead of being
+        // signed-overflow UB -- round-4 advisor finding.  Valid streams never leave 16 bits.)
+        c.dc_pred = (int)((unsigned)c.dc_pred + (unsigned)diff);
+        blk[0] = (short)((unsigned)c.dc_pred * (unsigned)q[0]);
         for (int k = 1; k < 64;) {
             const int rs = huff_decode(br, ha);
             const int r = rs >> 4, s = rs & 15;
@@ -247,7 +249,7 @@ struct Decoder {
                 k += r;
                 if (k > 63) throw std::runtime_error("JPEG: corrupt block");
                 const int z = kZigzag[k++];
-                blk[z] = (short)(extend(br.bits(s), s) * q[z]);
+                blk[z] = (short)((unsigned)extend(br.bits(s), s) * (unsigned)q[z]);
             }
         }
     }
@@ -262,8 +264,8 @@ struct Decoder {
             const int t = huff_decode(br, dc[c.td]);
             if (t > 15) throw std::runtime_error("JPEG: corrupt block (DC category)");
             const int diff = t ? extend(br.bits(t), t) : 0;
-            c.dc_pred += diff;
-            d[0] = (short)(c.dc_pred * (1 << al));
+            c.dc_pred = (int)((unsigned)c.dc_pred + (unsigned)diff);
+            d[0] = (short)((unsigned)c.dc_pred << al);
         } else if (br.bits(1)) {
             d[0] = (short)(d[0] + (short)(1 << al));
         }
@@ -294,7 +296,7 @@ struct Decoder {
                 } else {
                     k += r;
                     if (k > 63) throw std::runtime_error("JPEG: corrupt block");
-                    d[kZigzag[k++]] = (short)(extend(br.bits(s), s) * (1 << al));
+                    d[kZigzag[k++]] = (short)((unsigned)extend(br.bits(s), s) << al);
                 }
             } while (k <= se);
             return;

@@ -233,6 +233,7 @@ class DataWriter(_Stage):
         self._pending = 0                 # items handed to save() and not yet fully processed by the writer thread
         self._pending_lock = Lock()
         self._thread = None
+        self.error = None                 # first exception of the writer thread (re-raised by stop() / results())
 
     def start(self):
         self._thread = Thread(target=self.update, daemon=True)
@@ -259,23 +260,33 @@ class DataWriter(_Stage):
                 boxes, scores, hm_data, pt1, pt2, orig_img, im_name = self.Q.get(timeout=0.001)
             except Empty:
                 continue
-            frame_out = None
-            if boxes is not None:
-                result = self._pose_of(boxes, scores, hm_data, pt1, pt2, im_name)
-                self.final_result.append(result)
-                if self.save_video:
-                    from .video import vis_frame
-                    frame_out = vis_frame(orig_img, result)
-            elif self.save_video and orig_img is not None:
-                frame_out = np.asarray(orig_img)
-            if frame_out is not None:
-                self.stream.write(frame_out)
-            with self._pending_lock:
-                self._pending -= 1
+            # the item always leaves the pending count, whatever happens to it: an exception in PnP / NMS / the video stream must
+            # not leave running() true forever with callers spinning on it (round-4 advisor finding); the first one is kept and
+            # re-raised by stop() / results()
+            try:
+                frame_out = None
+                if boxes is not None:
+                    result = self._pose_of(boxes, scores, hm_data, pt1, pt2, im_name)
+                    self.final_result.append(result)
+                    if self.save_video:
+                        from .video import vis_frame
+                        frame_out = vis_frame(orig_img, result)
+                elif self.save_video and orig_img is not None:
+                    frame_out = np.asarray(orig_img)
+                if frame_out is not None:
+                    self.stream.write(frame_out)
+            except Exception as exc:          # noqa: BLE001 -- forwarded to the caller's thread
+                if self.error is None:
+                    self.error = exc
+            finally:
+                with self._pending_lock:
+                    self._pending -= 1
 
     def running(self):
         # the reference only tests Q.empty() (racy: the last item may still be in flight, dataloader.py:743-746)
         time.sleep(0.002)
+        if self._thread is not None and not self._thread.is_alive():
+            return False                      # a dead writer will never drain the queue
         with self._pending_lock:
             return self._pending > 0
 
@@ -290,8 +301,15 @@ class DataWriter(_Stage):
             self._thread.join()                 # the writer finishes the item it holds (PnP, stream.write) before the stream is released
         if self.stream is not None:
             self.stream.release()
+        self._raise_pending_error()
+
+    def _raise_pending_error(self):
+        if self.error is not None:
+            exc, self.error = self.error, None
+            raise exc
 
     def results(self):
+        self._raise_pending_error()
         return self.final_result
 
 

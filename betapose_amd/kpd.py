@@ -175,6 +175,16 @@ class FastPoseHIP:
         """Lone-frame latency mode (include/betapose_hip.h bp_*_set_prefetch), see Darknet.set_prefetch."""
         self._ensure()
         _lib.check(_lib.lib().bp_kpd_set_prefetch(self._h, int(bool(on))))
+        self._latency_mode = bool(on)
+
+    def xcd_errors(self) -> int:
+        """Non-zero when a launch of the latency mode found a K slice on the wrong XCD since the last call (include/betapose_hip.h
+        bp_*_xcd_errors): its tile was not stored, the frame must be run again with the mode off.  Waits for the current stream."""
+        if not getattr(self, "_latency_mode", False) or self._h is None:
+            return 0
+        n = C.c_int(0)
+        _lib.check(_lib.lib().bp_kpd_xcd_errors(self._h, C.byref(n), _lib.current_stream()))
+        return int(n.value)
 
     def set_stamps(self, buf=None, slots: int = 0):
         """In-situ conv timing (include/betapose_hip.h bp_*_set_stamps): ``buf`` a cuda int64 tensor of

@@ -86,7 +86,24 @@ class FramePipeline:
             f = f.unsqueeze(0)
         self.frames.copy_(f, non_blocking=True)
         self.enqueue()
-        return self.results.cpu().numpy()
+        rec = self.results.cpu().numpy()
+        if self._latency_check():        # the latency mode's placement check failed: its results are void -- same frame, ordinary hand-off
+            self.enqueue()
+            rec = self.results.cpu().numpy()
+        return rec
+
+    def _latency_check(self) -> bool:
+        """Lone-frame latency mode only (Darknet.set_prefetch): True when a launch of this frame reported a K slice on the wrong XCD.
+        The mode is then switched off for both engines (the graph is rebuilt on the next enqueue) and stays off."""
+        bad = sum(m.xcd_errors() for m in (self.det, self.pose) if hasattr(m, "xcd_errors"))
+        if not bad:
+            return False
+        import warnings
+        warnings.warn("betapose_amd: block placement is not the round robin the lone-frame latency mode relies on; mode switched off, frame re-run")
+        for m in (self.det, self.pose):
+            if hasattr(m, "set_prefetch"):
+                m.set_prefetch(False)
+        return True
 
 
 class StreamedRunner:

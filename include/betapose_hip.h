@@ -133,12 +133,18 @@ int bp_yolo_profile(bp_yolo* y, int batch, int iters, float* ms, int* info, int 
 int bp_calibrate_ticks(long long ticks, float* ms, void* stream);
 /* lone-frame latency mode (off by default): split-K launches keep all K slices of an output tile on ONE XCD and hand the
  * partial sums over inside that XCD's L2 (checked in every launch against the XCC_ID the hardware reports: a block that is
- * not where the round-robin dispatch puts it aborts the stream instead of reading stale sums), and every convolution launch
+ * not where the round-robin dispatch puts it raises an error word instead of reading stale sums, bp_*_xcd_errors below), and every convolution launch
  * carries blocks that pull the NEXT convolution's filters into the L2 of the XCD that will read them.  +4.7 % frames/s
  * with one frame at a time (fp16 +4.8 %), a loss of 1-2 % with two or more frames in flight (no idle CUs to spare); results
  * are bit-identical either way.  A captured pipeline graph is rebuilt on the next run. */
 int bp_yolo_set_prefetch(bp_yolo* y, int on);
 int bp_kpd_set_prefetch(bp_kpd* k, int on);
+/* the latency mode's placement check: *count != 0 when, since the last call, a split-K launch found a K slice on another XCD
+ * than its reducing block.  Such a launch raises an error word and does NOT store the affected tile (no trap: the context and the
+ * other streams live on), so the frame's results are invalid: switch the mode off (bp_*_set_prefetch(., 0)) and run the frame
+ * again.  Waits for `stream`, clears the word.  Always 0 outside the latency mode. */
+int bp_yolo_xcd_errors(bp_yolo* y, int* count, void* stream);
+int bp_kpd_xcd_errors(bp_kpd* k, int* count, void* stream);
 int bp_yolo_set_stamps(bp_yolo* y, unsigned long long* d_buf, int slots);
 int bp_kpd_set_stamps(bp_kpd* k, unsigned long long* d_buf, int slots);
 int bp_yolo_op_name(const bp_yolo* y, int i, char* out, int cap);

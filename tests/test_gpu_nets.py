@@ -23,6 +23,31 @@ from oracle import kpd_ref, yolo_ref  # noqa: E402
 BOX_TOL, BOX_RTOL, PROB_TOL, HM_TOL = 2e-3, 3e-5, 2e-5, 2e-4
 
 
+def _f16_rows_vs_oracle(p16, frames_idx, what):
+    """The fp16 modes against the ORACLE's rows directly (round-4 verdict item 5; yolo/darknet.py:319-363 restated in oracle/yolo_ref.py),
+    at the mode's stated tolerances: centres 0.25 px, sizes 5e-2 + 2 %, probabilities 5e-3."""
+    blocks = helpers.yolo_blocks()
+    convs = W.split_darknet_stream(blocks, helpers.yolo_stream())
+    for b in frames_idx:
+        ref = yolo_ref.darknet_forward(blocks, convs, helpers.yolo_input_from_frame(helpers.frames(b + 1)[b]))[0]
+        d = (p16[b] - ref).abs()
+        assert float(d[:, :2].max()) < 0.25, (what, b)
+        assert bool((d[:, 2:4] <= 0.05 + 2e-2 * ref[:, 2:4].abs()).all()), (what, b)
+        assert float(d[:, 4:].max()) < 5e-3, (what, b)
+
+
+def _f16_heatmaps_vs_oracle(hm16, inps, idx, what, max_flips):
+    """... and the key-point detector's heat-maps against kpd_ref (KPD/src/models/FastPose.py:13-35 restated): <= 1e-2 absolute at a
+    heat-map scale of ~2, at most ``max_flips`` arg-max pixels (KPD/src/utils/eval.py:113-131) away from the oracle's."""
+    sd = helpers.kpd_state_dict()
+    flips = 0
+    for i in idx:
+        ref = kpd_ref.fastpose_forward(sd, inps[i:i + 1])[0]
+        assert float((hm16[i] - ref).abs().max()) < 1e-2, (what, i)
+        flips += int((hm16[i].reshape(50, -1).argmax(1) != ref.reshape(50, -1).argmax(1)).sum())
+    assert flips <= max_flips, (what, flips)
+
+
 def _box_ok(got, ref):
     got, ref = np.asarray(got), np.asarray(ref)
     return bool((np.abs(got - ref) <= BOX_TOL + BOX_RTOL * np.abs(ref)).all())
@@ -210,6 +235,36 @@ def test_latency_mode_is_bit_identical(yolo, kpd, cuda, pipe_gold):
     assert torch.equal(yolo(xs.to(cuda)).cpu(), base_y)
 
 
+def test_latency_mode_placement_fault_raises_the_error_word_not_a_trap(yolo, kpd, cuda, monkeypatch):
+    """A K slice that reports another XCD than its reducing block (injected: BP_XCD_FAULT, conv_dev.h xcd_home_mark) must NOT
+    kill the context (round 4 trapped): the launch raises the engine's error word and skips the tile, ``xcd_errors()`` reports it
+    once, other work on the device goes on, and ``FramePipeline.run`` switches the mode off and returns the ordinary result."""
+    import warnings
+    from betapose_amd.pipeline import FramePipeline
+    frame = helpers.frames(1)[0]
+    pipe = FramePipeline(yolo, kpd, 480, 640, batch=1, use_graph=False)
+    base = pipe.run(frame).copy()
+    try:
+        monkeypatch.setenv("BP_XCD_FAULT", "1")
+        yolo.set_prefetch(True)
+        kpd.set_prefetch(True)
+        x = helpers.yolo_input_from_frame(frame)
+        yolo(x.to(cuda))
+        assert yolo.xcd_errors() != 0 and yolo.xcd_errors() == 0          # reported, then cleared
+        assert float(torch.ones(8, device=cuda).sum()) == 8.0              # the context is alive
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            rec = pipe.run(frame)
+        assert any("latency mode" in str(m.message) for m in w)
+        assert np.array_equal(rec, base)
+        assert not yolo._latency_mode and not kpd._latency_mode
+    finally:
+        monkeypatch.delenv("BP_XCD_FAULT", raising=False)
+        yolo.set_prefetch(False)
+        kpd.set_prefetch(False)
+    assert np.array_equal(pipe.run(frame), base)
+
+
 # ---- fp16-MFMA mode (BASELINE configs[2]: batched inference, 28 crops / batch, fp16 MFMA conv path).  Operands of
 # every conv with Cin % 32 == 0 are rounded to fp16, accumulation and activations stay fp32.  Stated tolerances against
 # the fp32 oracle: heat-maps <= 1e-2 absolute (measured 1.4e-3 at a heat-map scale of 2.3), box centres <= 0.25 px,
@@ -255,6 +310,7 @@ def test_f16_modes_yolo_batch28(cuda, pipe_gold):
         assert same >= 27, (mode, same)                                  # (a frame whose two best boxes are closer than the fp16 rounding may swap)
         for b in range(2):
             assert int(p16[b, :, 4].argmax()) == int(pipe_gold["f%d_obj_argmax" % b])
+        _f16_rows_vs_oracle(p16, (0, 27), mode)
         one = torch.cat([net(x[i:i + 1].to(cuda)).cpu() for i in (0, 13, 27)])
         d1 = (one - p16[[0, 13, 27]]).abs()
         assert float(d1[..., :2].max()) < 0.25 and float(d1[..., 4:].max()) < 5e-3, mode
@@ -338,6 +394,8 @@ def test_f16r_mode_fp16_skip_connections(cuda, pipe_gold):
     assert int((a != a32).sum()) <= 8                                     # <= 2 % of 400 key points
     gold = np.stack([pipe_gold["f%d_kp_idx" % i] for i in range(4)])
     assert int((a[:4].numpy() != gold).sum()) <= 4
+    _f16_rows_vs_oracle(p16r, (0, 1), "f16r")
+    _f16_heatmaps_vs_oracle(hm, inps, (0, 5), "f16r", 2)
     # test taps of tensors that now exist as fp16 planes only are rebuilt from the plane (fp16-rounded values of the fp16-mode run)
     for i, (name, *_) in enumerate(kpd.taps()[:6]):
         t = kpd.tap(i, batch=8).cpu()
@@ -393,6 +451,7 @@ def test_f16_mode_kpd_batch28(cuda, pipe_gold):
     gold = np.stack([pipe_gold["f%d_kp_idx" % i] for i in range(4)])
     assert np.array_equal(a32[:4].numpy(), gold)
     assert int((a16[:4].numpy() != gold).sum()) <= 4                     # <= 2 % of the 200 golden key points
+    _f16_heatmaps_vs_oracle(hm16, inps, (0, 27), "f16 batch 28", 2)
 
 
 # ---- bf16x3 mode: fp32 operands split exactly into three bf16 terms, six partial products on the bf16 MFMA, fp32

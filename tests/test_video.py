@@ -103,6 +103,23 @@ def test_vis_frame_and_data_writer_video(tmp_path):
     assert video.FrameSource(str(tmp_path / "o" / "1.avi")).frame_count == 1
 
 
+def test_data_writer_survives_a_failing_item():
+    """An item that makes the writer thread raise (here: a box with no heat-maps) must still leave the pending count, so that
+    ``while writer.running()`` ends, and the exception reaches the caller through stop() (round-4 advisor finding)."""
+    import time
+    import pytest
+    from betapose_amd.dataloader import DataWriter
+    dw = DataWriter(synth.CAM_K, 50, synth.synth_kp3d(50)).start()
+    dw.save(np.zeros((1, 4), np.float32), np.ones((1, 1), np.float32), None, None, None, None, "bad.png")
+    dw.save(None, None, None, None, None, None, "empty.png")          # a frame without detections behind it is still drained
+    t0 = time.time()
+    while dw.running():
+        assert time.time() - t0 < 20, "running() never turned false after the writer raised"
+    with pytest.raises(Exception):
+        dw.stop()
+    assert dw.results() == []
+
+
 def test_prep_frame_equals_the_reference_on_its_golden_frames(golden_dir):
     """``letterbox_image`` / ``prep_frame`` against vectors produced by the reference's OWN functions (yolo/preprocess.py:
     18-60, tools/make_golden_video.py) with the stated bicubic stand-in for its one ``cv2.resize`` call: canvas size and

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of plan files on the configs[2] shape (28 frames per launch x 3 streams): tools/_ab28.sh reps precision plan1 plan2 ... ("none" = built-in)
+# A/B of plan files on the configs[2] shape (28 frames per launch x 3 streams): tools/ab28.sh reps precision plan1 plan2 ... ("none" = built-in)
 reps=$1; prec=$2; shift; shift
 B="python bench.py --batch 28 --streams 3 --precision $prec --no-cpu-baseline --no-served-legs --no-flip-rate --no-side-runs --no-roofline --other-modes= --steps 60 --warmup 10 --repeats 3"
 for rep in $(seq $reps); do

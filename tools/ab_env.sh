@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of an environment switch in the whole pipeline: tools/_ab_env.sh reps VAR   (alternates VAR unset / VAR=1)
+# A/B of an environment switch in the whole pipeline: tools/ab_env.sh reps VAR   (alternates VAR unset / VAR=1)
 reps=$1; var=$2
 B="python bench.py --no-cpu-baseline --no-served-legs --no-flip-rate --no-side-runs --no-roofline --other-modes= --steps 200 --warmup 60 --repeats 3"
 for rep in $(seq $reps); do

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of plan files in the whole pipeline (4 frames in flight), alternating: tools/_ab_plans.sh reps plan1 plan2 ...  ("none" = built-in plan)
+# A/B of plan files in the whole pipeline (4 frames in flight), alternating: tools/ab_plans.sh reps plan1 plan2 ...  ("none" = built-in plan)
 reps=$1; shift
 B="python bench.py --no-cpu-baseline --no-served-legs --no-flip-rate --no-side-runs --no-roofline --other-modes= --steps 200 --warmup 60 --repeats 3"
 for rep in $(seq $reps); do
