@@ -314,15 +314,21 @@ def roofline(det, pose, batch):
         ms, info = net.profile(batch=batch, iters=10)
         flops, _bytes = net.op_stats()
         total_ms += float(ms.sum())
+        carry_f = carry_b = 0.0          # FLOPs / bytes of convolutions computed inside the NEXT launch (members of a fused block: tile -1)
         for i in range(len(ms)):
             if not info[i, 0]:
+                continue
+            if int(info[i, 1]) == -1:
+                carry_f += float(flops[i]) * batch
+                carry_b += float(_bytes[i])
                 continue
             key = (int(info[i, 1]), int(info[i, 2]))
             g = groups.setdefault(key, {"ms": 0.0, "flops": 0.0, "launches": 0, "bytes": 0.0})
             g["ms"] += float(ms[i])
-            g["flops"] += float(flops[i]) * batch
-            g["bytes"] += float(_bytes[i])
+            g["flops"] += float(flops[i]) * batch + carry_f
+            g["bytes"] += float(_bytes[i]) + carry_b
             g["launches"] += 1
+            carry_f = carry_b = 0.0
     key = max(groups, key=lambda k: groups[k]["ms"])
     g = groups[key]
     conv_ms = sum(v["ms"] for v in groups.values())
@@ -346,6 +352,8 @@ def roofline(det, pose, batch):
             return "bp::conv_halo_kernel<%d, *>" % (2 if tile == 21 else 4)   # tap-resident halo (conv_halo.hip); * = loader passes, by map width
         if tile == 23:
             return "bp::conv_halo_k2_kernel<*>"                            # ... with two K groups inside the block
+        if tile == 40:
+            return "bp::conv_fused_kernel<*>"                              # whole residual / bottleneck block in one launch (conv_fused.hip)
         if tile == 24:
             return "bp::conv_igemm_bdk2_kernel"                            # filters direct, two K groups inside an eight-wave block
         if tile in (7, 8, 9):
@@ -422,14 +430,22 @@ def layer_classes(det, pose, batch, peak_mode):
     for net in (det, pose):
         ms, info = net.profile(batch=batch, iters=10)
         flops, byts = net.op_stats()
+        carry_g = carry_m = 0.0
         for i, (nm, is_conv) in enumerate(net.op_names()):
-            c = cls.setdefault(op_class(nm, is_conv), {"launches": 0, "ms": 0.0, "gflop": 0.0, "MB": 0.0})
-            if int(info[i][1]) == -1:       # launches nothing: the op rides in its producer's epilogue (SE average pools)
+            fused_head = is_conv and int(info[i][1]) == 40
+            c = cls.setdefault("fused blocks (1x1 -> 3x3 [-> 1x1] + skip, one launch)" if fused_head else op_class(nm, is_conv),
+                               {"launches": 0, "ms": 0.0, "gflop": 0.0, "MB": 0.0})
+            if int(info[i][1]) == -1:       # launches nothing: the op rides in its producer's epilogue (SE average pools) or inside the next launch (fused blocks)
+                if is_conv:
+                    carry_g += float(flops[i]) * batch / 1e9
+                    carry_m += float(byts[i]) / 1e6
                 continue
             c["launches"] += 1
             c["ms"] += float(ms[i])
-            c["gflop"] += float(flops[i]) * batch / 1e9
-            c["MB"] += float(byts[i]) / 1e6
+            c["gflop"] += float(flops[i]) * batch / 1e9 + (carry_g if is_conv else 0.0)
+            c["MB"] += float(byts[i]) / 1e6 + (carry_m if is_conv else 0.0)
+            if is_conv:
+                carry_g = carry_m = 0.0
     out = {}
     for k, c in sorted(cls.items(), key=lambda kv: -kv[1]["ms"]):
         pk = PEAK_FP32_MFMA_TFLOPS if k.startswith("stems") else peak_mode
@@ -750,8 +766,10 @@ def main():
     torch.cuda.synchronize()
     lat["on"] = True
     t0 = time.perf_counter()
+    cpu0 = time.process_time()
     run(a.steps, True)
     t_own = time.perf_counter() - t0
+    cpu_own = time.process_time() - cpu0      # host CPU seconds of this rank (all its threads) inside the timed region
     lat["on"] = False
     # xGMI gather of detections only: steps*batch records of 316 floats per rank, in global frame order on rank 0
     flat = records.reshape(-1, records.shape[-1])
@@ -762,6 +780,7 @@ def main():
     el = bpd.max_over_ranks(time.perf_counter() - t0)
     lat_flight = np.array(lat["ms"]) if lat["ms"] else np.zeros(1)
     rank_fps = bpd.gather_floats(a.steps * a.batch / t_own)
+    rank_cpu_ms = bpd.gather_floats(cpu_own / (a.steps * a.batch) * 1e3)
 
     # ---- more K-step regions, back to back, each bracketed like the first (barrier + synchronize both sides, max over
     # ranks): a single 20-step region is a 20 ms window
@@ -879,6 +898,7 @@ def main():
                         "max": round(max(region_fps), 2), "frames_run_before_each": frames_before,
                         "note": "`value` is region 0 (right behind the commanded warm-up); `value_settled` = p50 of the regions that started after >= 60 frames"},
             "detections": stats["det"], "poses": stats["pose"],
+            "host_cpu_ms_per_frame": round(rank_cpu_ms[0], 3),
             "records_gathered": int((gathered[:, 0].view(np.int32) >= -1).sum()) if gathered is not None else 0,
         }
         assert gathered.shape == (frames_total, records.shape[-1])
@@ -892,6 +912,8 @@ def main():
             import torch.distributed as tdist
             out["rccl"] = {"backend": tdist.get_backend(), "ranks": world, "weight_broadcast_ms": round(t_bc, 1),
                            "per_rank_frames_per_sec": [round(v, 2) for v in rank_fps],
+                           "per_rank_host_cpu_ms_per_frame": [round(v, 3) for v in rank_cpu_ms],
+                           "host_cores": os.cpu_count(),
                            "collectives": "broadcast of 2 fp32 weight streams (246 + 239 MB) at start-up, all_gather of "
                                           "316-float records, barriers around the timed region"}
     if rank == 0 and not a.no_roofline:

@@ -55,6 +55,10 @@ PROTOTYPES = {
     "bp_calibrate_ticks": (C.c_int, [C.c_longlong, c_float_p, vp]),
     "bp_yolo_set_prefetch": (C.c_int, [vp, C.c_int]),
     "bp_kpd_set_prefetch": (C.c_int, [vp, C.c_int]),
+    "bp_yolo_set_fusion": (C.c_int, [vp, C.c_int]),
+    "bp_kpd_set_fusion": (C.c_int, [vp, C.c_int]),
+    "bp_yolo_fused_launches": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int)]),
+    "bp_kpd_fused_launches": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int)]),
     "bp_yolo_xcd_errors": (C.c_int, [vp, C.POINTER(C.c_int), vp]),
     "bp_kpd_xcd_errors": (C.c_int, [vp, C.POINTER(C.c_int), vp]),
     "bp_yolo_set_stamps": (C.c_int, [vp, vp, C.c_int]),

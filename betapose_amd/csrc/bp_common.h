@@ -171,7 +171,8 @@ enum ConvTile : int { TILE_64x64 = 0, TILE_128x64 = 1, TILE_W64_1x1 = 2, TILE_W6
                       TILE_HALO64K2 = 23,   // 64x64 block, 4 waves = 2 K groups x 2 column halves: the K split inside the block (no slabs)
                       TILE_BD_K2 = 24,      // the filters-direct 64x64 tile with 8 waves = 2 K groups of 2x2 waves (conv_igemm.hip, any kernel size / stride)
                       TILE_PLH128 = 25,     // conv_pl.hip 128x128 with the activations of a 3x3 / stride-1 layer from an LDS-resident halo (fp16; round 4)
-                      TILE_LAST = 25 };
+                      TILE_LAST = 25,       // (the last id a policy may force)
+                      TILE_FUSED = 40 };    // reporting only (Net::profile): the op is the last member of a block fused into one launch (conv_fused.hip)
 
 // when non-null, launch_conv brackets the implicit-GEMM kernel itself (not the split-K reduce) with these events
 struct ConvProfHook { hipEvent_t e0, e1; };
@@ -205,6 +206,11 @@ void launch_f32_to_planes(const float* in, int ld, long long pixels, int C, unsi
 // ... and back (test taps of tensors whose fp32 store was dropped): exact for np == 3
 void launch_planes_to_f32(const unsigned short* planes, long long plane_elems, int np, float* out, int ld, long long pixels, int C,
                           hipStream_t s);
+// conv_fused.hip (round 5): [1x1] -> [3x3 / stride 1] (-> [1x1]) + skip connection of one residual / bottleneck block in ONE launch on
+// 8 x 8 output patches (bf16x3, fp32 activations); `post` may be null
+bool conv_fused_eligible(const ConvParams& pre, const ConvParams& c3, const ConvParams* post);
+int conv_fused_blocks(const ConvParams& pre, const ConvParams& c3, const ConvParams* post);
+void launch_conv_fused(const ConvParams& pre, const ConvParams& c3, const ConvParams* post, hipStream_t s);
 int conv_tiles(const ConvParams& p, int tile);   // blocks per K-slice
 bool conv_stem3_eligible(const ConvParams& p);   // conv_igemm.hip: the layer can run on TILE_STEM3
 void conv_grid_setup(ConvParams& q, int bm, int bn);   // fills mtiles / n_tiles / work_blocks / pf_first from M, CoutPad, splits, xcd_home

@@ -214,6 +214,7 @@ int bp_yolo_clone(const bp_yolo* y, bp_yolo** out) {
     c->device = y->device;
     c->net.reset(y->net->clone());
     if (y->net->precision() != bp::PREC_F32) c->net->set_precision(y->net->precision_id());
+    c->net->set_fusion(y->net->fusion());
     *out = c.release();
     return 0;
     BP_CATCH
@@ -288,6 +289,7 @@ int bp_kpd_clone(const bp_kpd* k, bp_kpd** out) {
     c->device = k->device;
     c->net.reset(k->net->clone());
     if (k->net->precision() != bp::PREC_F32) c->net->set_precision(k->net->precision_id());
+    c->net->set_fusion(k->net->fusion());
     *out = c.release();
     return 0;
     BP_CATCH
@@ -396,6 +398,25 @@ int bp_calibrate_ticks(long long ticks, float* ms, void* stream) {
 }
 int bp_yolo_set_prefetch(bp_yolo* y, int on) { y->net->set_prefetch(on != 0); return 0; }
 int bp_kpd_set_prefetch(bp_kpd* k, int on) { k->net->set_prefetch(on != 0); return 0; }
+// conv -> conv fusion of residual / bottleneck blocks (conv_fused.hip): on by default; *launches = groups that run as ONE launch at `batch`
+int bp_yolo_set_fusion(bp_yolo* y, int on) { y->net->set_fusion(on != 0); return 0; }
+int bp_kpd_set_fusion(bp_kpd* k, int on) { k->net->set_fusion(on != 0); return 0; }
+int bp_yolo_fused_launches(bp_yolo* y, int batch, int* launches) {
+    BP_TRY
+    BP_CHECK(y && launches && batch >= 1 && batch <= y->net->max_batch(), "arguments");
+    BP_HIP(hipSetDevice(y->device));
+    *launches = y->net->fused_launches(batch);
+    return 0;
+    BP_CATCH
+}
+int bp_kpd_fused_launches(bp_kpd* k, int batch, int* launches) {
+    BP_TRY
+    BP_CHECK(k && launches && batch >= 1 && batch <= k->net->max_batch(), "arguments");
+    BP_HIP(hipSetDevice(k->device));
+    *launches = k->net->fused_launches(batch);
+    return 0;
+    BP_CATCH
+}
 int bp_yolo_xcd_errors(bp_yolo* y, int* count, void* stream) {
     BP_TRY
     BP_CHECK(y && count, "null argument");

@@ -97,11 +97,16 @@ __device__ __forceinline__ void xcd_home_mark(const P& p, int tile_id, int split
 // stores nothing for the tile -- no trap (round 4 killed the whole HIP context, every stream of the process, on a mismatch): the host
 // reads the word behind the frame (Net::take_xcd_errors; FramePipeline.run), switches the latency mode off and runs the frame again on
 // the ordinary hand-off.  Returns false on a mismatch (block-uniform).
+// `flag`: the block's "I am the last slice" word in LDS (holds 1 here) -- reused for the block-wide verdict, because a reduction builtin
+// (__syncthreads_or) brings its own static LDS scratch into EVERY kernel that includes the tail, and the halo kernels' dynamic LDS
+// opt-in of 160 KB - 64 B then exceeds the CU's 160 KB (hipFuncSetAttribute: invalid argument; found on the first GPU run of round 5)
 template <class P>
-__device__ __forceinline__ bool xcd_home_verify(const P& p, int tile_id) {
+__device__ __forceinline__ bool xcd_home_verify(const P& p, int tile_id, int* flag) {
     const bool bad = (int)threadIdx.x < p.splits &&
         __hip_atomic_load(&p.xcc_of[tile_id * 64 + (int)threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != xcc_id();
-    const bool any_bad = __syncthreads_or(bad ? 1 : 0) != 0;
+    if (bad) *flag = 3;                 // (every offender stores the same value)
+    __syncthreads();
+    const bool any_bad = *flag != 1;
     if (any_bad && threadIdx.x == 0 && p.err_word) __hip_atomic_fetch_or(p.err_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return !any_bad;
 }
@@ -306,11 +311,25 @@ struct PixShufRows {
 // switches once per block): RES 0 none, 1 add before the activation (ResNet), 2 add after it (YOLO shortcut).
 // Output and residual go through raw buffer descriptors whose range ends at row M, so rows past the tensor are dropped
 // by the hardware -- no per-pass branch.
+// SE channel scale of the residual (ConvParams::res_scale [N][Cout], the SE blocks' "downsample" convolutions: out = act(conv + T * y),
+// SE_Resnet.py:31-40 with SELayer): four channels of the row's IMAGE -- rows of a tile may belong to different images of a batch.  Until
+// round 5 these four layers took the element-wise epilogue: 168 / 92 / 60 / 73 us at batch 28 (fp16) where their sister 1x1 layers take
+// 63 / 35 / 23 / 17, and 18.5 us against 8.7 at batch 1.
+struct ResScaleRows {
+    const float* rs;          // res_scale + the thread's first channel
+    int m_first, m_step, hw, Cout, m_last;
+    float rcp_hw;
+    __device__ __forceinline__ f32x4 at(int pass) const {
+        const int m = min(m_first + pass * m_step, m_last);      // (rows past M read the last image's scale; their store is dropped)
+        return *reinterpret_cast<const f32x4*>(rs + fast_div(m, hw, rcp_hw) * Cout);
+    }
+};
+
 template <int ACT, int RES, int PASSES, int PF>
 __device__ __forceinline__ void epilogue_rows(const float* srow, int s_step, f32x4 bias4,
                                               __amdgpu_buffer_rsrc_t rsrcO, unsigned off_o, unsigned step_o,
                                               __amdgpu_buffer_rsrc_t rsrcR, unsigned off_r, unsigned step_r, const f32x4* rpre,
-                                              const PlaneDesc& pd, bool r16 = false, const PixShufRows* ps = nullptr) {
+                                              const PlaneDesc& pd, bool r16 = false, const PixShufRows* ps = nullptr, const ResScaleRows* rsc = nullptr) {
     // ps (PixelShuffle stores, conv_tail.inc): the output byte offset of a pass comes from its row's pixel instead of off_o + pass * step_o
     // PF: the residual rows were requested before the tile was staged (rpre[pass], registers): a cold 16-B load costs the
     // block > 1 us at the very end of the kernel otherwise
@@ -321,6 +340,7 @@ __device__ __forceinline__ void epilogue_rows(const float* srow, int s_step, f32
         if constexpr (RES != 0) {
             if constexpr (PF) r4 = rpre[pass];
             else r4 = load_res4(rsrcR, off_r, r16);
+            if (rsc) r4 *= rsc->at(pass);
         }
         v += bias4;
         if constexpr (RES == 1) v += r4;

@@ -285,7 +285,9 @@ __device__ __forceinline__ void conv_igemm_body(const P& p, const int bp_bid, fl
 #define BP_NT 256
 #define BP_SLAST (*s_last_p)
 #define BP_TAIL_STAMP(k_) BP_STAMP(k_)
+#define BP_EP_RES_SCALE true
 #include "conv_tail.inc"
+#undef BP_EP_RES_SCALE
 #undef BP_TAIL_STAMP
 #undef BP_NT
 #undef BP_SLAST
@@ -628,7 +630,9 @@ __device__ __forceinline__ void conv_igemm_h_body(const P& p, const int bp_bid, 
 #define BP_EARLY_BIAS bias_early
 #define BP_HAS_ACC kg_has_acc
 #define BP_TAIL_STAMP(k_) BH_STAMP(k_)
+#define BP_EP_RES_SCALE (KG == 1)      /* the four-wave tile runs the SE blocks' downsample layers; the K2 form keeps its 126 registers */
 #include "conv_tail.inc"
+#undef BP_EP_RES_SCALE
 #undef BP_HAS_ACC
 #undef BP_EARLY_BIAS
 #undef BP_TAIL_STAMP

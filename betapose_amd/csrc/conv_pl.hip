@@ -83,7 +83,7 @@ __global__ __launch_bounds__(64 * (WM * WN * KG + LW)) void conv_pl_kernel(const
     constexpr int HALO_BYTES = HALO ? (HRT + 1) * 64 : 0;                 // one halo buffer: HRT rows + the zero row
     constexpr int CHUNK = NP * (A_PLANE + B_PLANE);
     constexpr int STAGE = CPS * CHUNK;
-    constexpr int EP_SLABS_ = BM > 128 ? BM / 64 : 1;       // epilogue staging in 64-row slabs on the big tiles (conv_tail.inc)
+    constexpr int EP_SLABS_ = BM > 128 ? BM / (32 * TM > 64 ? 32 * TM : 64) : 1;       // epilogue staging in slabs of 64 rows (or one wave's rows) on the big tiles (conv_tail.inc)
     constexpr int EPI_BYTES = (BM / EP_SLABS_) * LDT * 4;
     constexpr int RING = NST * STAGE;
     constexpr int KGSUM_BYTES = (KG - 1) * NWC * TM * TN * 4096;      // the other groups' accumulators, fragment order
@@ -587,7 +587,11 @@ __global__ __launch_bounds__(64 * (WM * WN * KG + LW)) void conv_pl_kernel(const
 #define BP_SPLITS my_splits
 #define BP_SLAB_TILE (p.hy_splits > 0 ? tile_id - p.hy_full : tile_id)
 #define BP_SLAB_TILES (p.hy_splits > 0 ? p.n_tiles - p.hy_full : (p.n_tiles ? p.n_tiles : (int)gridDim.x / p.splits))
+#define BP_EP_RES_SCALE true           /* the SE blocks' downsample layers in the fp16 modes */
+#define BP_EP_PIXSHUF                  /* the DUC layers' PixelShuffle stores through the staged epilogue (round 5: they ran 229 us each at batch 28 on the element-wise path) */
 #include "conv_tail.inc"
+#undef BP_EP_PIXSHUF
+#undef BP_EP_RES_SCALE
 #undef BP_SPLITS
 #undef BP_SLAB_TILE
 #undef BP_SLAB_TILES
@@ -606,7 +610,7 @@ bool conv_tile_is_pl(int tile) {
 #ifdef BP_EXPERIMENTAL
     if (tile == TILE_PL128S || tile == TILE_PL64K2 || tile == TILE_PL64BD) return true;
 #endif
-    return tile == TILE_PL64 || tile == TILE_PL128 || tile == TILE_PL128x64 || tile == TILE_PL256x128 || tile == TILE_PLH128;
+    return tile == TILE_PL64 || tile == TILE_PL128 || tile == TILE_PL128x64 || tile == TILE_PL256x128 || conv_tile_is_plh(tile);
 }
 
 bool conv_plh_eligible(const ConvParams& p) {
@@ -651,6 +655,10 @@ static void launch_pl_np(const ConvParams& p, int tile, hipStream_t s) {
                 else launch_pl_t<1, 2, 2, 2, 2, 4, 1, 0, 1, false, 256>(p, s);
             } else throw Error("the halo plane tile is an fp16 tile");
             break;
+        // (round 5: the halo form with 128 x 64 outputs per wave -- 2x2 waves on a 256x128 block, <1, 2, 2, 4, 2, 4 | 3, 1, 0, 1, false, 320 | 384>,
+        // an A / B fragment pair feeding 8 MFMAs instead of 4 -- was built on this template, parity-green, and is SLOWER: 204 VGPRs + 128
+        // accumulator registers leave one wave per SIMD, 97.7 / 93.8 / 77.1 us against 66.6 / 63.4 / 66.6 us for the 52x52 / 26x26 / 13x13
+        // layers at batch 28, profiles/r05_plh_kernels.txt; removed)
 #ifdef BP_EXPERIMENTAL   // two round-3 forms that are parity-green and bring nothing:
         // planes for the activations + filter fragments direct from global memory (BDIR): 4 blocks per CU and no in-kernel
         // operand split, but both waves of a column pair pull the same fragments through the vector-memory path -- alone

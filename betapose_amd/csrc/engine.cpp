@@ -37,6 +37,7 @@ Tensor Net::new_tensor(int H, int W, int C) {
 }
 
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+static int env_int_early(const char* name, int dflt) { const char* v = std::getenv(name); return v ? std::atoi(v) : dflt; }
 
 float* Net::upload_weights(const float* host, size_t count) {
     if (reuse_) {
@@ -388,6 +389,8 @@ static const PlanEntry kPlanPL1[] = {
     // 7-10 % faster alone than the best all-DMA tile, +1.7-2.6 % on configs[2]).  A row is taken only by layers the tile can run
     // (choose_pl checks conv_plh_eligible): the stride-2 layers that share a row's key fall through to the row below it
     {   4732,  1024,  144, TILE_PLH128,  1},
+    {   8960,  1024,  144, TILE_PLH128,  1},   // DUC1 / DUC2 (round 5: their PixelShuffle stores take the staged epilogue in conv_pl.hip too)
+    {  35840,   512,   72, TILE_PLH128,  1},
     {   8960,   256,   72, TILE_PLH128,  1},
     {  18928,   512,   72, TILE_PLH128,  1},
     {  35840,   128,   36, TILE_PLH128,  1},
@@ -660,7 +663,88 @@ size_t Net::workspace_need() const {
     return std::max(need, (size_t)4 << 20);   // headroom so a later policy change can still split small layers
 }
 
+// ---- conv -> conv fusion (conv_fused.hip).  Structure first: op j is a 3x3 / stride-1 convolution whose input tensor is produced by a
+// 1x1 convolution i and read by nobody else; optionally its own output is read only by a 1x1 convolution k.  (yolo/darknet.py:319-363:
+// the 1x1 / 3x3 pair of a Darknet-53 residual block; SE_Resnet.py:25-42: conv1 / conv2 / conv3 of a bottleneck.)
+void Net::find_fuse_groups() {
+    fuse_groups_.clear();
+    auto readers = [&](const float* t) {
+        int n = 0;
+        for (const Op& o : ops_) {
+            if (o.type == OP_CONV) n += (o.conv.in == t) + (o.conv.res == t);
+            else n += (o.a == t) + (o.b == t);
+        }
+        return n;
+    };
+    auto producer = [&](const float* t, int ld) {
+        int idx = -1, n = 0;
+        for (int i = 0; i < (int)ops_.size(); ++i) {
+            const Op& o = ops_[i];
+            if (o.type == OP_CONV ? (o.conv.out == t && o.conv.out_ld == ld) : o.out == t) { idx = i; ++n; }
+        }
+        return n == 1 ? idx : -1;
+    };
+    for (int j = 0; j < (int)ops_.size(); ++j) {
+        const Op& c3 = ops_[j];
+        if (c3.type != OP_CONV || c3.conv.ksize != 3 || c3.conv.stride != 1 || c3.conv.pad != 1) continue;
+        const int i = producer(c3.conv.in, c3.conv.in_ld);
+        if (i < 0 || i >= j || ops_[i].type != OP_CONV) continue;
+        const ConvParams& pre = ops_[i].conv;
+        if (!(pre.ksize == 1 && pre.stride == 1 && pre.res == nullptr && pre.res_scale == nullptr && pre.store_mode == ST_NHWC && pre.Cout == c3.conv.Cin)) continue;
+        if (readers(pre.out) != 1 || ops_[i].pool_out) continue;
+        if (i != j - 1) continue;                // (the members are consecutive launches in both networks: nothing runs between them)
+        FuseGroup g{i, j, -1};
+        if (j + 1 < (int)ops_.size() && ops_[j + 1].type == OP_CONV) {
+            const ConvParams& post = ops_[j + 1].conv;
+            if (post.in == c3.conv.out && post.in_ld == c3.conv.out_ld && post.ksize == 1 && post.stride == 1 && c3.conv.res == nullptr &&
+                c3.conv.store_mode == ST_NHWC && readers(c3.conv.out) == 1 && !ops_[j].pool_out)
+                g.post = j + 1;
+        }
+        fuse_groups_.push_back(g);
+    }
+}
+
+// Which groups run fused under the current plan at this batch size: bf16x3 on the fp32-activation path, every member eligible for the
+// fused kernel, enough patches to be worth a launch of their own.  A three-member group whose last 1x1 cannot join (the SE blocks'
+// conv3 carries the average pool in its epilogue) falls back to its first two members.
+void Net::plan_roles(int batch) {
+    if (roles_batch_ == batch && roles_version_ == plan_version_) return;
+    roles_.assign(ops_.size(), FR_NONE);
+    role_group_.assign(ops_.size(), -1);
+    roles_batch_ = batch; roles_version_ = plan_version_;
+    static const bool env_off = std::getenv("BP_NO_FUSION") != nullptr;
+    static const int min_blocks = env_int_early("BP_FUSE_MIN_BLOCKS", 48);
+    if (!fusion_ || env_off || precision_ != PREC_BF16X3 || force_tile_ >= 0) return;
+    for (int gi = 0; gi < (int)fuse_groups_.size(); ++gi) {
+        const FuseGroup& g = fuse_groups_[gi];
+        ConvParams a, b, c;
+        int ta, tb, tc;
+        prepare_conv(ops_[g.pre], batch, a, ta);
+        prepare_conv(ops_[g.c3], batch, b, tb);
+        bool three = g.post >= 0;
+        if (three) {
+            prepare_conv(ops_[g.post], batch, c, tc);
+            three = conv_fused_eligible(a, b, &c) && conv_fused_blocks(a, b, &c) >= min_blocks;
+        }
+        if (three) {
+            roles_[g.pre] = roles_[g.c3] = FR_SKIP; roles_[g.post] = FR_HEAD3;
+            role_group_[g.pre] = role_group_[g.c3] = role_group_[g.post] = gi;
+        } else if (conv_fused_eligible(a, b, nullptr) && conv_fused_blocks(a, b, nullptr) >= min_blocks) {
+            roles_[g.pre] = FR_SKIP; roles_[g.c3] = FR_HEAD2;
+            role_group_[g.pre] = role_group_[g.c3] = gi;
+        }
+    }
+}
+
+int Net::fused_launches(int batch) {
+    plan_roles(batch);
+    int n = 0;
+    for (int r : roles_) n += r == FR_HEAD2 || r == FR_HEAD3;
+    return n;
+}
+
 void Net::finalize() {
+    find_fuse_groups();
     (void)xcc_base();   // the one-time dispatch probe runs here (it allocates and copies: not inside a stream capture)
     partial_floats_ = workspace_need();
     partial_ = arena_.alloc(partial_floats_);
@@ -1054,6 +1138,26 @@ void Net::emit_conv_ops(int batch, std::vector<MegaOp>& out) {
 #endif
 
 void Net::run_op(const Op& op, int batch, hipStream_t s) {
+    if (op.type == OP_CONV) {
+        plan_roles(batch);
+        const int idx = (int)(&op - ops_.data());
+        const int role = roles_[idx];
+        if (role == FR_SKIP) return;                       // computed inside the group's one launch (at its last member)
+        if (role == FR_HEAD2 || role == FR_HEAD3) {
+            const FuseGroup& g = fuse_groups_[role_group_[idx]];
+            ConvParams a, b, c;
+            int ta, tb, tc;
+            prepare_conv(ops_[g.pre], batch, a, ta);
+            prepare_conv(ops_[g.c3], batch, b, tb);
+            if (role == FR_HEAD3) prepare_conv(ops_[g.post], batch, c, tc);
+            launch_conv_fused(a, b, role == FR_HEAD3 ? &c : nullptr, s);
+            return;
+        }
+    }
+    run_op_unfused(op, batch, s);
+}
+
+void Net::run_op_unfused(const Op& op, int batch, hipStream_t s) {
     switch (op.type) {
         case OP_CONV: {
             ConvParams p;
@@ -1112,7 +1216,8 @@ int Net::profile(int batch, int iters, float* ms, int* info, int cap, hipStream_
     run_ops(batch, s);   // warm
     for (int it = 0; it < iters; ++it) {
         for (int i = 0; i < n; ++i) {
-            if (ops_[i].type == OP_CONV) {
+            plan_roles(batch);
+            if (ops_[i].type == OP_CONV && roles_[i] != FR_SKIP) {      // (a member computed inside its block's one launch launches nothing: empty bracket)
                 ConvProfHook hook{ev[2 * i], ev[2 * i + 1]};
                 g_conv_prof = &hook;
                 try { run_op(ops_[i], batch, s); } catch (...) { g_conv_prof = nullptr; throw; }
@@ -1144,6 +1249,13 @@ int Net::profile(int batch, int iters, float* ms, int* info, int cap, hipStream_
                 if (ops_[i].conv.mfma_mode != PREC_F32 && tile != TILE_64x64 && tile != TILE_128x64)
                     vec = 1 + ops_[i].conv.mfma_mode;   // 2 fp16 operands, 3 bf16x3 operands
             }
+            // members of a fused block (conv_fused.hip): the skipped ones launch nothing (tile -1, like the pooled average pools), the
+            // last one carries the block's one launch (TILE_FUSED); their FLOPs / bytes belong to that launch (bench.py adds them up)
+            if (conv) {
+                plan_roles(batch);
+                if (roles_[i] == FR_SKIP) { tile = -1; ms[i] = 0.f; }
+                else if (roles_[i] == FR_HEAD2 || roles_[i] == FR_HEAD3) { tile = TILE_FUSED; splits = 1; vec = 3; }
+            }
             info[4 * i] = conv; info[4 * i + 1] = fused_away ? -1 : tile; info[4 * i + 2] = vec; info[4 * i + 3] = splits;
         }
     }
@@ -1153,6 +1265,15 @@ int Net::profile(int batch, int iters, float* ms, int* info, int cap, hipStream_
 void Net::tap_copy(int i, int batch, float* d_out_nchw, hipStream_t s) {
     BP_CHECK(i >= 0 && i < (int)taps_.size(), "tap index");
     const Tensor& t = taps_[i];
+    // a tensor that lives only inside a fused block (conv_fused.hip) is rebuilt here by the unfused launches of the members that make it:
+    // their inputs are intact (one allocation per layer output) -- the tap then shows what the UNFUSED kernels compute from the same input
+    plan_roles(batch);
+    for (int j = 0; j < (int)ops_.size(); ++j)
+        if (ops_[j].type == OP_CONV && roles_[j] == FR_SKIP && ops_[j].conv.out == t.p) {
+            const FuseGroup& g = fuse_groups_[role_group_[j]];
+            run_op_unfused(ops_[g.pre], batch, s);
+            if (j == g.c3) run_op_unfused(ops_[g.c3], batch, s);
+        }
     // a tensor whose producers dropped the fp32 store (plan_planes) is rebuilt from its planes first: exact in the
     // bf16x3 mode (the planes ARE the fp32 value), the fp16-rounded value in the fp16 mode
     if (ActAlloc* a = find_act(t.p); a && a->planes && !a->f32_read && precision_ != PREC_F32)

@@ -110,6 +110,11 @@ public:
     // that will read them (bp_common.h ConvParams::xcd_home / pf_*).  Off by default: +4.7 % one frame at a time, -1 .. -2 %
     // with two to four in flight
     void set_prefetch(bool on) { prefetch_ = on; ++plan_version_; }
+    // conv -> conv fusion of whole residual / bottleneck blocks (conv_fused.hip, round 5; on by default, BP_NO_FUSION=1 / set_fusion(false)
+    // for the unfused plan: A/B runs, the fused-vs-unfused tests)
+    void set_fusion(bool on) { fusion_ = on; ++plan_version_; }
+    bool fusion() const { return fusion_; }
+    int fused_launches(int batch);        // groups the current plan runs as ONE launch at this batch size
     int take_xcd_errors(hipStream_t s);   // non-zero: some launch of the latency mode found a K slice on the wrong XCD and skipped its tile -- run the frame again without the mode
     bool pool_in_epilogue(const Op& conv, int batch, int tile) const;
     bool pooled_by_conv(const Op& pool, int batch) const;
@@ -153,6 +158,18 @@ protected:
     unsigned long long* stamps_ = nullptr;
     int stamp_slots_ = 0;
     bool prefetch_ = false;
+    // fusion groups: consecutive convolutions [1x1] -> [3x3 / stride 1] (-> [1x1]) whose intermediate tensors nobody else reads (found once, in
+    // finalize()); which of them run fused is a property of the plan (precision, batch size): roles_ caches it per (batch, plan version)
+    struct FuseGroup { int pre, c3, post; };
+    enum FuseRole : int { FR_NONE = 0, FR_SKIP = 1, FR_HEAD2 = 2, FR_HEAD3 = 3 };
+    std::vector<FuseGroup> fuse_groups_;
+    std::vector<int> roles_, role_group_;
+    int roles_batch_ = -1;
+    unsigned roles_version_ = ~0u;
+    bool fusion_ = true;
+    void find_fuse_groups();
+    void plan_roles(int batch);
+    void run_op_unfused(const Op& op, int batch, hipStream_t s);
     bool f16_res_ = false;        // fp16 skip connections (set_precision(PREC_F16_RES))
     unsigned plan_version_ = 0;   // bumped whenever launches would change (captured graphs must be rebuilt)
 };

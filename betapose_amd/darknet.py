@@ -206,6 +206,17 @@ class Darknet:
         _lib.check(_lib.lib().bp_yolo_set_prefetch(self._h, int(bool(on))))
         self._latency_mode = bool(on)
 
+    def set_fusion(self, on: bool = True):
+        """Conv -> conv fusion of whole residual / bottleneck blocks (include/betapose_hip.h bp_*_set_fusion; default on)."""
+        self._ensure()
+        _lib.check(_lib.lib().bp_yolo_set_fusion(self._h, int(bool(on))))
+
+    def fused_launches(self, batch: int = 1) -> int:
+        self._ensure()
+        n = C.c_int(0)
+        _lib.check(_lib.lib().bp_yolo_fused_launches(self._h, int(batch), C.byref(n)))
+        return int(n.value)
+
     def xcd_errors(self) -> int:
         """Non-zero when a launch of the latency mode found a K slice on the wrong XCD since the last call (include/betapose_hip.h
         bp_*_xcd_errors): its tile was not stored, the frame must be run again with the mode off.  Waits for the current stream."""

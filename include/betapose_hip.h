@@ -139,6 +139,16 @@ int bp_calibrate_ticks(long long ticks, float* ms, void* stream);
  * are bit-identical either way.  A captured pipeline graph is rebuilt on the next run. */
 int bp_yolo_set_prefetch(bp_yolo* y, int on);
 int bp_kpd_set_prefetch(bp_kpd* k, int on);
+/* conv -> conv fusion (round 5; default on, bf16x3 mode): a Darknet-53 residual block's 1x1 + 3x3 + shortcut (yolo/darknet.py:319-363)
+ * and a bottleneck's conv1 + conv2 (+ conv3 + skip connection; KPD/src/models/layers/SE_Resnet.py:25-42) run as ONE launch on 8 x 8 output
+ * patches where the block's maps are large and its channel counts small (208x208 / 104x104 detector blocks, 80x64 key-point blocks): the
+ * intermediate tensors stay in LDS.  Same results as the unfused plan within fp32 rounding (a different summation order in the 3x3).
+ * set_fusion(0) restores one launch per convolution; fused_launches reports how many groups the current plan fuses at `batch`.  A captured
+ * pipeline graph is rebuilt on the next run. */
+int bp_yolo_set_fusion(bp_yolo* y, int on);
+int bp_kpd_set_fusion(bp_kpd* k, int on);
+int bp_yolo_fused_launches(bp_yolo* y, int batch, int* launches);
+int bp_kpd_fused_launches(bp_kpd* k, int batch, int* launches);
 /* the latency mode's placement check: *count != 0 when, since the last call, a split-K launch found a K slice on another XCD
  * than its reducing block.  Such a launch raises an error word and does NOT store the affected tile (no trap: the context and the
  * other streams live on), so the frame's results are invalid: switch the mode off (bp_*_set_prefetch(., 0)) and run the frame

@@ -259,7 +259,7 @@ def test_conv_planes_from_the_fp32_kernels(cuda):
                                    (5, 10, 8, 64, 64, 1), (1, 40, 32, 32, 128, 1), (2, 7, 63, 32, 64, 1), (1, 3, 2, 64, 64, 2)])
 @pytest.mark.parametrize("tile", ["plh128"])
 def test_conv_pl_halo_tile_f16(cuda, shape, tile):
-    """TILE_PLH128 / TILE_PLH256 (round 4): the 128x128 / 256x128 fp16 plane tiles with the activations of a 3x3 / stride-1 layer read from an LDS-resident
+    """TILE_PLH128 (round 4): the 128x128 fp16 plane tile with the activations of a 3x3 / stride-1 layer read from an LDS-resident
     halo (one fetch per 32-channel group instead of one per tap).  Same operands and the same fp32 sums per tap as the all-DMA
     128x128 tile: against torch on the fp16-rounded operands, against that tile, bit-reproducible, planes = RNE of the output;
     images whose rows wrap inside a tile, tiles spanning images, M far below the tile, W up to 63, K slices of whole groups."""

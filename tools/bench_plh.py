@@ -8,7 +8,7 @@ import torch
 from betapose_amd import ops
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 28
 # (H, W, Cin, Cout, launches per frame)
-SHAPES = [(52, 52, 128, 256, 11), (26, 26, 256, 512, 11), (13, 13, 512, 1024, 7), (20, 16, 256, 256, 22), (10, 8, 512, 512, 2), (40, 32, 128, 128, 3)]
+SHAPES = [(20, 16, 512, 1024, 1), (40, 32, 256, 512, 1), (52, 52, 128, 256, 11), (26, 26, 256, 512, 11), (13, 13, 512, 1024, 7), (20, 16, 256, 256, 22), (10, 8, 512, 512, 2), (40, 32, 128, 128, 3)]
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
 tot = {}
