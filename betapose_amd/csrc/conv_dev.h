@@ -62,7 +62,7 @@ template <class P>
 __device__ __forceinline__ PlaneDesc make_plane_desc(const P& p) {
     PlaneDesc d;
     unsigned short* base = p.out16 ? p.out16 : reinterpret_cast<unsigned short*>(p.out);
-    const int bytes = (int)min((long long)p.M * p.out_ld * (p.store_mode == ST_PIXSHUF ? 8 : 2), (long long)0x7fffff00);   // (a PixelShuffle output has 4 M pixels of out_ld channels)
+    const int bytes = (int)min((long long)p.M * p.out_ld * ((p.store_mode == ST_PIXSHUF || p.store_mode == ST_UP2) ? 8 : 2), (long long)0x7fffff00);   // (a PixelShuffle output has 4 M pixels of out_ld channels)
     d.np = p.out16 ? p.out_np : 0;
     d.f32 = !(p.out16 && p.skip_f32);
     d.r0 = __builtin_amdgcn_make_buffer_rsrc(base, 0, bytes, 0x00020000);
@@ -306,6 +306,25 @@ struct PixShufRows {
     }
 };
 
+// Nearest x2 upsample stores (ST_UP2, the two route branches of YOLOv3: yolo/darknet.py:273-276 nn.Upsample behind a 1x1 convolution) through
+// the staged epilogue: tile row -> byte offset of the thread's four channels at output pixel (2 oy, 2 ox); the other three copies sit one pixel
+// right / one row down.  (Round 5: on the element-wise path these two layers carried a 6-13 us tail at batch 1 and ran 38 us against 17 us
+// for their sister layers at batch 28.)
+struct Up2Rows {
+    int m_first, m_step, M, hw, OW, OH, out_ld;
+    unsigned sub;             // channel part, bytes
+    float rcp_hw, rcp_ow;
+    __device__ __forceinline__ unsigned offset(int pass) const {
+        const int m = m_first + pass * m_step;
+        if (m >= M) return OOB;
+        const int b = fast_div(m, hw, rcp_hw);
+        const int rem = m - b * hw;
+        const int oy = fast_div(rem, OW, rcp_ow);
+        const int ox = rem - oy * OW;
+        return (unsigned)((((b * 2 * OH + 2 * oy) * (2 * OW) + 2 * ox) * out_ld) * 4) + sub;
+    }
+};
+
 // Row loop of the staged (16-B per lane) epilogue: each pass reads 4 consecutive channels of one tile row from the
 // LDS staging tile, applies bias / residual / activation and stores 16 B.  ACT and RES are compile-time (the caller
 // switches once per block): RES 0 none, 1 add before the activation (ResNet), 2 add after it (YOLO shortcut).
@@ -319,6 +338,10 @@ struct ResScaleRows {
     const float* rs;          // res_scale + the thread's first channel
     int m_first, m_step, hw, Cout, m_last;
     float rcp_hw;
+    // (A form that requested the first and last pass's image scales once, ahead of the row loop, and selected per pass was SLOWER than this
+    // load per pass -- 120.8 / 73.1 / 43.7 / 38.7 us against 106.1 / 62.8 / 41.3 / 35.9 us for the four layers at batch 28: the loads hit the
+    // L1 and the selects serialised the loop; removed.)
+    __device__ __forceinline__ void prefetch(int) {}
     __device__ __forceinline__ f32x4 at(int pass) const {
         const int m = min(m_first + pass * m_step, m_last);      // (rows past M read the last image's scale; their store is dropped)
         return *reinterpret_cast<const f32x4*>(rs + fast_div(m, hw, rcp_hw) * Cout);
@@ -329,7 +352,8 @@ template <int ACT, int RES, int PASSES, int PF>
 __device__ __forceinline__ void epilogue_rows(const float* srow, int s_step, f32x4 bias4,
                                               __amdgpu_buffer_rsrc_t rsrcO, unsigned off_o, unsigned step_o,
                                               __amdgpu_buffer_rsrc_t rsrcR, unsigned off_r, unsigned step_r, const f32x4* rpre,
-                                              const PlaneDesc& pd, bool r16 = false, const PixShufRows* ps = nullptr, const ResScaleRows* rsc = nullptr) {
+                                              const PlaneDesc& pd, bool r16 = false, const PixShufRows* ps = nullptr, const ResScaleRows* rsc = nullptr,
+                                              const Up2Rows* up = nullptr) {
     // ps (PixelShuffle stores, conv_tail.inc): the output byte offset of a pass comes from its row's pixel instead of off_o + pass * step_o
     // PF: the residual rows were requested before the tile was staged (rpre[pass], registers): a cold 16-B load costs the
     // block > 1 us at the very end of the kernel otherwise
@@ -354,6 +378,20 @@ __device__ __forceinline__ void epilogue_rows(const float* srow, int s_step, f32
         if constexpr (RES == 2) v += r4;
         const u32x4 o = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
         if (ps) off_o = ps->offset(pass);
+        if (up) {
+            off_o = up->offset(pass);
+            const unsigned right = (unsigned)(up->out_ld * 4), down = (unsigned)(2 * up->OW * up->out_ld * 4);
+            if (off_o != OOB) {      // (OOB + an increment could wrap into range)
+                if (pd.f32) {
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rsrcO, (int)(off_o + right), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rsrcO, (int)(off_o + down), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(o, rsrcO, (int)(off_o + down + right), 0, 0);
+                }
+                emit_planes4(pd, v, (off_o + right) >> 1);
+                emit_planes4(pd, v, (off_o + down) >> 1);
+                emit_planes4(pd, v, (off_o + down + right) >> 1);
+            }
+        }
         if (pd.f32) __builtin_amdgcn_raw_buffer_store_b128(o, rsrcO, (int)off_o, 0, 0);
         emit_planes4(pd, v, off_o >> 1);      // the planes mirror the fp32 view: same element index, half the bytes
         srow += s_step;

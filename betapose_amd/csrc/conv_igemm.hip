@@ -32,6 +32,8 @@
 // Fragment trick: lane l reads A[row=l&31][4h..4h+3] (h=l>>5) as one b128 and feeds
 // component j to MFMA j, so MFMA j contracts k = {j, 4+j} of the 8-wide sub-chunk;
 // B uses the same k mapping, and the sum over k is order-free.
+#include <cstdlib>
+
 #include "conv_dev.h"
 
 namespace bp {
@@ -630,8 +632,10 @@ __device__ __forceinline__ void conv_igemm_h_body(const P& p, const int bp_bid, 
 #define BP_EARLY_BIAS bias_early
 #define BP_HAS_ACC kg_has_acc
 #define BP_TAIL_STAMP(k_) BH_STAMP(k_)
-#define BP_EP_RES_SCALE (KG == 1)      /* the four-wave tile runs the SE blocks' downsample layers; the K2 form keeps its 126 registers */
+#define BP_EP_RES_SCALE true            /* the SE blocks' downsample layers (both the four-wave tile and the K2 form run some of them) */
+#define BP_EP_UP2                       /* the detector's two upsampling 1x1 layers */
 #include "conv_tail.inc"
+#undef BP_EP_UP2
 #undef BP_EP_RES_SCALE
 #undef BP_HAS_ACC
 #undef BP_EARLY_BIAS
@@ -757,6 +761,122 @@ __global__ __launch_bounds__(64 * CG) void stem3x3_kernel(const ConvParams p) {
     stem3x3_body<CG>(p, (int)blockIdx.x, tile);
 }
 
+// =====================================================================================================================
+// The same stem in the fp16 modes (round 5): on the matrix cores.  At 28 frames per launch the direct convolution above takes 296 us --
+// 4 % of configs[2] -- with its waves issuing 22 % of their cycles (profiles/r04_pmc_wave_stalls_batch28_f16r.json), while the layer is
+// 8.4 GFLOP and 310 MB of fp16 output: a 100 us pass.  Here a block owns 128 consecutive pixels: every tap is ONE 16-B load per pixel as
+// before (the packed RGB frames: red, green, blue and the neighbour's red, which meets a zero filter entry), converted to four fp16 and
+// parked as the pixel's im2col row in LDS -- 9 taps x 4 = 36 of 48 k, rows of 112 B (an odd multiple of 16 B: conflict-free fragment
+// reads); each wave multiplies its 32 pixels by the 32 filters (fp16, from the packed fp32 filters, k = tap 4 + channel as they are stored)
+// with three v_mfma_f32_32x32x16_f16; bias / activation, then 16-B stores of the fp16 plane (+ the fp32 tensor where it is still read)
+// through an LDS tile.  fp16 operands, fp32 accumulation: the arithmetic of the mode (train_YOLO/src/convolutional_kernels.cu:268-280
+// converts the first layer's activations too); the fp32-accurate modes keep the direct convolution.
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void stem3x3_f16_kernel(const ConvParams p) {
+    constexpr int RB = 112, LDT = 36;                    // im2col row bytes; staging row floats
+    __shared__ __attribute__((aligned(16))) char lds[128 * LDT * 4 > 128 * RB ? 128 * LDT * 4 : 128 * RB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = (int)blockIdx.x * 128;
+    // the filters of this lane's channel (column lane & 31), k half lane >> 5 of the three k-steps: fp32 -> fp16 once per block
+    f16x8 fb[3];
+    {
+        const float* w = p.w + (long long)(lane & 31) * p.Kpad + 8 * (lane >> 5);
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(w + 16 * ks), hi = *reinterpret_cast<const f32x4*>(w + 16 * ks + 4);
+            const f16x4 l = __builtin_convertvector(lo, f16x4), h = __builtin_convertvector(hi, f16x4);
+            fb[ks] = __builtin_shufflevector(l, h, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+    }
+    const f32x4 bias4 = *reinterpret_cast<const f32x4*>(p.bias + (tid & 1) * 16), bias4b = *reinterpret_cast<const f32x4*>(p.bias + (tid & 1) * 16 + 4),
+                bias4c = *reinterpret_cast<const f32x4*>(p.bias + (tid & 1) * 16 + 8), bias4d = *reinterpret_cast<const f32x4*>(p.bias + (tid & 1) * 16 + 12);
+    // ---- im2col rows: thread -> pixel tid >> 1, taps of parity tid & 1
+    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.in), 0, (int)min((long long)p.N * p.H * p.W * p.in_ld * 4, (long long)OOB), 0x00020000);
+    {
+        const int pix = tid >> 1;
+        const int m = min(m0 + pix, p.M - 1);            // (rows past M: a duplicate of the last pixel, not stored)
+        const int hw = p.OH * p.OW;
+        const int b = m / hw, rem = m - b * hw;
+        const int oy = rem / p.OW, ox = rem - oy * p.OW;
+        f32x4 x[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int t = 2 * i + (tid & 1);
+            const int ky = (t * 11) >> 5, kx = t - 3 * ky;   // t / 3 for t < 9 (t = 9: never in the image test below)
+            const int iy = oy + ky - 1, ix = ox + kx - 1;
+            const bool ok = t < 9 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            x[i] = buf_load4(rsrcA, ok ? (unsigned)((((b * p.H + iy) * p.W + ix) * p.in_ld) * 4) : OOB, 0);
+        }
+        char* const row = lds + pix * RB;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int t = 2 * i + (tid & 1);
+            f32x4 v = x[i];
+            if (p.Cin < 4) v.w = 0.f;                    // (the neighbour's red: its filter entry is zero, but the last pixel of the tensor reads past it)
+            if (t < 9) *reinterpret_cast<f16x4*>(row + 8 * t) = __builtin_convertvector(v, f16x4);
+        }
+        // k 36 .. 47 of the row: zeros (12 fp16 = 24 B; the odd-tap thread writes them)
+        if (tid & 1) {
+            *reinterpret_cast<u32x2*>(row + 72) = u32x2{0u, 0u};
+            *reinterpret_cast<u32x4*>(row + 80) = u32x4{0u, 0u, 0u, 0u};
+        }
+    }
+    __syncthreads();
+    // ---- 32 pixels x 32 channels per wave
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    {
+        const char* const arow = lds + (32 * wave + (lane & 31)) * RB + (lane >> 5) * 16;
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(arow + 32 * ks), fb[ks], acc, 0, 0, 0);
+    }
+    __syncthreads();                                     // the im2col rows are dead: the tile is staged over them
+    float* const S = reinterpret_cast<float*>(lds);
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        S[(32 * wave + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDT + (lane & 31)] = acc[r];
+    __syncthreads();
+    // ---- stores: thread -> pixel tid >> 1, channels 16 (tid & 1) .. + 15
+    const int pix = tid >> 1, m = m0 + pix, c0 = (tid & 1) * 16;
+    if (m < p.M && c0 < p.Cout) {
+        const float* srow = S + pix * LDT + c0;
+        f32x4 v[4] = {*reinterpret_cast<const f32x4*>(srow) + bias4, *reinterpret_cast<const f32x4*>(srow + 4) + bias4b,
+                      *reinterpret_cast<const f32x4*>(srow + 8) + bias4c, *reinterpret_cast<const f32x4*>(srow + 12) + bias4d};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (p.act == ACT_LEAKY) {
+                v[q].x = v[q].x > 0.f ? v[q].x : 0.1f * v[q].x; v[q].y = v[q].y > 0.f ? v[q].y : 0.1f * v[q].y;
+                v[q].z = v[q].z > 0.f ? v[q].z : 0.1f * v[q].z; v[q].w = v[q].w > 0.f ? v[q].w : 0.1f * v[q].w;
+            } else if (p.act == ACT_RELU) {
+                v[q].x = v[q].x > 0.f ? v[q].x : 0.f; v[q].y = v[q].y > 0.f ? v[q].y : 0.f;
+                v[q].z = v[q].z > 0.f ? v[q].z : 0.f; v[q].w = v[q].w > 0.f ? v[q].w : 0.f;
+            }
+        }
+        const long long e = (long long)m * p.out_ld + c0;
+        if (!(p.out16 && p.skip_f32)) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(p.out + e + 4 * q) = v[q];
+        }
+        if (p.out16) {                                   // (one fp16 plane: RNE of the fp32 value, as every producer writes it)
+            const f16x4 h0 = __builtin_convertvector(v[0], f16x4), h1 = __builtin_convertvector(v[1], f16x4),
+                        h2 = __builtin_convertvector(v[2], f16x4), h3 = __builtin_convertvector(v[3], f16x4);
+            *reinterpret_cast<f16x8*>(p.out16 + e) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+            *reinterpret_cast<f16x8*>(p.out16 + e + 8) = __builtin_shufflevector(h2, h3, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+    }
+}
+
+// the fp16 modes' stem: 32 output channels, an fp16 plane wanted by the next layer (BP_NO_STEM_F16=1: the direct convolution, A/B runs)
+static bool stem3_f16_wanted(const ConvParams& p) {
+    static const bool off = std::getenv("BP_NO_STEM_F16") != nullptr;
+    return !off && p.out16 != nullptr && p.out_np == 1 && p.Cout == 32 && p.Kpad >= 48 && p.out_ld % 8 == 0 &&
+           (reinterpret_cast<uintptr_t>(p.out16) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0;
+}
+
 bool conv_stem3_eligible(const ConvParams& p) {
     return p.cin_pack == 4 && p.Cin <= 4 && p.in_ld >= p.Cin && p.in_ld <= 4 && p.ksize == 3 && p.stride == 1 && p.pad == 1 && p.OH == p.H && p.OW == p.W &&
            p.Cout % 4 == 0 && p.Cout <= 64 && p.CoutPad >= ((p.Cout + 7) / 8) * 8 && p.Kpad >= 36 && p.store_mode == ST_NHWC &&
@@ -766,6 +886,12 @@ bool conv_stem3_eligible(const ConvParams& p) {
 
 static void launch_stem3(const ConvParams& p, hipStream_t s) {
     BP_CHECK(conv_stem3_eligible(p) && p.splits == 1, "not a 3x3 / stride-1 / packed-RGB stem");
+    if (stem3_f16_wanted(p)) {
+        const dim3 g((p.M + 127) / 128);
+        if (g_conv_prof) hipExtLaunchKernelGGL(stem3x3_f16_kernel, g, dim3(256), 0, s, g_conv_prof->e0, g_conv_prof->e1, 0, p);
+        else hipLaunchKernelGGL(stem3x3_f16_kernel, g, dim3(256), 0, s, p);
+        return;
+    }
     const int cg = (p.Cout + 7) / 8;
     const dim3 grid((p.M + 63) / 64);
 #define BP_STEM(CG_)                                                                                                       \

@@ -588,9 +588,11 @@ __global__ __launch_bounds__(64 * (WM * WN * KG + LW)) void conv_pl_kernel(const
 #define BP_SLAB_TILE (p.hy_splits > 0 ? tile_id - p.hy_full : tile_id)
 #define BP_SLAB_TILES (p.hy_splits > 0 ? p.n_tiles - p.hy_full : (p.n_tiles ? p.n_tiles : (int)gridDim.x / p.splits))
 #define BP_EP_RES_SCALE true           /* the SE blocks' downsample layers in the fp16 modes */
+#define BP_EP_UP2                      /* the detector's two upsampling 1x1 layers */
 #define BP_EP_PIXSHUF                  /* the DUC layers' PixelShuffle stores through the staged epilogue (round 5: they ran 229 us each at batch 28 on the element-wise path) */
 #include "conv_tail.inc"
 #undef BP_EP_PIXSHUF
+#undef BP_EP_UP2
 #undef BP_EP_RES_SCALE
 #undef BP_SPLITS
 #undef BP_SLAB_TILE

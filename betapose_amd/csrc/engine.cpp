@@ -714,7 +714,7 @@ void Net::plan_roles(int batch) {
     roles_batch_ = batch; roles_version_ = plan_version_;
     static const bool env_off = std::getenv("BP_NO_FUSION") != nullptr;
     static const int min_blocks = env_int_early("BP_FUSE_MIN_BLOCKS", 48);
-    if (!fusion_ || env_off || precision_ != PREC_BF16X3 || force_tile_ >= 0) return;
+    if (!fusion_ || env_off || precision_ == PREC_F32 || force_tile_ >= 0) return;      // (bf16x3 on fp32 activations, fp16 on the operand planes)
     for (int gi = 0; gi < (int)fuse_groups_.size(); ++gi) {
         const FuseGroup& g = fuse_groups_[gi];
         ConvParams a, b, c;
@@ -887,6 +887,13 @@ void Net::plan_planes(int prec) {
         if (!a || (op.conv.in - a->base) % 8 != 0 || a->elems % 8 != 0) continue;
         a->wanted = true;
     }
+    // fp16 skip connections (PREC_F16_RES): a tensor that is ONLY ever a skip connection -- the SE blocks' T = bn3(conv3), which the
+    // "downsample" convolution adds scaled (SE_Resnet.py:31-40) -- gets an fp16 plane too, so that it travels as 2 bytes per element like every
+    // other skip connection of the mode (round 5: at 28 frames per launch layer1.0's T was 147 MB written and 147 MB read as fp32)
+    if (f16_res_ && np == 1)
+        for (Op& op : ops_)
+            if (op.type == OP_CONV && op.conv.res)
+                if (ActAlloc* r = find_act(op.conv.res); r && (op.conv.res - r->base) % 8 == 0 && r->elems % 8 == 0 && (op.conv.res_ld & 7) == 0) r->wanted = true;
     for (ActAlloc& a : acts_)
         if (a.wanted && !a.planes) {
             a.planes = (unsigned short*)arena_.alloc_bytes(3 * a.elems * sizeof(unsigned short));
@@ -956,6 +963,9 @@ void Net::plan_planes(int prec) {
         if (op.type == OP_CONV) {
             if (!op.conv.res16) mark(op.conv.res);
             if (!(op.conv.in16 && op.conv.wpl)) mark(op.conv.in);
+        } else if (op.type == OP_AVGPOOL && &op != ops_.data() && (&op - 1)->type == OP_CONV && (&op - 1)->pool_out == op.out) {
+            // the SE average pool normally rides in the producing convolution's epilogue (pool_in_epilogue: fp32 sums of the accumulators,
+            // nothing reads the tensor); where it cannot (a tile that spans images), run_op rebuilds the fp32 tensor from the plane first
         } else {
             mark(op.a); mark(op.b);
         }
@@ -1187,6 +1197,10 @@ void Net::run_op_unfused(const Op& op, int batch, hipStream_t s) {
             break;
         case OP_AVGPOOL:
             if (pooled_by_conv(op, batch)) break;      // its slice sums were written by the producing conv's epilogue
+            // (a tensor whose fp32 store was dropped because only its plane is read -- plan_planes -- is rebuilt from the plane for this kernel)
+            if (ActAlloc* a = find_act(op.a); a && a->planes && !a->f32_read && precision_ != PREC_F32)
+                launch_planes_to_f32(a->planes + (op.a - a->base), (long long)a->elems, precision_ == PREC_F16 ? 1 : 3, const_cast<float*>(op.a), op.a_ld,
+                                     (long long)batch * op.H * op.W, op.C, s);
             launch_avgpool(op.a, op.a_ld, op.out, batch, op.H * op.W, op.C, s);
             break;
         case OP_FC: {
@@ -1254,7 +1268,7 @@ int Net::profile(int batch, int iters, float* ms, int* info, int cap, hipStream_
             if (conv) {
                 plan_roles(batch);
                 if (roles_[i] == FR_SKIP) { tile = -1; ms[i] = 0.f; }
-                else if (roles_[i] == FR_HEAD2 || roles_[i] == FR_HEAD3) { tile = TILE_FUSED; splits = 1; vec = 3; }
+                else if (roles_[i] == FR_HEAD2 || roles_[i] == FR_HEAD3) { tile = TILE_FUSED; splits = 1; vec = 1 + ops_[i].conv.mfma_mode; }
             }
             info[4 * i] = conv; info[4 * i + 1] = fused_away ? -1 : tile; info[4 * i + 2] = vec; info[4 * i + 3] = splits;
         }

@@ -70,16 +70,18 @@ def test_kpd_fused_bottlenecks_equal_the_unfused_plan_tap_by_tap(cuda):
         assert float((fused(inps[bb:bb + 1].to(cuda)).cpu()[0] - h3[bb]).abs().max()) <= 1e-4
 
 
-def test_fusion_is_a_property_of_the_bf16x3_plan_only(cuda):
-    """The fp32-MFMA and fp16 modes keep one launch per convolution (the fused kernel is bf16x3 on fp32 activations); switching the
-    mode or the fusion flag re-plans, and a clone inherits the flag."""
+def test_fusion_follows_the_plan(cuda):
+    """The fp32-MFMA mode keeps one launch per convolution; bf16x3 (fp32 activations) and the fp16 modes (operand planes) fuse the same
+    three groups; switching the mode or the fusion flag re-plans, and a clone inherits the flag."""
     net = Darknet("yolo/cfg/yolov3-single.cfg", reso=416, max_batch=1).load_stream(helpers.yolo_stream()).cuda().eval()
     x = helpers.yolo_input_from_frame(helpers.frames(1)[0]).to(cuda)
     assert net.fused_launches(1) == 3
     base = net(x).cpu()
-    for mode in ("f32", "f16"):
+    net.set_precision("f32")
+    assert net.fused_launches(1) == 0 and torch.isfinite(net(x)).all()
+    for mode in ("f16", "f16r"):
         net.set_precision(mode)
-        assert net.fused_launches(1) == 0
+        assert net.fused_launches(1) == 1
         assert torch.isfinite(net(x)).all()
     net.set_precision("bf16x3")
     assert net.fused_launches(1) == 3 and torch.equal(net(x).cpu(), base)
@@ -91,6 +93,37 @@ def test_fusion_is_a_property_of_the_bf16x3_plan_only(cuda):
     net.set_fusion(True)
     assert torch.equal(net(x).cpu(), base)
     assert float((unf[..., 4:] - base[..., 4:]).abs().max()) <= 2e-5
+
+
+@pytest.mark.parametrize("mode", ["f16", "f16r"])
+def test_fp16_fused_blocks_equal_the_unfused_plan(cuda, mode):
+    """The fp16 form of the fused block (operand planes in, fp16 plane [+ fp32 tensor] out, fp16 skip connections in 'f16r'): the
+    intermediates are rounded to fp16 where the unfused launches round them, so fused and unfused differ by summation order and by the
+    fp16 roundings that order flips -- held to the fp16 modes' stated tolerances (tests/test_gpu_nets.py), tap by tap at 1e-2 of the
+    layer's scale, batch 1 and 3."""
+    fused, plain = _pair(lambda: Darknet("yolo/cfg/yolov3-single.cfg", reso=416, max_batch=3).load_stream(helpers.yolo_stream()).cuda().eval())
+    kf, kp = _pair(lambda: FastPoseHIP(helpers.kpd_state_dict(), n_classes=50, max_batch=3).cuda().eval())
+    for n in (fused, plain, kf, kp):
+        n.set_precision(mode)
+    assert fused.fused_launches(3) == 1 and kf.fused_launches(3) == 3 and plain.fused_launches(3) == 0      # (fp16: the 104x104 blocks stay unfused, conv_fused.hip fused_form)
+    x = torch.cat([helpers.yolo_input_from_frame(f) for f in helpers.frames(3)])
+    g = torch.Generator().manual_seed(78)
+    inps = torch.rand(3, 3, 320, 256, generator=g) - 0.45
+    for batch in (1, 3):
+        pf, pp = fused(x[:batch].to(cuda)).cpu(), plain(x[:batch].to(cuda)).cpu()
+        assert torch.equal(fused(x[:batch].to(cuda)).cpu(), pf)
+        d = (pf - pp).abs()
+        assert float(d[..., :2].max()) < 0.25 and float(d[..., 4:].max()) < 5e-3
+        assert bool((d[..., 2:4] <= 0.05 + 2e-2 * pp[..., 2:4].abs()).all())
+        for i, (name, *_s) in enumerate(fused.taps()[:12]):
+            a, bb = fused.tap(i, batch=batch).cpu(), plain.tap(i, batch=batch).cpu()
+            assert float((a - bb).abs().max()) <= 1e-2 * max(1.0, float(bb.abs().max())), ("yolo tap " + name, mode)
+        hf, hp = kf(inps[:batch].to(cuda)).cpu(), kp(inps[:batch].to(cuda)).cpu()
+        assert torch.equal(kf(inps[:batch].to(cuda)).cpu(), hf)
+        assert float((hf - hp).abs().max()) < 1e-2
+        for i, (name, *_s) in enumerate(kf.taps()[:5]):
+            a, bb = kf.tap(i, batch=batch).cpu(), kp.tap(i, batch=batch).cpu()
+            assert float((a - bb).abs().max()) <= 1e-2 * max(1.0, float(bb.abs().max())), ("kpd tap " + name, mode)
 
 
 def test_fused_blocks_at_other_resolutions(cuda):

@@ -20,8 +20,13 @@ def tot(d, c):
             a = per.setdefault(k, [0, 0.0]); a[0] += 1; a[1] += float(r["Counter_Value"])
     return per
 F = tot("$REPO/gpurun_out/pmcf_FETCH_SIZE", "FETCH_SIZE"); W = tot("$REPO/gpurun_out/pmcf_WRITE_SIZE", "WRITE_SIZE")
-frames = 44.0
+import re
+extra = "$EXTRA"
+def arg(name, dflt):
+    m = re.findall(r"--%s[ =](\d+)" % name, extra)
+    return int(m[-1]) if m else dflt
+frames = float((arg("steps", 40) + arg("warmup", 4)) * arg("batch", 1))     # (every frame of the run, warm-up included, is under the counters)
 fb = sum(v[1] for v in F.values()) * 1024 * 2 / frames; wb = sum(v[1] for v in W.values()) * 1024 / frames
-print(json.dumps({"streams": $ST, "fetch_MB_per_frame(x2 corrected)": fb / 1e6, "write_MB_per_frame": wb / 1e6,
+print(json.dumps({"streams": $ST, "frames_counted": frames, "bench_args": extra, "fetch_MB_per_frame(x2 corrected)": fb / 1e6, "write_MB_per_frame": wb / 1e6,
                   "per_kernel_fetch_MB_per_frame": {k: round(v[1] * 2048 / frames / 1e6, 1) for k, v in sorted(F.items(), key=lambda kv: -kv[1][1])[:6]}}, indent=1))
 PY
