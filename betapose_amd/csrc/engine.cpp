@@ -519,12 +519,13 @@ static void choose_h16(const ConvParams& c, long long M, int mode, int sk_max, i
 
 // a forced kernel id (bp_*_set_policy, tests and sweeps) applies to the layers it can run and is ignored for the others:
 // the fp32-MFMA tiles run any layer (they read the fp32 activations), the operand-plane tiles the layers with planes
-static bool tile_runs(int tile, const ConvParams& c) {
+static bool tile_runs(int tile, const ConvParams& c, long long M = 0) {
     // a layer planned on the operand planes (in16 + wpl) may have NO fp32 input: plan_planes() dropped the fp32 store of producers
     // whose readers all take the planes.  The kernels that read fp32 activations are therefore never forced onto such a layer
     // (round-3 advisor finding: a forced tile 0 / 1 in the fp16 mode read tensors nobody stored)
     const bool on_planes = c.in16 != nullptr && c.wpl != nullptr;
     if (tile == TILE_64x64 || tile == TILE_128x64) return !on_planes;
+    if (tile == TILE_S1) return conv_s1_eligible(c, M);
     if (conv_tile_is_pl(tile)) return c.mfma_mode != PREC_F32 && conv_pl_eligible(c) && (!conv_tile_is_plh(tile) || conv_plh_eligible(c));
     if (tile == TILE_64x64_BD || tile == TILE_BD_K2) return c.mfma_mode == PREC_BF16X3 && conv_h16_eligible(c) && c.w16s != nullptr && !on_planes;
     if (conv_tile_is_halo(tile)) return c.mfma_mode == PREC_BF16X3 && c.in16 == nullptr && conv_halo_eligible(c, tile);
@@ -550,13 +551,18 @@ static void choose_launch(const Op& op, int batch, int force_tile, int sk_target
     int s = 1;
     if (mode != PREC_F32) {
         choose_h16(c, M, mode, sk_max, &t, &s, lone);
-        if (force_tile >= 0 && tile_runs(force_tile, c)) t = force_tile;
+        // round 5: the 1x1 layers of the batched fp16 runs (one K slice on a conv_pl tile, no SE pool in the epilogue) on the persistent
+        // streaming kernel (conv_s1.hip); BP_NO_S1=1: the plane tiles as before (A/B runs)
+        static const bool s1_off = std::getenv("BP_NO_S1") != nullptr;
+        if (!s1_off && mode == PREC_F16 && s == 1 && conv_tile_is_pl(t) && !op.pool_out && conv_s1_eligible(c, M)) t = TILE_S1;
+        if (force_tile >= 0 && !(force_tile == TILE_S1 && op.pool_out) && tile_runs(force_tile, c, M)) t = force_tile;
         if (!(sk_target == 512 && sk_min_chunks == 4 && sk_max == 8)) {   // explicit policy (tests, sweeps)
             const long long blocks = ((M + conv_tile_bm(t) - 1) / conv_tile_bm(t)) *
                                      ((c.CoutPad + conv_tile_bn(t) - 1) / conv_tile_bn(t));
             s = 1;
             while (blocks * s < sk_target && c.nchunks / (s + 1) >= sk_min_chunks && s < sk_max) ++s;
         }
+        if (t == TILE_S1) s = 1;     // (a persistent grid: no K slices)
     } else if (stem3_wanted(c, force_tile)) {
         t = TILE_STEM3;       // the RGB 3x3 stem: direct convolution, no K slices
     } else {

@@ -280,6 +280,52 @@ def test_conv_pl_halo_tile_f16(cuda, shape, tile):
     _check(out.cpu().permute(0, 3, 1, 2), base.cpu().permute(0, 3, 1, 2), tol=2e-5 * scale)
 
 
+S1_SHAPES = [
+    # N, H, W, Cin, Cout, stride, act, res (None / before the activation / after it)
+    (2, 40, 32, 256, 128, 1, "leaky", None),        # one pass, activation slots with look-ahead (the YOLO 52x52 class)
+    (7, 20, 16, 256, 1024, 1, "relu", "pre"),       # several passes per item, N groups across blocks (KPD conv3 class)
+    (8, 20, 16, 512, 256, 1, "relu", None),         # K = 512: 128 filter registers per lane, one block per CU
+    (4, 104, 80, 64, 256, 1, "relu", "pre"),        # K = 64 (KPD layer1 class): tiles of 4 KB, eight of them ahead
+    (5, 26, 26, 512, 256, 1, "leaky", "post"),      # M tail (3 380 rows = 105 tiles + 20 rows), skip connection behind the activation
+    (3, 80, 64, 256, 512, 2, "linear", None),       # stride 2 (the downsample layers)
+    (2, 45, 37, 128, 136, 1, "leaky", "post"),      # Cout % 128 != 0 (CoutPad 192: the second column group overhangs), odd map, K = 128
+    (1, 52, 52, 384, 128, 1, "leaky", None),        # K = 384 (the route layers)
+]
+
+
+@pytest.mark.parametrize("shape", S1_SHAPES)
+def test_conv_s1_streaming_1x1_f16(cuda, shape):
+    """TILE_S1 (conv_s1.hip, round 5): the 1x1 layers of the batched fp16 runs as a persistent streaming kernel -- activations of a 32-row
+    M-tile in LDS several tiles ahead, the filter fragments of a wave in registers for the whole kernel, a loader wave with a scoreboard.
+    Same operands and the same MFMA sequence per output element as the 64x64 plane tile: BIT-IDENTICAL to it; against torch on the
+    fp16-rounded operands at the accumulation-order bar; planes = RNE of the output; bit-reproducible."""
+    N, H, W, Cin, Cout, st, act, rmode = shape
+    g = torch.Generator().manual_seed(9100 + Cin + Cout + H)
+    x = (torch.randn(N, H, W, Cin, generator=g) * torch.exp(0.5 * torch.randn(N, H, W, 1, generator=g))).half().float()
+    w = (torch.randn(Cout, Cin, 1, 1, generator=g) / np.sqrt(Cin)).half().float()
+    b = torch.randn(Cout, generator=g)
+    OH, OW = (H - 1) // st + 1, (W - 1) // st + 1
+    res = torch.randn(N, OH, OW, Cout, generator=g) if rmode else None
+    ref = _ref(x, w, b, st, 0, act, res, rmode == "post")
+    kw = dict(stride=st, pad=0, act=act, res=res.to(cuda) if rmode else None, res_after_act=rmode == "post", splits=1)
+    out, pl = ops.conv2d_nhwc(x.to(cuda), w, b, tile="s1_f16", planes=True, **kw)
+    assert torch.equal(out, ops.conv2d_nhwc(x.to(cuda), w, b, tile="s1_f16", **kw))
+    assert torch.equal(_planes_to_f32(pl, "f16"), out.half().float())
+    base = ops.conv2d_nhwc(x.to(cuda), w, b, tile="pl64_f16", **kw)
+    assert torch.equal(out, base), "max |d| %.3e" % float((out - base).abs().max())
+    _check(out.cpu().permute(0, 3, 1, 2), ref, tol=2e-5 * max(1.0, float(ref.abs().mean())))
+
+
+def test_conv_s1_refuses_other_layers(cuda):
+    """The streaming tile takes 1x1 layers with M >= 2 048, N >= 128, K in {64, 128, 256, 384, 512} only: anything else is refused loudly."""
+    g = torch.Generator().manual_seed(5)
+    for (N, H, W, Cin, Cout, k) in [(1, 13, 13, 256, 128, 1), (2, 40, 32, 64, 64, 1), (2, 40, 32, 64, 128, 3), (2, 40, 32, 32, 128, 1), (2, 40, 32, 1024, 128, 1)]:
+        x = torch.randn(N, H, W, Cin, generator=g)
+        w = torch.randn(Cout, Cin, k, k, generator=g)
+        with pytest.raises(Exception):
+            ops.conv2d_nhwc(x.to(cuda), w, None, pad=k // 2, tile="s1_f16", splits=1)
+
+
 def test_conv_pl_full_size_layers(cuda):
     """Full-size layers of both networks: against the definition (fp64) and the size-independent linearity property."""
     g = torch.Generator().manual_seed(23)

@@ -33,7 +33,7 @@ ap.add_argument("--engine-like", action="store_true", help="residual added after
 ap.add_argument("--all-splits", action="store_true", help="print every slice count, not only the best")
 a = ap.parse_args()
 tiles = a.tiles.split(",") if a.tiles else (["bd", "pl64", "pl128x64", "pl128"] if a.mode == "b3" else ["64x64", "w2x2", "pl64", "pl128x64", "pl128", "pl256x128"])
-BMN = {"bd": (64, 64), "64x64": (64, 64), "w2x2": (128, 128), "pl64": (64, 64), "pl128": (128, 128), "pl128x64": (128, 64), "pl256x128": (256, 128), "pl128s": (128, 128), "pl64k2": (64, 64), "pl64bd": (64, 64), "128x64": (128, 64), "plh128": (128, 128)}
+BMN = {"bd": (64, 64), "64x64": (64, 64), "w2x2": (128, 128), "pl64": (64, 64), "pl128": (128, 128), "pl128x64": (128, 64), "pl256x128": (256, 128), "pl128s": (128, 128), "pl64k2": (64, 64), "pl64bd": (64, 64), "128x64": (128, 64), "plh128": (128, 128), "s1": (32, 128)}
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
 peak = 2500.0 / (6 if a.mode == "b3" else 1)
