@@ -13,7 +13,7 @@
 //   * a wave keeps the FILTER FRAGMENTS of its 32 output columns IN REGISTERS for the whole kernel (K / 4 VGPRs: 64 at K = 256, 128 at
 //     K = 512): read once per block, never again -- no filter traffic, no filter waits, no per-stage barrier;
 //   * a block (4 compute waves = 128 columns, + 1 loader wave) is PERSISTENT over the 32-row M-tiles of its column group; the tiles'
-//     activations (2 KB per 32-k chunk) arrive in LDS by LDS-DMA NL tiles ahead, the skip-connection tile (+ SE scales) two tiles ahead;
+//     activations (2 KB per 32-k chunk) arrive in LDS by LDS-DMA one tile ahead (two buffers), the skip-connection tile (+ SE scales) too;
 //   * everything that comes from HBM is issued by the LOADER wave, which does nothing else: s_waitcnt vmcnt counts in order, so a wave that
 //     mixed these fetches with anything short would wait for HBM every time.  The loader keeps a SCOREBOARD -- the number of vector-memory
 //     instructions it has issued and, per buffer, that number at the time of the buffer's fetch (one VGPR, buffer = lane) -- and waits with
@@ -56,8 +56,15 @@ __device__ __forceinline__ void s1_vm_wait(int allowed) {
 }
 #undef S1_W
 
-template <int NCH>     // 32-k chunks of the layer's K (compile-time: the filter fragments are a register array)
+// NCH: 32-k chunks of the layer's K (compile-time: the filter fragments are a register array).
+// KH = 2 (K = 1 024): a wave's 32 columns x K would be 256 registers, so the block takes 64 columns and its four compute waves are 2 column
+// halves x 2 K HALVES (128 filter registers each); behind the tile's MFMAs the two K halves of a column half swap partial sums through their
+// staging tiles -- the wave of the low K half finishes rows 0-15, the other one rows 16-31 (the sum of the two halves is the same number either
+// way; it is NOT the 64x64 plane tile's one-chain sum: equal within the accumulation-order bar, not bit for bit).
+template <int NCH, int KH>
 __global__ __launch_bounds__(384) void conv_s1_kernel(const ConvParams p, const S1Args a) {
+    constexpr int GW = S1_BN / KH;          // columns of the block's group
+    constexpr int NCW = NCH / KH;           // chunks per compute wave
     // the ONE LDS object of the kernel (conv_pl.hip: a second one makes hipcc drain vmcnt before every fragment read)
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -65,7 +72,8 @@ __global__ __launch_bounds__(384) void conv_s1_kernel(const ConvParams p, const 
     const int nlw = (int)(blockDim.x >> 6) - 4;                 // loader waves: 1, or 2 (K >= 384: loader l fetches the chunks c with c % 2 == l)
     const int oR = a.off_res;
     float* const ldsBias = reinterpret_cast<float*>(lds + a.off_bias);
-    const int rtile = a.res_bytes == 4 ? 16384 : 8192;      // bytes of the skip-connection tile inside a buffer; the scales sit behind it
+    const int rrow = GW * a.res_bytes;                      // bytes of a row of the skip-connection tile
+    const int rtile = 32 * rrow;                            // ... of the tile inside a buffer; the scales sit behind it
     // block -> (XCD, column group, M-tile slot): the column groups of an M-tile run on ONE XCD (its activations are fetched from HBM once)
     const int xcd = (int)blockIdx.x & 7, bq = (int)blockIdx.x >> 3;
     const int ng = bq % a.NG, ms = bq / a.NG;
@@ -73,10 +81,10 @@ __global__ __launch_bounds__(384) void conv_s1_kernel(const ConvParams p, const 
     // M-tiles of this block: (ms + k MS) 8 + xcd for k = 0 .. nit - 1 (the last group of eight may end before xcd)
     int nit = ms < MT8 ? (MT8 - 1 - ms) / a.MS + 1 : 0;
     if (nit > 0 && (ms + (nit - 1) * a.MS) * 8 + xcd >= a.MT) --nit;
-    const int n0 = ng * S1_BN;
+    const int n0 = ng * GW;
 
     // the column group's bias (padded to CoutPad by the engine) -> LDS, once
-    if (tid < S1_BN) ldsBias[tid] = n0 + tid < p.CoutPad ? p.bias[n0 + tid] : 0.f;
+    if (tid < GW) ldsBias[tid] = n0 + tid < p.CoutPad ? p.bias[n0 + tid] : 0.f;
     const bool has_res = a.res_bytes != 0, r16 = a.res_bytes == 2, has_scale = p.res_scale != nullptr;
     const float rcp_hw = 1.0f / (float)a.hw, rcp_ow = 1.0f / (float)p.OW;
 
@@ -133,25 +141,28 @@ __global__ __launch_bounds__(384) void conv_s1_kernel(const ConvParams p, const 
             const int mt = (ms + k * a.MS) * 8 + xcd, j = k % a.rq;
             const int m0 = mt * S1_BM;
             char* const dst = lds + oR + j * a.rbuf;
-            if (r16) {        // [32 rows][256 B]: piece i = rows 4 i ..+3, lane -> row (lane >> 4), 16 B = columns 8 (lane & 15) ..+7
+            if (r16) {        // [32 rows][GW x 2 B]: a piece = 1 KB = 512 / GW rows, lane -> (row, 16 B = 8 columns)
+                constexpr int LPR = GW / 8, RPP = 64 / LPR, NP_ = 32 / RPP;      // lanes per row, rows per piece, pieces
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int m = m0 + 4 * i + (lane >> 4), n = n0 + 8 * (lane & 15);
+                for (int i = 0; i < NP_; ++i) {
+                    const int m = m0 + RPP * i + lane / LPR, n = n0 + 8 * (lane % LPR);
                     dma16(rsrcR, dst + i * 1024, (m < p.M && n < p.Cout) ? (unsigned)((m * p.res_ld + n) * 2) : OOB, 0);
                 }
-                vm += 8;
-            } else {          // [32 rows][512 B]: piece i = rows 2 i, 2 i + 1, lane -> row (lane >> 5), 16 B = columns 4 (lane & 31) ..+3
+                vm += NP_;
+            } else {          // [32 rows][GW x 4 B]: lane -> (row, 16 B = 4 columns)
+                constexpr int LPR = GW / 4, RPP = 64 / LPR, NP_ = 32 / RPP;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const int m = m0 + 2 * i + (lane >> 5), n = n0 + 4 * (lane & 31);
+                for (int i = 0; i < NP_; ++i) {
+                    const int m = m0 + RPP * i + lane / LPR, n = n0 + 4 * (lane % LPR);
                     dma16(rsrcR, dst + i * 1024, (m < p.M && n < p.Cout) ? (unsigned)((m * p.res_ld + n) * 4) : OOB, 0);
                 }
-                vm += 16;
+                vm += NP_;
             }
-            if (has_scale) {  // [2 images][128 columns] floats: lanes 0-31 the image of the tile's first row, lanes 32-63 the next one
+            if (has_scale) {  // [2 images][GW columns] floats: GW / 4 lanes per image -- the image of the tile's first row, then the next one
+                constexpr int LPI = GW / 4;
                 const int b0 = fast_div(min(m0, p.M - 1), a.hw, rcp_hw);
-                const int b = min(b0 + (lane >> 5), p.N - 1), n = n0 + 4 * (lane & 31);
-                dma16(rsrcS, dst + rtile, n < p.Cout ? (unsigned)((b * p.Cout + n) * 4) : OOB, 0);
+                const int b = min(b0 + lane / LPI, p.N - 1), n = n0 + 4 * (lane % LPI);
+                dma16(rsrcS, dst + rtile, (lane < 2 * LPI && n < p.Cout) ? (unsigned)((b * p.Cout + n) * 4) : OOB, 0);
                 ++vm;
             }
             seqr = lane == j ? vm : seqr;
@@ -164,6 +175,7 @@ __global__ __launch_bounds__(384) void conv_s1_kernel(const ConvParams p, const 
             s1_vm_wait(vm - need);
             asm volatile("s_barrier" ::: "memory");       // tile k has landed; every compute wave is done with tile k - 1
             if (k > 0) { a_issue(k - 1 + a.NL); r_issue(k - 1 + a.rq); }
+            if constexpr (KH == 2) asm volatile("s_barrier" ::: "memory");      // (the compute waves' exchange of partial sums)
         }
         return;
     }
@@ -175,17 +187,20 @@ __global__ __launch_bounds__(384) void conv_s1_kernel(const ConvParams p, const 
         __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)min((long long)p.M * p.out_ld * 4, (long long)OOB), 0x00020000);
     const PlaneDesc pd = make_plane_desc(p);
     float* const stg = reinterpret_cast<float*>(lds + a.off_stg) + w * S1_STG_FLOATS;
+    const int kh = KH == 2 ? (w >> 1) : 0;            // K half of the wave
+    const int wq = KH == 2 ? (w & 1) : w;             // its 32 columns inside the group
     // fragment geometry: lane -> row (lane & 31), logical granule 2 ks + (lane >> 5) at slot granule ^ ((row >> 2) & 3)
     const int fsw = ((lane & 31) >> 2) & 3;
     const int fr0 = (lane & 31) * 64 + ((((lane >> 5)) ^ fsw) << 4), fr1 = fr0 ^ 32;
     // ---- the wave's filter fragments: its 32 columns x K, read ONCE from the packed image ([CoutPad / 64][chunk][64 rows][64 B])
-    f16x8 fb[NCH][2];
+    f16x8 fb[NCW][2];
     {
-        const int t64 = 2 * ng + (w >> 1);
-        const int row_off = (w & 1) * 2048;            // the wave's 32 rows inside the 64-row tile (the swizzle key (row >> 2) & 3 is unchanged)
+        const int col0 = n0 + 32 * wq;
+        const int t64 = col0 >> 6;
+        const int row_off = ((col0 >> 5) & 1) * 2048;  // the wave's 32 rows inside the 64-row tile (the swizzle key (row >> 2) & 3 is unchanged)
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const int so = (t64 * NCH + c) * 4096 + row_off;
+        for (int c = 0; c < NCW; ++c) {
+            const int so = (t64 * NCH + kh * NCW + c) * 4096 + row_off;
             fb[c][0] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrcB, fr0, so, 0));
             fb[c][1] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrcB, fr1, so, 0));
         }
@@ -194,7 +209,7 @@ __global__ __launch_bounds__(384) void conv_s1_kernel(const ConvParams p, const 
     __syncthreads();
     // epilogue geometry of the lane: staging row (lane >> 3) + 8 pass, columns 4 (lane & 7) ..+3 of the wave's 32
     const int e_row = lane >> 3, e_q = lane & 7;
-    const int nl = 32 * w + 4 * e_q, n = n0 + nl;      // the lane's first column inside the group / the layer
+    const int nl = 32 * wq + 4 * e_q, n = n0 + nl;     // the lane's first column inside the group / the layer
     const f32x4 bias4 = *reinterpret_cast<const f32x4*>(ldsBias + nl);
     const bool n_ok = n < p.Cout;
 
@@ -206,8 +221,8 @@ __global__ __launch_bounds__(384) void conv_s1_kernel(const ConvParams p, const 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         {
-            const char* const ab = lds + (k % a.NL) * (NCH * 2048);
-            static_for<NCH>([&](auto cc) __attribute__((always_inline)) {
+            const char* const ab = lds + (k % a.NL) * (NCH * 2048) + kh * (NCW * 2048);
+            static_for<NCW>([&](auto cc) __attribute__((always_inline)) {
                 constexpr int c = decltype(cc)::value;
                 const f16x8 a0 = *reinterpret_cast<const f16x8*>(ab + c * 2048 + fr0);
                 const f16x8 a1 = *reinterpret_cast<const f16x8*>(ab + c * 2048 + fr1);
@@ -221,26 +236,45 @@ __global__ __launch_bounds__(384) void conv_s1_kernel(const ConvParams p, const 
         {
             const char* const rb = lds + oR + (k % a.rq) * a.rbuf;
             const int b0 = has_scale ? fast_div(min(m0, p.M - 1), a.hw, rcp_hw) : 0;
+            float own[8];     // KH == 2: the sums of the 16 rows this wave finishes
+            if constexpr (KH == 2) {
+                // the wave of the low K half finishes rows 0-15 (registers 0-7), the other one rows 16-31: each parks the rows it gives away
+                // in the PARTNER's staging tile, and behind a barrier adds what the partner parked in its own
+                float* const pstg = reinterpret_cast<float*>(lds + a.off_stg) + (w ^ 2) * S1_STG_FLOATS;
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
+                for (int r = 0; r < 8; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    own[r] = kh ? acc[8 + r] : acc[r];
+                    pstg[row * 36 + (lane & 31)] = kh ? acc[r] : acc[8 + r];
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    own[r] += stg[row * 36 + (lane & 31)];
+                }
+            }
+#pragma unroll
+            for (int half = 0; half < (KH == 2 ? 1 : 2); ++half) {
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);     // row inside the half
-                    stg[row * 36 + (lane & 31)] = acc[8 * half + r];
+                    if constexpr (KH == 2) stg[row * 36 + (lane & 31)] = own[r];
+                    else stg[row * 36 + (lane & 31)] = acc[8 * half + r];
                 }
 #pragma unroll
                 for (int ps = 0; ps < 2; ++ps) {
-                    const int hrow = 8 * ps + e_row, row = 16 * half + hrow;
+                    const int hrow = 8 * ps + e_row, row = 16 * (KH == 2 ? kh : half) + hrow;
                     const int m = m0 + row;
                     f32x4 v = *reinterpret_cast<const f32x4*>(stg + hrow * 36 + 4 * e_q);
                     v += bias4;
                     f32x4 r4 = {0.f, 0.f, 0.f, 0.f};
                     if (has_res) {
-                        if (r16) r4 = __builtin_convertvector(*reinterpret_cast<const f16x4*>(rb + row * 256 + nl * 2), f32x4);
-                        else r4 = *reinterpret_cast<const f32x4*>(rb + row * 512 + nl * 4);
+                        if (r16) r4 = __builtin_convertvector(*reinterpret_cast<const f16x4*>(rb + row * rrow + nl * 2), f32x4);
+                        else r4 = *reinterpret_cast<const f32x4*>(rb + row * rrow + nl * 4);
                         if (has_scale) {
                             const int b = fast_div(min(m, p.M - 1), a.hw, rcp_hw);
-                            r4 *= *reinterpret_cast<const f32x4*>(rb + rtile + (b - b0) * 512 + nl * 4);
+                            r4 *= *reinterpret_cast<const f32x4*>(rb + rtile + (b - b0) * (GW * 4) + nl * 4);
                         }
                         if (!p.res_after_act) v += r4;
                     }
@@ -274,21 +308,25 @@ static bool s1_plan(const ConvParams& p, long long M, int res_bytes, S1Args* out
     S1Args a{};
     const int nch = p.nchunks;
     a.MT = (int)((M + S1_BM - 1) / S1_BM);
-    a.NG = (p.CoutPad + S1_BN - 1) / S1_BN;
+    const int gw = nch == 32 ? S1_BN / 2 : S1_BN;      // K = 1 024: 64 columns per block (two K halves per column half)
+    a.NG = (p.CoutPad + gw - 1) / gw;
     a.res_bytes = res_bytes;
     a.hw = p.OH * p.OW;
-    a.rbuf = res_bytes ? (res_bytes == 4 ? 16384 : 8192) + (p.res_scale ? 1024 : 0) : 0;
+    a.rbuf = res_bytes ? 32 * gw * res_bytes + (p.res_scale ? 1024 : 0) : 0;
     const int bias_b = S1_BN * 4, stg_b = 4 * S1_STG_FLOATS * 4, tile_b = nch * 2048;
     // blocks per CU: the filter fragments take K / 4 registers per lane -- two blocks (ten waves) per CU up to K = 256, one beyond
     static const int force_bpc = std::getenv("BP_S1_BPC") ? std::atoi(std::getenv("BP_S1_BPC")) : 0;     // (A/B runs)
     static const int force_nl = std::getenv("BP_S1_NL") ? std::atoi(std::getenv("BP_S1_NL")) : 0;
     const int bpc = force_bpc ? force_bpc : (nch <= 8 ? 2 : 1);
-    const int budget = (bpc == 2 ? 80 * 1024 - 64 : 160 * 1024 - 128);
+    const int budget = (160 * 1024 - 192) / bpc;
     a.rq = res_bytes ? 2 : 0;
     int nl = (budget - stg_b - bias_b - a.rq * a.rbuf) / tile_b;
     if (nl < 2 && a.rq == 2) { a.rq = 1; nl = (budget - stg_b - bias_b - a.rq * a.rbuf) / tile_b; }
-    if (nl < 1) return false;
-    a.NL = std::min(nl, force_nl ? force_nl : 8);
+    if (nl < 2) return false;     // (the hand-over needs two buffers: tile k + 1 lands while tile k is read)
+    // look-ahead: TWO tiles.  More is slower (measured at batch 28, fp16 skip connections: 52x52 256 -> 128 17.2 us with two tiles, 18.0 with
+    // three, 19.6 with four; 256 -> 1024 15.5 / 16.4 / 16.1): a block has 4-9 tiles in all, so deep look-ahead is every block asking for most of
+    // its input at once -- the first tiles queue behind everybody's later ones
+    a.NL = std::min(nl, force_nl >= 2 ? force_nl : 2);
     const int MT8 = (a.MT + 7) / 8;
     a.MS = std::max(1, std::min(MT8, (bpc * 256) / (8 * a.NG)));
     a.off_stg = a.NL * tile_b;
@@ -304,7 +342,7 @@ bool conv_s1_eligible(const ConvParams& p, long long M) {
     if (!(conv_pl_eligible(p) && p.wpl != nullptr && p.mfma_mode == PREC_F16)) return false;
     if (!(p.ksize == 1 && p.pad == 0 && (p.stride == 1 || p.stride == 2) && p.Kpad == p.Cin && p.store_mode == ST_NHWC)) return false;
     const int nch = p.nchunks;
-    if (!(nch == 2 || nch == 4 || nch == 8 || nch == 12 || nch == 16)) return false;      // K = 64, 128, 256, 384, 512 (the instantiated forms)
+    if (!(nch == 2 || nch == 4 || nch == 8 || nch == 12 || nch == 16 || nch == 32)) return false;      // K = 64, 128, 256, 384, 512, 1 024 (the instantiated forms)
     // K = 512 (128 filter registers per lane, one block per CU): measured at batch 28 against the 64x64 plane tile -- 512 -> 128 loses
     // (19.9 against 17.6 us), 512 -> 256 ties, the wider layers win; BP_S1_K512=1 takes them all (A/B runs)
     static const bool k512_all = std::getenv("BP_S1_K512") != nullptr;
@@ -319,18 +357,18 @@ bool conv_s1_eligible(const ConvParams& p, long long M) {
     return s1_plan(p, M, p.res ? 4 : 0, &a, &g, &l);     // (sized for the larger skip-connection format: the plan holds whichever the launch gets)
 }
 
-template <int NCH>
+template <int NCH, int KH = 1>
 static void launch_s1_t(const ConvParams& p, const S1Args& a, int grid, int lds_bytes, hipStream_t s) {
-    if (lds_bytes > 64 * 1024) allow_big_lds(reinterpret_cast<const void*>(conv_s1_kernel<NCH>));
+    if (lds_bytes > 64 * 1024) allow_big_lds(reinterpret_cast<const void*>(conv_s1_kernel<NCH, KH>));
     if (g_conv_prof)
-        hipExtLaunchKernelGGL(conv_s1_kernel<NCH>, dim3(grid), dim3(NCH >= 12 ? 384 : 320), lds_bytes, s, g_conv_prof->e0, g_conv_prof->e1, 0, p, a);
+        hipExtLaunchKernelGGL((conv_s1_kernel<NCH, KH>), dim3(grid), dim3(NCH >= 12 ? 384 : 320), lds_bytes, s, g_conv_prof->e0, g_conv_prof->e1, 0, p, a);
     else
-        hipLaunchKernelGGL(conv_s1_kernel<NCH>, dim3(grid), dim3(NCH >= 12 ? 384 : 320), lds_bytes, s, p, a);
+        hipLaunchKernelGGL((conv_s1_kernel<NCH, KH>), dim3(grid), dim3(NCH >= 12 ? 384 : 320), lds_bytes, s, p, a);
 }
 
 void launch_conv_s1(const ConvParams& p, hipStream_t s) {
     BP_CHECK(conv_s1_eligible(p, p.M) && p.splits == 1 && p.hy_splits == 0 && !p.xcd_home,
-             "streaming 1x1 tile: fp16 mode, 1x1 / stride 1 or 2, NHWC store, K in {64, 128, 256, 384, 512}, N >= 128, M >= 2048, one K slice");
+             "streaming 1x1 tile: fp16 mode, 1x1 / stride 1 or 2, NHWC store, K in {64, 128, 256, 384, 512, 1024}, N >= 128, M >= 2048, one K slice");
     BP_CHECK((long long)p.N * p.H * p.W * p.in_ld * 2 < (long long)OOB, "activation planes too large for 32-bit offsets");
     S1Args a; int grid = 0, lds_bytes = 0;
     BP_CHECK(s1_plan(p, p.M, p.res ? (p.res16 ? 2 : 4) : 0, &a, &grid, &lds_bytes), "streaming 1x1 tile: no LDS plan");
@@ -339,6 +377,7 @@ void launch_conv_s1(const ConvParams& p, hipStream_t s) {
         case 4: launch_s1_t<4>(p, a, grid, lds_bytes, s); break;
         case 8: launch_s1_t<8>(p, a, grid, lds_bytes, s); break;
         case 12: launch_s1_t<12>(p, a, grid, lds_bytes, s); break;
+        case 32: launch_s1_t<32, 2>(p, a, grid, lds_bytes, s); break;
         default: launch_s1_t<16>(p, a, grid, lds_bytes, s); break;
     }
 }
