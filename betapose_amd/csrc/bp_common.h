@@ -197,7 +197,7 @@ bool conv_halo_eligible(const ConvParams& p, int tile);   // 3x3 / stride 1 / pa
 // by whole 32-channel groups = 9 chunks)
 void conv_split_plan(const ConvParams& p, int tile, int want, int* splits, int* cps);
 inline bool conv_tile_is_plh(int tile) { return tile == TILE_PLH128; }
-bool conv_plh_eligible(const ConvParams& p);  // TILE_PLH128 can run the layer (fp16, 3x3 / stride 1 / pad 1, W <= 63, whole channel groups per K slice)
+bool conv_plh_eligible(const ConvParams& p);  // TILE_PLH128 can run the layer (fp16, 3x3 / stride 1 / pad 1, W <= 126, whole channel groups per K slice)
 bool conv_pl_eligible(const ConvParams& p);   // planes + wpl present, Cin % 32 == 0, taps fit the 32-bit mask
 bool conv_s1_eligible(const ConvParams& p, long long M);   // TILE_S1 can run the layer at M output pixels (fp16, 1x1 / stride 1 or 2, NHWC store, 64 <= K <= 1024, N >= 128, M >= 2048)
 void launch_conv_s1(const ConvParams& p, hipStream_t s);   // conv_s1.hip

@@ -617,7 +617,7 @@ bool conv_tile_is_pl(int tile) {
 
 bool conv_plh_eligible(const ConvParams& p) {
     return conv_pl_eligible(p) && p.mfma_mode == PREC_F16 && p.ksize == 3 && p.stride == 1 && p.pad == 1 && p.OH == p.H && p.OW == p.W &&
-           p.W <= 63 && p.nchunks % 9 == 0 && p.Kpad == 9 * p.Cin;
+           p.W <= 126 && p.nchunks % 9 == 0 && p.Kpad == 9 * p.Cin;
 }
 
 bool conv_pl_eligible(const ConvParams& p) {
@@ -652,9 +652,12 @@ static void launch_pl_np(const ConvParams& p, int tile, hipStream_t s) {
         case TILE_PLH128:     // 128x128 with the activations from an LDS-resident halo (fp16, 3x3 / stride 1 / pad 1, W <= 63)
             if constexpr (NP == 1) {
                 BP_CHECK(conv_plh_eligible(p) && (p.splits == 1 || p.chunks_per_split % 9 == 0) && !p.xcd_home && p.hy_splits == 0,
-                         "halo plane tile: fp16 mode, 3x3 / stride 1 / pad 1, W <= 63, K slices of whole channel groups, plain grid");
+                         "halo plane tile: fp16 mode, 3x3 / stride 1 / pad 1, W <= 126, K slices of whole channel groups, plain grid");
                 if (p.W <= 31) launch_pl_t<1, 2, 2, 2, 2, 4, 1, 0, 1, false, 192>(p, s);
-                else launch_pl_t<1, 2, 2, 2, 2, 4, 1, 0, 1, false, 256>(p, s);
+                else if (p.W <= 63) launch_pl_t<1, 2, 2, 2, 2, 4, 1, 0, 1, false, 256>(p, s);
+                // (round 5) maps up to 126 wide -- the detector's two 104x104 3x3 layers: 384 halo rows (a 128-pixel strip reads 338 input pixels,
+                // 2.6x instead of 9x), and a 3-deep filter ring so that two blocks still fit a CU (2 x 24.6 KB of halo + 24 KB)
+                else launch_pl_t<1, 2, 2, 2, 2, 3, 1, 0, 1, false, 384>(p, s);
             } else throw Error("the halo plane tile is an fp16 tile");
             break;
         // (round 5: the halo form with 128 x 64 outputs per wave -- 2x2 waves on a 256x128 block, <1, 2, 2, 4, 2, 4 | 3, 1, 0, 1, false, 320 | 384>,

@@ -345,8 +345,11 @@ bool conv_s1_eligible(const ConvParams& p, long long M) {
     if (!(nch == 2 || nch == 4 || nch == 8 || nch == 12 || nch == 16 || nch == 32)) return false;      // K = 64, 128, 256, 384, 512, 1 024 (the instantiated forms)
     // K = 512 (128 filter registers per lane, one block per CU): measured at batch 28 against the 64x64 plane tile -- 512 -> 128 loses
     // (19.9 against 17.6 us), 512 -> 256 ties, the wider layers win; BP_S1_K512=1 takes them all (A/B runs)
-    static const bool k512_all = std::getenv("BP_S1_K512") != nullptr;
+    const bool k512_all = std::getenv("BP_S1_K512") != nullptr;     // (read per call: the tests switch it inside one process)
     if (nch == 16 && p.CoutPad < 256 && !k512_all) return false;
+    // K = 1 024 (two K halves per column half): 1 024 -> 256 and 1 024 -> 512 tie with the plane tile (16.3 against 16.2 us, 17.6 against 16.7),
+    // 1 024 -> 2 048 / stride 2 wins (30.2 against 36.5): the wide layers only
+    if (nch == 32 && p.CoutPad < 1024 && !k512_all) return false;
     if (p.CoutPad < S1_BN || (p.Cout & 3) || (p.out_ld & 3) || p.OH * p.OW < S1_BM) return false;
     if (M < 2048 || p.pool_out != nullptr) return false;
     if (p.res && ((p.res_ld & 7) != 0)) return false;

@@ -395,6 +395,7 @@ static const PlanEntry kPlanPL1[] = {
     {  18928,   512,   72, TILE_PLH128,  1},
     {  35840,   128,   36, TILE_PLH128,  1},
     {  75712,   256,   36, TILE_PLH128,  1},
+    { 302848,   128,   18, TILE_PLH128,  1},   // the 104x104 layers (round 5: 384 halo rows); BP_PLH_W63=1 keeps them on the 256x128 all-DMA tile (A/B runs)
     {   2240,   512,   64, TILE_PL64,  1},
     {   2240,   512,  144, TILE_PL64,  1},
     {   2240,  2048,   16, TILE_PL64,  1},
@@ -437,21 +438,27 @@ static const PlanEntry kPlanPL1[] = {
     {0, 0, 0, 0, 0},
 };
 
+// the halo plane tile runs the layer; BP_PLH_W63=1: maps up to 63 wide only, as before round 5 (A/B runs)
+static bool plh_ok(const ConvParams& c) {
+    static const bool w63 = std::getenv("BP_PLH_W63") != nullptr;
+    return conv_plh_eligible(c) && (c.W <= 63 || !w63);
+}
+
 // conv_pl.hip (operand planes + LDS-DMA): which block tile, how many K slices
 static void choose_pl(const ConvParams& c, long long M, int mode, int sk_max, int* tile, int* splits) {
     for (const PlanEntry& e : plan_file_entries())
         if (e.M == (int)M && e.CoutPad == c.CoutPad && e.nchunks == c.nchunks && conv_tile_is_pl(e.tile) &&
-            (!conv_tile_is_plh(e.tile) || conv_plh_eligible(c))) { *tile = e.tile; *splits = e.splits; return; }
+            (!conv_tile_is_plh(e.tile) || plh_ok(c))) { *tile = e.tile; *splits = e.splits; return; }
     for (const PlanEntry* e = (mode == PREC_F16 ? kPlanPL1 : kPlanPL3); e->M != 0; ++e)   // tables end with a zero row
         if (e->M == (int)M && e->CoutPad == c.CoutPad && e->nchunks == c.nchunks &&
-            (!conv_tile_is_plh(e->tile) || conv_plh_eligible(c))) { *tile = e->tile; *splits = e->splits; return; }     // (a 3x3 row also matches stride-2 / 1x1 layers of the same K)
+            (!conv_tile_is_plh(e->tile) || plh_ok(c))) { *tile = e->tile; *splits = e->splits; return; }     // (a 3x3 row also matches stride-2 / 1x1 layers of the same K)
     // other shapes (batched runs): the 128x128 block once its grid covers the chip (half the operand bytes per FLOP of the
     // 64x64 block: profiles/r03_bench_pl_batch28.txt), else the 64x64 block with enough K slices to fill it
     // (short K loops -- the 1x1 layers of the bottlenecks -- stay on the 64x64 block even then: a 128x128 block runs one per
     // CU and its prologue / epilogue are not covered by a neighbour's K loop; profiles/r03_tune_pl_f16_batch28.txt)
     const long long tiles128 = ((M + 127) / 128) * ((c.CoutPad + 127) / 128);
     int t = (c.CoutPad >= 128 && tiles128 >= 192 && c.nchunks >= 32) ? TILE_PL128 : TILE_PL64;
-    if (t == TILE_PL128 && mode == PREC_F16 && conv_plh_eligible(c)) t = TILE_PLH128;     // 3x3 / stride 1: the halo form beats the all-DMA tile wherever both run
+    if (t == TILE_PL128 && mode == PREC_F16 && plh_ok(c)) t = TILE_PLH128;     // 3x3 / stride 1: the halo form beats the all-DMA tile wherever both run
     int s = 1;
     if (t == TILE_PL64) {
         const long long blocks = ((M + 63) / 64) * (c.CoutPad / 64);

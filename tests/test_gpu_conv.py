@@ -256,13 +256,14 @@ def test_conv_planes_from_the_fp32_kernels(cuda):
 
 
 @pytest.mark.parametrize("shape", [(1, 13, 13, 64, 128, 1), (2, 26, 26, 64, 192, 1), (1, 52, 52, 128, 256, 2), (3, 20, 16, 96, 128, 3),
-                                   (5, 10, 8, 64, 64, 1), (1, 40, 32, 32, 128, 1), (2, 7, 63, 32, 64, 1), (1, 3, 2, 64, 64, 2)])
+                                   (5, 10, 8, 64, 64, 1), (1, 40, 32, 32, 128, 1), (2, 7, 63, 32, 64, 1), (1, 3, 2, 64, 64, 2),
+                                   (1, 104, 104, 64, 128, 1), (2, 9, 126, 32, 64, 1), (1, 20, 64, 64, 128, 2)])     # (round 5: maps up to 126 wide, 384 halo rows)
 @pytest.mark.parametrize("tile", ["plh128"])
 def test_conv_pl_halo_tile_f16(cuda, shape, tile):
     """TILE_PLH128 (round 4): the 128x128 fp16 plane tile with the activations of a 3x3 / stride-1 layer read from an LDS-resident
     halo (one fetch per 32-channel group instead of one per tap).  Same operands and the same fp32 sums per tap as the all-DMA
     128x128 tile: against torch on the fp16-rounded operands, against that tile, bit-reproducible, planes = RNE of the output;
-    images whose rows wrap inside a tile, tiles spanning images, M far below the tile, W up to 63, K slices of whole groups."""
+    images whose rows wrap inside a tile, tiles spanning images, M far below the tile, W up to 126, K slices of whole groups."""
     N, H, W, Cin, Cout, splits = shape
     g = torch.Generator().manual_seed(8800 + H * W + Cin)
     x = (torch.randn(N, H, W, Cin, generator=g) * torch.exp(torch.randn(N, H, W, 1, generator=g))).half().float()
@@ -297,12 +298,13 @@ S1_SHAPES = [
 
 
 @pytest.mark.parametrize("shape", S1_SHAPES)
-def test_conv_s1_streaming_1x1_f16(cuda, shape):
+def test_conv_s1_streaming_1x1_f16(cuda, shape, monkeypatch):
     """TILE_S1 (conv_s1.hip, round 5): the 1x1 layers of the batched fp16 runs as a persistent streaming kernel -- activations of a 32-row
     M-tile in LDS several tiles ahead, the filter fragments of a wave in registers for the whole kernel, a loader wave with a scoreboard.
     Same operands and the same MFMA sequence per output element as the 64x64 plane tile: BIT-IDENTICAL to it (K <= 512); against torch on the
     fp16-rounded operands at the accumulation-order bar; planes = RNE of the output; bit-reproducible."""
     N, H, W, Cin, Cout, st, act, rmode = shape
+    monkeypatch.setenv("BP_S1_K512", "1")      # (the plan keeps the narrow K >= 512 layers on the plane tile, where the two tie: every form is tested here)
     g = torch.Generator().manual_seed(9100 + Cin + Cout + H)
     x = (torch.randn(N, H, W, Cin, generator=g) * torch.exp(0.5 * torch.randn(N, H, W, 1, generator=g))).half().float()
     w = (torch.randn(Cout, Cin, 1, 1, generator=g) / np.sqrt(Cin)).half().float()
