@@ -354,6 +354,8 @@ def roofline(det, pose, batch):
             return "bp::conv_halo_k2_kernel<*>"                            # ... with two K groups inside the block
         if tile == 40:
             return "bp::conv_fused_kernel<*>"                              # whole residual / bottleneck block in one launch (conv_fused.hip)
+        if tile == 26:
+            return "bp::conv_s1_kernel<*>"                                 # 1x1 layers of the batched fp16 runs: persistent streaming kernel (conv_s1.hip; * = K chunks, K halves)
         if tile == 24:
             return "bp::conv_igemm_bdk2_kernel"                            # filters direct, two K groups inside an eight-wave block
         if tile in (7, 8, 9):
@@ -372,7 +374,9 @@ def roofline(det, pose, batch):
         tf_ = g_["flops"] / (g_["ms"] * 1e-3) / 1e12
         per_kernel.append({"kernel": kernel_name(k_[0], m_) if m_ != "f32" else ("bp::stem3x3_kernel" if k_[0] == 20 else "bp::conv_igemm_kernel<1, 1, %d>" % k_[1]),
                            "launches": g_["launches"], "us_per_step": round(g_["ms"] * 1e3, 1), "avg_launch_us": round(g_["ms"] / g_["launches"] * 1e3, 2),
-                           "gflop": round(g_["flops"] / 1e9, 2), "achieved_TFLOPs": round(tf_, 1), "frac": round(tf_ / peak_of[m_], 4)})
+                           "gflop": round(g_["flops"] / 1e9, 2), "achieved_TFLOPs": round(tf_, 1), "frac": round(tf_ / peak_of[m_], 4),
+                           # (per-op bytes are the batch-1 figure -- fp32 operands and results, weights once: not scaled to batched runs)
+                           "algorithmic_GBps": round(g_["bytes"] / (g_["ms"] * 1e-3) / 1e9, 1) if batch == 1 else None})
     try:
         import glob
         for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic*.json")))[::-1]:

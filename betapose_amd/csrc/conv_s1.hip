@@ -198,11 +198,22 @@ __global__ __launch_bounds__(384) void conv_s1_kernel(const ConvParams p, const 
         const int col0 = n0 + 32 * wq;
         const int t64 = col0 >> 6;
         const int row_off = ((col0 >> 5) & 1) * 2048;  // the wave's 32 rows inside the 64-row tile (the swizzle key (row >> 2) & 3 is unchanged)
-#pragma unroll
-        for (int c = 0; c < NCW; ++c) {
-            const int so = (t64 * NCH + kh * NCW + c) * 4096 + row_off;
-            fb[c][0] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrcB, fr0, so, 0));
-            fb[c][1] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrcB, fr1, so, 0));
+        // every block of a column group reads the SAME fragments, at the same moment (kernel start): the chunks are requested in one of
+        // four rotated orders by block, so that the blocks of an XCD do not all queue on one L2 line at a time
+        auto load_from = [&](auto startc) __attribute__((always_inline)) {
+            constexpr int start = decltype(startc)::value;
+            static_for<NCW>([&](auto ic) __attribute__((always_inline)) {
+                constexpr int c = (decltype(ic)::value + start) % NCW;
+                const int so = (t64 * NCH + kh * NCW + c) * 4096 + row_off;
+                fb[c][0] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrcB, fr0, so, 0));
+                fb[c][1] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrcB, fr1, so, 0));
+            });
+        };
+        switch (NCW >= 4 ? (ms & 3) : 0) {
+            case 1: load_from(std::integral_constant<int, NCW / 4>{}); break;
+            case 2: load_from(std::integral_constant<int, NCW / 2>{}); break;
+            case 3: load_from(std::integral_constant<int, (3 * NCW) / 4>{}); break;
+            default: load_from(std::integral_constant<int, 0>{}); break;
         }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -343,13 +354,12 @@ bool conv_s1_eligible(const ConvParams& p, long long M) {
     if (!(p.ksize == 1 && p.pad == 0 && (p.stride == 1 || p.stride == 2) && p.Kpad == p.Cin && p.store_mode == ST_NHWC)) return false;
     const int nch = p.nchunks;
     if (!(nch == 2 || nch == 4 || nch == 8 || nch == 12 || nch == 16 || nch == 32)) return false;      // K = 64, 128, 256, 384, 512, 1 024 (the instantiated forms)
-    // K = 512 (128 filter registers per lane, one block per CU): measured at batch 28 against the 64x64 plane tile -- 512 -> 128 loses
-    // (19.9 against 17.6 us), 512 -> 256 ties, the wider layers win; BP_S1_K512=1 takes them all (A/B runs)
-    const bool k512_all = std::getenv("BP_S1_K512") != nullptr;     // (read per call: the tests switch it inside one process)
-    if (nch == 16 && p.CoutPad < 256 && !k512_all) return false;
-    // K = 1 024 (two K halves per column half): 1 024 -> 256 and 1 024 -> 512 tie with the plane tile (16.3 against 16.2 us, 17.6 against 16.7),
-    // 1 024 -> 2 048 / stride 2 wins (30.2 against 36.5): the wide layers only
-    if (nch == 32 && p.CoutPad < 1024 && !k512_all) return false;
+    // K = 1 024 (64 columns per block, two K halves per column half), measured at batch 28 against the 64x64 plane tile on one box: 1 024 -> 256
+    // ties (16.0 against 16.2 us), 13x13 1 024 -> 512 loses (17.4 against 16.3), 1 024 -> 2 048 / stride 2 wins (30.2 against 36.5): the wide
+    // layers only.  (K = 512: 512 -> 128 16.7 against 20.8 us, 26x26 512 -> 256 17.2 against 18.8 -- all of them.)  BP_S1_K512=1 takes every
+    // K = 1 024 layer (tests, A/B runs; read per call: the tests switch it inside one process)
+    const bool k1024_all = std::getenv("BP_S1_K512") != nullptr;
+    if (nch == 32 && p.CoutPad < 1024 && !k1024_all) return false;
     if (p.CoutPad < S1_BN || (p.Cout & 3) || (p.out_ld & 3) || p.OH * p.OW < S1_BM) return false;
     if (M < 2048 || p.pool_out != nullptr) return false;
     if (p.res && ((p.res_ld & 7) != 0)) return false;

@@ -14,6 +14,9 @@ tools/pmc_mfma_busy.sh > /dev/null 2>&1 && cp $OUT/pmc_mfma_busy.json $OUT/r05_p
 python tools/per_op.py > $OUT/r05_per_op_b1_bf16x3.txt 2>/dev/null
 python tools/per_op.py --batch 28 --precision f16r --iters 5 > $OUT/r05_per_op_b28_f16r.txt 2>/dev/null
 python tools/per_op.py --batch 28 --precision f16 --iters 5 > $OUT/r05_per_op_b28_f16.txt 2>/dev/null
+# the streaming 1x1 kernel (conv_s1.hip) against the plan without it: per-op table and the configs[2] A/B on this box
+BP_NO_S1=1 python tools/per_op.py --batch 28 --precision f16r --iters 5 > $OUT/r05_per_op_b28_f16r_no_s1.txt 2>/dev/null
+tools/ab_s1.sh 2 > $OUT/r05_ab_s1.txt 2>&1
 python tools/fused_stamps.py > $OUT/r05_fused_stamps.txt 2>/dev/null
 python bench.py --no-cpu-baseline --no-served-legs --no-flip-rate --other-modes= --steps 200 --warmup 20 --insitu $OUT/r05_insitu_layer_times.txt > $OUT/r05_bench_insitu.json 2>/dev/null
 rm -rf $OUT/trace_headline $OUT/trace_b28 $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmcf_* $OUT/pmc_stalls $OUT/pmc_mfma* $OUT/pmc_busy* 2>/dev/null
