@@ -68,8 +68,10 @@ namespace bp {
 // conflict-free for any 16 consecutive rows, so for any tap shift), a tap outside the image reads a zero row.  The ring
 // carries the filters only.  L2 -> LDS bytes per group at 128x128: 88 KB instead of 144 KB -- the fp16 K loop is bound by exactly
 // that.  K slices are cut by whole groups (nine chunks).
-template <int NP, int WM, int WN, int TM, int TN, int NST, int CPS, int LW = 0, int KG = 1, bool BDIR = false, int HRT = 0>
-__global__ __launch_bounds__(64 * (WM * WN * KG + LW)) void conv_pl_kernel(const ConvParams p) {
+// B3 (round 5, halo form): THREE blocks per CU -- the epilogue staged in two slabs of 64 rows (the 128-row staging tile alone was 67.6 KB, more
+// than the ring and the halos together), and the register budget of three waves per SIMD asked of the compiler (launch bounds)
+template <int NP, int WM, int WN, int TM, int TN, int NST, int CPS, int LW = 0, int KG = 1, bool BDIR = false, int HRT = 0, bool B3 = false>
+__global__ __launch_bounds__(64 * (WM * WN * KG + LW), B3 ? 3 : 1) void conv_pl_kernel(const ConvParams p) {
     constexpr bool HALO = HRT > 0;
     static_assert(!HALO || (NP == 1 && CPS == 1 && LW == 0 && KG == 1 && !BDIR && HRT % (16 * WM * WN) == 0), "halo form: fp16, one chunk per stage");
     static_assert(LW == 0 || KG == 1, "loader waves and K groups are alternatives");
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(64 * (WM * WN * KG + LW)) void conv_pl_kernel(const
     constexpr int HALO_BYTES = HALO ? (HRT + 1) * 64 : 0;                 // one halo buffer: HRT rows + the zero row
     constexpr int CHUNK = NP * (A_PLANE + B_PLANE);
     constexpr int STAGE = CPS * CHUNK;
-    constexpr int EP_SLABS_ = BM > 128 ? BM / (32 * TM > 64 ? 32 * TM : 64) : 1;       // epilogue staging in slabs of 64 rows (or one wave's rows) on the big tiles (conv_tail.inc)
+    constexpr int EP_SLABS_ = BM > 128 ? BM / (32 * TM > 64 ? 32 * TM : 64) : (B3 ? 2 : 1);       // epilogue staging in slabs of 64 rows (or one wave's rows) on the big tiles (conv_tail.inc)
     constexpr int EPI_BYTES = (BM / EP_SLABS_) * LDT * 4;
     constexpr int RING = NST * STAGE;
     constexpr int KGSUM_BYTES = (KG - 1) * NWC * TM * TN * 4096;      // the other groups' accumulators, fragment order
@@ -625,7 +627,7 @@ bool conv_pl_eligible(const ConvParams& p) {
            ((reinterpret_cast<uintptr_t>(p.in16) & 15) == 0) && (p.in16_plane % 8 == 0);
 }
 
-template <int NP, int WM, int WN, int TM, int TN, int NST, int CPS, int LW = 0, int KG = 1, bool BDIR = false, int HRT = 0>
+template <int NP, int WM, int WN, int TM, int TN, int NST, int CPS, int LW = 0, int KG = 1, bool BDIR = false, int HRT = 0, bool B3 = false>
 static void launch_pl_t(const ConvParams& p, hipStream_t s) {
     BP_CHECK(BDIR ? p.wbd != nullptr : p.wpl != nullptr, "conv_pl: the filter image of this tile is missing");
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -637,9 +639,9 @@ static void launch_pl_t(const ConvParams& p, hipStream_t s) {
     BP_CHECK(q.hy_splits == 0 || (q.hy_full >= 0 && q.hy_full < q.n_tiles), "hybrid grid: whole tiles out of range");
     dim3 grid(conv_grid_blocks(q));
     if (g_conv_prof)
-        hipExtLaunchKernelGGL((conv_pl_kernel<NP, WM, WN, TM, TN, NST, CPS, LW, KG, BDIR, HRT>), grid, dim3(64 * (WM * WN * KG + LW)), 0, s, g_conv_prof->e0, g_conv_prof->e1, 0, q);
+        hipExtLaunchKernelGGL((conv_pl_kernel<NP, WM, WN, TM, TN, NST, CPS, LW, KG, BDIR, HRT, B3>), grid, dim3(64 * (WM * WN * KG + LW)), 0, s, g_conv_prof->e0, g_conv_prof->e1, 0, q);
     else
-        hipLaunchKernelGGL((conv_pl_kernel<NP, WM, WN, TM, TN, NST, CPS, LW, KG, BDIR, HRT>), grid, dim3(64 * (WM * WN * KG + LW)), 0, s, q);
+        hipLaunchKernelGGL((conv_pl_kernel<NP, WM, WN, TM, TN, NST, CPS, LW, KG, BDIR, HRT, B3>), grid, dim3(64 * (WM * WN * KG + LW)), 0, s, q);
 }
 
 template <int NP>
@@ -653,7 +655,13 @@ static void launch_pl_np(const ConvParams& p, int tile, hipStream_t s) {
             if constexpr (NP == 1) {
                 BP_CHECK(conv_plh_eligible(p) && (p.splits == 1 || p.chunks_per_split % 9 == 0) && !p.xcd_home && p.hy_splits == 0,
                          "halo plane tile: fp16 mode, 3x3 / stride 1 / pad 1, W <= 126, K slices of whole channel groups, plain grid");
-                if (p.W <= 31) launch_pl_t<1, 2, 2, 2, 2, 4, 1, 0, 1, false, 192>(p, s);
+                // maps up to 31 wide whose grid is MORE than two blocks per CU: three blocks per CU (template parameter B3: 3-deep ring, two epilogue
+                // slabs, 154 registers).  Batch 28, one launch at a time: 26x26 256 -> 512 (592 blocks) 61-67 -> 52-55 us, DUC1 (560) 111 -> 100;
+                // grids that fit two per CU anyway lose the fourth ring stage for nothing (13x13 512 -> 1024, 296 blocks: 63 -> 63; 20x16 256 -> 256,
+                // 140 blocks: 26.6 -> 29.8) and keep the form below.  BP_NO_PLH_B3=1: off (A/B runs; read per call)
+                const long long tiles128 = (((long long)p.M + 127) / 128) * ((p.CoutPad + 127) / 128);
+                if (p.W <= 31 && tiles128 > 512 && !std::getenv("BP_NO_PLH_B3")) launch_pl_t<1, 2, 2, 2, 2, 3, 1, 0, 1, false, 192, true>(p, s);
+                else if (p.W <= 31) launch_pl_t<1, 2, 2, 2, 2, 4, 1, 0, 1, false, 192>(p, s);
                 else if (p.W <= 63) launch_pl_t<1, 2, 2, 2, 2, 4, 1, 0, 1, false, 256>(p, s);
                 // (round 5) maps up to 126 wide -- the detector's two 104x104 3x3 layers: 384 halo rows (a 128-pixel strip reads 338 input pixels,
                 // 2.6x instead of 9x), and a 3-deep filter ring so that two blocks still fit a CU (2 x 24.6 KB of halo + 24 KB)
