@@ -662,6 +662,10 @@ static void launch_pl_np(const ConvParams& p, int tile, hipStream_t s) {
                 const long long tiles128 = (((long long)p.M + 127) / 128) * ((p.CoutPad + 127) / 128);
                 if (p.W <= 31 && tiles128 > 512 && !std::getenv("BP_NO_PLH_B3")) launch_pl_t<1, 2, 2, 2, 2, 3, 1, 0, 1, false, 192, true>(p, s);
                 else if (p.W <= 31) launch_pl_t<1, 2, 2, 2, 2, 4, 1, 0, 1, false, 192>(p, s);
+                // ... and maps up to 63 wide (halos of 2 x 16.4 KB): three blocks per CU only with a TWO-deep ring.  One launch at a time it is a tie
+                // (52x52 128 -> 256, 1 184 blocks: 60-73 -> 56-73 us by layer), with three streams in flight +0.7 % (5 335 -> 5 375 frames/s,
+                // profiles/r05_ab_plh_b3.txt): taken
+                else if (p.W <= 63 && tiles128 > 512 && !std::getenv("BP_NO_PLH_B3")) launch_pl_t<1, 2, 2, 2, 2, 2, 1, 0, 1, false, 256, true>(p, s);
                 else if (p.W <= 63) launch_pl_t<1, 2, 2, 2, 2, 4, 1, 0, 1, false, 256>(p, s);
                 // (round 5) maps up to 126 wide -- the detector's two 104x104 3x3 layers: 384 halo rows (a 128-pixel strip reads 338 input pixels,
                 // 2.6x instead of 9x), and a 3-deep filter ring so that two blocks still fit a CU (2 x 24.6 KB of halo + 24 KB)

@@ -258,7 +258,7 @@ def test_conv_planes_from_the_fp32_kernels(cuda):
 @pytest.mark.parametrize("shape", [(1, 13, 13, 64, 128, 1), (2, 26, 26, 64, 192, 1), (1, 52, 52, 128, 256, 2), (3, 20, 16, 96, 128, 3),
                                    (5, 10, 8, 64, 64, 1), (1, 40, 32, 32, 128, 1), (2, 7, 63, 32, 64, 1), (1, 3, 2, 64, 64, 2),
                                    (1, 104, 104, 64, 128, 1), (2, 9, 126, 32, 64, 1), (1, 20, 64, 64, 128, 2),      # (round 5: maps up to 126 wide, 384 halo rows)
-                                   (28, 26, 26, 64, 512, 1)])                                                    # (round 5: 592 tiles -> the three-blocks-per-CU form)
+                                   (28, 26, 26, 64, 512, 1), (28, 52, 52, 32, 128, 1)])                          # (round 5: 592 tiles -> the three-blocks-per-CU forms, 3- and 2-deep ring)
 @pytest.mark.parametrize("tile", ["plh128"])
 def test_conv_pl_halo_tile_f16(cuda, shape, tile):
     """TILE_PLH128 (round 4): the 128x128 fp16 plane tile with the activations of a 3x3 / stride-1 layer read from an LDS-resident
