@@ -28,5 +28,6 @@ def arg(name, dflt):
 frames = float((arg("steps", 40) + arg("warmup", 4)) * arg("batch", 1))     # (every frame of the run, warm-up included, is under the counters)
 fb = sum(v[1] for v in F.values()) * 1024 * 2 / frames; wb = sum(v[1] for v in W.values()) * 1024 / frames
 print(json.dumps({"streams": $ST, "frames_counted": frames, "bench_args": extra, "fetch_MB_per_frame(x2 corrected)": fb / 1e6, "write_MB_per_frame": wb / 1e6,
-                  "per_kernel_fetch_MB_per_frame": {k: round(v[1] * 2048 / frames / 1e6, 1) for k, v in sorted(F.items(), key=lambda kv: -kv[1][1])[:6]}}, indent=1))
+                  "per_kernel_fetch_MB_per_frame": {k: round(v[1] * 2048 / frames / 1e6, 1) for k, v in sorted(F.items(), key=lambda kv: -kv[1][1])[:16]},
+                  "per_kernel_write_MB_per_frame": {k: round(v[1] * 1024 / frames / 1e6, 1) for k, v in sorted(W.items(), key=lambda kv: -kv[1][1])[:16]}}, indent=1))
 PY
