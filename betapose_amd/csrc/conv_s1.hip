@@ -367,7 +367,11 @@ bool conv_s1_eligible(const ConvParams& p, long long M) {
     if (p.out16 != nullptr && p.out_np != 1) return false;
     if (M * p.out_ld * 4 >= (long long)OOB || (p.res && M * p.res_ld * 4 >= (long long)OOB)) return false;
     S1Args a; int g, l;
-    return s1_plan(p, M, p.res ? 4 : 0, &a, &g, &l);     // (sized for the larger skip-connection format: the plan holds whichever the launch gets)
+    if (!s1_plan(p, M, p.res ? 4 : 0, &a, &g, &l)) return false;     // (sized for the larger skip-connection format: the plan holds whichever the launch gets)
+    // a persistent block pays its start-up (filter fragments, first tile) over the tiles it walks: with fewer than three tiles per block the
+    // 64x64 plane tile wins -- configs-style runs of 2 / 4 / 8 frames per launch x 3 streams lost 0.7 / 1.3 / 2.0 % with this kernel on every
+    // M >= 2 048 layer (28 frames per launch: 4.4-17 tiles per block, +6.5 %).  BP_S1_K512=1 (tests) takes such layers too.
+    return k1024_all || (a.MT + 7) / 8 >= 3 * a.MS;
 }
 
 template <int NCH, int KH = 1>
