@@ -3,7 +3,8 @@
 // Same contract as conv_pl.hip for the layers it takes (1x1, stride 1 or 2, NHWC store; bias / LeakyReLU / ReLU / skip connection before or
 // after the activation / SE scale of the skip connection; fp16 plane and / or fp32 tensor out; yolo/darknet.py:240-259, SE_Resnet.py:25-42),
 // same operands (the producer's fp16 plane, conv_pl.hip's packed filter image), same MFMA sequence per output element (chunks in order, two
-// v_mfma_f32_32x32x16_f16 per 32-k chunk, bias added to the finished sum) -- so its results are bit-identical to TILE_PL64's.
+// v_mfma_f32_32x32x16_f16 per 32-k chunk, bias added to the finished sum) -- so its results are bit-identical to TILE_PL64's (the K = 1 024
+// form, which adds two half-K chains, at the accumulation-order bar: see KH below).
 //
 // Why: at batch 28 these layers are memory streams (AI 60-250 FLOP/B), and on the 64x64 plane tile they ran at 1.5-2.3 TB/s of HBM traffic.
 // In-kernel stamps: a block's life is 7 us for one 64x64x256 tile (0.9 us of index math, 3.5 us for four stages whose first operands come
