@@ -10,6 +10,7 @@ tools/pmc_frame_traffic.sh 1 --batch 28 --precision f16r --steps 6 --warmup 2 > 
 tools/pmc_mfma_busy.sh --precision f16r --batch 28 --steps 3 --warmup 1 > /dev/null 2>&1 && cp $OUT/pmc_mfma_busy.json $OUT/r05_pmc_mfma_busy_batch28_f16r.json
 BP_PMC_KERNEL=conv_igemm_bdk2 tools/pmc_traffic.sh > /dev/null 2>&1 && cp $OUT/pmc_traffic.json $OUT/r05_pmc_traffic.json
 tools/pmc_frame_traffic.sh 1 > $OUT/r05_pmc_frame_traffic.json 2>/dev/null
+tools/pmc_wave_stalls.sh --batch 28 --precision f16r --steps 4 --warmup 1 > /dev/null 2>&1 && cp $OUT/pmc_wave_stalls.json $OUT/r05_pmc_wave_stalls_batch28_f16r.json
 tools/pmc_mfma_busy.sh > /dev/null 2>&1 && cp $OUT/pmc_mfma_busy.json $OUT/r05_pmc_mfma_busy.json
 python tools/per_op.py > $OUT/r05_per_op_b1_bf16x3.txt 2>/dev/null
 python tools/per_op.py --batch 28 --precision f16r --iters 5 > $OUT/r05_per_op_b28_f16r.txt 2>/dev/null
