@@ -671,7 +671,13 @@ static void pipeline_enqueue(bp_pipeline* p, hipStream_t s) {
     const int reso = yn.reso();
     bp::ResizeTables t{p->hb, p->hk, p->ksh, p->vb, p->vk, p->ksv};
     // a1: Pillow-exact bicubic stretch to reso x reso, BGR -> RGB, /255, straight into the detector's NHWC input
+#ifdef BP_EXPERIMENTAL   // timing experiment only (WRONG results): BP_ABLATE_RESIZE=1 leaves both resize launches out of
+    // the frame (the detector sees whatever its input buffer holds) -- the upper bound of what fusing them into the stem could buy (round-4 verdict item 6; tools/ab_resize.sh)
+    static const bool no_resize = std::getenv("BP_ABLATE_RESIZE") != nullptr;
+    if (!no_resize) bp::launch_resize_bicubic(p->frames, p->batch, p->H, p->W, p->tmp, yn.input_nhwc(), nullptr, reso, reso, t, 1, s);
+#else
     bp::launch_resize_bicubic(p->frames, p->batch, p->H, p->W, p->tmp, yn.input_nhwc(), nullptr, reso, reso, t, 1, s);
+#endif
     // a3-a5: detector + decode + arg-max objectness
     // every stage writes its part of the frame's result row directly (sel[8] | pts[8] | kp[50][6]): no gather launch
     const int R = BP_RESULT_FLOATS;
