@@ -772,12 +772,14 @@ __global__ __launch_bounds__(64 * CG) void stem3x3_kernel(const ConvParams p) {
 // through an LDS tile.  fp16 operands, fp32 accumulation: the arithmetic of the mode (train_YOLO/src/convolutional_kernels.cu:268-280
 // converts the first layer's activations too); the fp32-accurate modes keep the direct convolution.
 // =====================================================================================================================
+// A block walks G consecutive groups of 128 pixels (round 5; G = groups / grid, the launcher's choice): the taps of group g + 1 are requested before group g goes through LDS, the
+// matrix cores and its stores.  One group per block was a chain of latencies -- kernel arguments, index math, the taps' round trip, three
+// barriers, the stores' acknowledgement -- per 18 KB of traffic: 174 us for a 232 MB layer at 28 frames per launch.
 __global__ __launch_bounds__(256) void stem3x3_f16_kernel(const ConvParams p) {
     constexpr int RB = 112, LDT = 36;                    // im2col row bytes; staging row floats
     __shared__ __attribute__((aligned(16))) char lds[128 * LDT * 4 > 128 * RB ? 128 * LDT * 4 : 128 * RB];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m0 = (int)blockIdx.x * 128;
     // the filters of this lane's channel (column lane & 31), k half lane >> 5 of the three k-steps: fp32 -> fp16 once per block
     f16x8 fb[3];
     {
@@ -791,16 +793,15 @@ __global__ __launch_bounds__(256) void stem3x3_f16_kernel(const ConvParams p) {
     }
     const f32x4 bias4 = *reinterpret_cast<const f32x4*>(p.bias + (tid & 1) * 16), bias4b = *reinterpret_cast<const f32x4*>(p.bias + (tid & 1) * 16 + 4),
                 bias4c = *reinterpret_cast<const f32x4*>(p.bias + (tid & 1) * 16 + 8), bias4d = *reinterpret_cast<const f32x4*>(p.bias + (tid & 1) * 16 + 12);
-    // ---- im2col rows: thread -> pixel tid >> 1, taps of parity tid & 1
     const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.in), 0, (int)min((long long)p.N * p.H * p.W * p.in_ld * 4, (long long)OOB), 0x00020000);
-    {
-        const int pix = tid >> 1;
-        const int m = min(m0 + pix, p.M - 1);            // (rows past M: a duplicate of the last pixel, not stored)
-        const int hw = p.OH * p.OW;
+    const int pix = tid >> 1;                            // thread -> pixel tid >> 1 of the group, taps of parity tid & 1
+    const int hw = p.OH * p.OW;
+    // the five taps of this thread for the group that starts at pixel m0 (rows past M: a duplicate of the last pixel, not stored)
+    auto load_taps = [&](int m0, f32x4* x) __attribute__((always_inline)) {
+        const int m = min(m0 + pix, p.M - 1);
         const int b = m / hw, rem = m - b * hw;
         const int oy = rem / p.OW, ox = rem - oy * p.OW;
-        f32x4 x[5];
 #pragma unroll
         for (int i = 0; i < 5; ++i) {
             const int t = 2 * i + (tid & 1);
@@ -809,64 +810,80 @@ __global__ __launch_bounds__(256) void stem3x3_f16_kernel(const ConvParams p) {
             const bool ok = t < 9 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
             x[i] = buf_load4(rsrcA, ok ? (unsigned)((((b * p.H + iy) * p.W + ix) * p.in_ld) * 4) : OOB, 0);
         }
-        char* const row = lds + pix * RB;
+    };
+    const int groups = (p.M + 127) / 128, G = (groups + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int g0 = (int)blockIdx.x * G;
+    f32x4 xn[5];
+    load_taps(g0 * 128, xn);
+    for (int g = 0; g < G; ++g) {
+        const int m0 = (g0 + g) * 128;
+        if (m0 >= p.M) break;                            // (block-uniform)
+        f32x4 x[5];
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int t = 2 * i + (tid & 1);
-            f32x4 v = x[i];
-            if (p.Cin < 4) v.w = 0.f;                    // (the neighbour's red: its filter entry is zero, but the last pixel of the tensor reads past it)
-            if (t < 9) *reinterpret_cast<f16x4*>(row + 8 * t) = __builtin_convertvector(v, f16x4);
-        }
-        // k 36 .. 47 of the row: zeros (12 fp16 = 24 B; the odd-tap thread writes them)
-        if (tid & 1) {
-            *reinterpret_cast<u32x2*>(row + 72) = u32x2{0u, 0u};
-            *reinterpret_cast<u32x4*>(row + 80) = u32x4{0u, 0u, 0u, 0u};
-        }
-    }
-    __syncthreads();
-    // ---- 32 pixels x 32 channels per wave
-    f32x16 acc;
+        for (int i = 0; i < 5; ++i) x[i] = xn[i];
+        if (g + 1 < G && m0 + 128 < p.M) load_taps(m0 + 128, xn);     // the next group's taps travel while this one is processed
+        // ---- im2col rows
+        {
+            char* const row = lds + pix * RB;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    {
-        const char* const arow = lds + (32 * wave + (lane & 31)) * RB + (lane >> 5) * 16;
-#pragma unroll
-        for (int ks = 0; ks < 3; ++ks)
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(arow + 32 * ks), fb[ks], acc, 0, 0, 0);
-    }
-    __syncthreads();                                     // the im2col rows are dead: the tile is staged over them
-    float* const S = reinterpret_cast<float*>(lds);
-#pragma unroll
-    for (int r = 0; r < 16; ++r)
-        S[(32 * wave + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDT + (lane & 31)] = acc[r];
-    __syncthreads();
-    // ---- stores: thread -> pixel tid >> 1, channels 16 (tid & 1) .. + 15
-    const int pix = tid >> 1, m = m0 + pix, c0 = (tid & 1) * 16;
-    if (m < p.M && c0 < p.Cout) {
-        const float* srow = S + pix * LDT + c0;
-        f32x4 v[4] = {*reinterpret_cast<const f32x4*>(srow) + bias4, *reinterpret_cast<const f32x4*>(srow + 4) + bias4b,
-                      *reinterpret_cast<const f32x4*>(srow + 8) + bias4c, *reinterpret_cast<const f32x4*>(srow + 12) + bias4d};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (p.act == ACT_LEAKY) {
-                v[q].x = v[q].x > 0.f ? v[q].x : 0.1f * v[q].x; v[q].y = v[q].y > 0.f ? v[q].y : 0.1f * v[q].y;
-                v[q].z = v[q].z > 0.f ? v[q].z : 0.1f * v[q].z; v[q].w = v[q].w > 0.f ? v[q].w : 0.1f * v[q].w;
-            } else if (p.act == ACT_RELU) {
-                v[q].x = v[q].x > 0.f ? v[q].x : 0.f; v[q].y = v[q].y > 0.f ? v[q].y : 0.f;
-                v[q].z = v[q].z > 0.f ? v[q].z : 0.f; v[q].w = v[q].w > 0.f ? v[q].w : 0.f;
+            for (int i = 0; i < 5; ++i) {
+                const int t = 2 * i + (tid & 1);
+                f32x4 v = x[i];
+                if (p.Cin < 4) v.w = 0.f;                    // (the neighbour's red: its filter entry is zero, but the last pixel of the tensor reads past it)
+                if (t < 9) *reinterpret_cast<f16x4*>(row + 8 * t) = __builtin_convertvector(v, f16x4);
+            }
+            // k 36 .. 47 of the row: zeros (12 fp16 = 24 B; the odd-tap thread writes them)
+            if (tid & 1) {
+                *reinterpret_cast<u32x2*>(row + 72) = u32x2{0u, 0u};
+                *reinterpret_cast<u32x4*>(row + 80) = u32x4{0u, 0u, 0u, 0u};
             }
         }
-        const long long e = (long long)m * p.out_ld + c0;
-        if (!(p.out16 && p.skip_f32)) {
+        __syncthreads();
+        // ---- 32 pixels x 32 channels per wave
+        f32x16 acc;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(p.out + e + 4 * q) = v[q];
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        {
+            const char* const arow = lds + (32 * wave + (lane & 31)) * RB + (lane >> 5) * 16;
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(arow + 32 * ks), fb[ks], acc, 0, 0, 0);
         }
-        if (p.out16) {                                   // (one fp16 plane: RNE of the fp32 value, as every producer writes it)
-            const f16x4 h0 = __builtin_convertvector(v[0], f16x4), h1 = __builtin_convertvector(v[1], f16x4),
-                        h2 = __builtin_convertvector(v[2], f16x4), h3 = __builtin_convertvector(v[3], f16x4);
-            *reinterpret_cast<f16x8*>(p.out16 + e) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-            *reinterpret_cast<f16x8*>(p.out16 + e + 8) = __builtin_shufflevector(h2, h3, 0, 1, 2, 3, 4, 5, 6, 7);
+        __syncthreads();                                     // the im2col rows are dead: the tile is staged over them
+        float* const S = reinterpret_cast<float*>(lds);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            S[(32 * wave + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDT + (lane & 31)] = acc[r];
+        __syncthreads();
+        // ---- stores: thread -> pixel tid >> 1, channels 16 (tid & 1) .. + 15
+        const int m = m0 + pix, c0 = (tid & 1) * 16;
+        if (m < p.M && c0 < p.Cout) {
+            const float* srow = S + pix * LDT + c0;
+            f32x4 v[4] = {*reinterpret_cast<const f32x4*>(srow) + bias4, *reinterpret_cast<const f32x4*>(srow + 4) + bias4b,
+                          *reinterpret_cast<const f32x4*>(srow + 8) + bias4c, *reinterpret_cast<const f32x4*>(srow + 12) + bias4d};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (p.act == ACT_LEAKY) {
+                    v[q].x = v[q].x > 0.f ? v[q].x : 0.1f * v[q].x; v[q].y = v[q].y > 0.f ? v[q].y : 0.1f * v[q].y;
+                    v[q].z = v[q].z > 0.f ? v[q].z : 0.1f * v[q].z; v[q].w = v[q].w > 0.f ? v[q].w : 0.1f * v[q].w;
+                } else if (p.act == ACT_RELU) {
+                    v[q].x = v[q].x > 0.f ? v[q].x : 0.f; v[q].y = v[q].y > 0.f ? v[q].y : 0.f;
+                    v[q].z = v[q].z > 0.f ? v[q].z : 0.f; v[q].w = v[q].w > 0.f ? v[q].w : 0.f;
+                }
+            }
+            const long long e = (long long)m * p.out_ld + c0;
+            if (!(p.out16 && p.skip_f32)) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(p.out + e + 4 * q) = v[q];
+            }
+            if (p.out16) {                                   // (one fp16 plane: RNE of the fp32 value, as every producer writes it)
+                const f16x4 h0 = __builtin_convertvector(v[0], f16x4), h1 = __builtin_convertvector(v[1], f16x4),
+                            h2 = __builtin_convertvector(v[2], f16x4), h3 = __builtin_convertvector(v[3], f16x4);
+                *reinterpret_cast<f16x8*>(p.out16 + e) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+                *reinterpret_cast<f16x8*>(p.out16 + e + 8) = __builtin_shufflevector(h2, h3, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
         }
+        __syncthreads();                                     // the staging tile is read: the next group's rows go over it
     }
 }
 
@@ -887,7 +904,13 @@ bool conv_stem3_eligible(const ConvParams& p) {
 static void launch_stem3(const ConvParams& p, hipStream_t s) {
     BP_CHECK(conv_stem3_eligible(p) && p.splits == 1, "not a 3x3 / stride-1 / packed-RGB stem");
     if (stem3_f16_wanted(p)) {
-        const dim3 g((p.M + 127) / 128);
+        // groups per block: 8 (one launch at a time, 28 frames per launch: 190 us with one group per block, 142 / 126 / 116 / 121 with 2 / 4 / 8 / 16;
+        // BP_STEM_G for the sweep), fewer where that would leave less than two blocks per CU (one frame: 2 groups, 9.4 us)
+        static const int g_env = std::getenv("BP_STEM_G") ? std::atoi(std::getenv("BP_STEM_G")) : 0;
+        const int groups = (p.M + 127) / 128;
+        int per = g_env > 0 ? g_env : 8;
+        while (per > 1 && groups / per < 512) --per;
+        const dim3 g((groups + per - 1) / per);
         if (g_conv_prof) hipExtLaunchKernelGGL(stem3x3_f16_kernel, g, dim3(256), 0, s, g_conv_prof->e0, g_conv_prof->e1, 0, p);
         else hipLaunchKernelGGL(stem3x3_f16_kernel, g, dim3(256), 0, s, p);
         return;
