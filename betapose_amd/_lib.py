@@ -86,6 +86,7 @@ PROTOTYPES = {
     "bp_pipeline_set_fixed_box": (C.c_int, [vp, vp]),
     "bp_pipeline_run": (C.c_int, [vp, C.c_int, vp]),
     "bp_pipeline_prepare": (C.c_int, [vp]),
+    "bp_pipeline_latency_faults": (C.c_int, [vp]),
     "bp_heatmap_argmax": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "bp_solve_pnp": (C.c_int, [vp, vp, C.c_int, vp, vp, vp]),
     "bp_solve_pnp_refined": (C.c_int, [vp, vp, C.c_int, vp, vp, vp]),

@@ -63,6 +63,7 @@ struct bp_pipeline {
     hipGraphExec_t exec = nullptr;
     hipStream_t cap_stream = nullptr;
     unsigned ver_y = 0, ver_k = 0;   // engine plan versions the graph was captured with
+    int latency_faults = 0;          // frames re-run because the latency mode's placement check failed (bp_pipeline_latency_faults)
     ~bp_pipeline() {
         if (exec) (void)hipGraphExecDestroy(exec);
         if (graph) (void)hipGraphDestroy(graph);
@@ -420,6 +421,7 @@ int bp_kpd_fused_launches(bp_kpd* k, int batch, int* launches) {
 int bp_yolo_xcd_errors(bp_yolo* y, int* count, void* stream) {
     BP_TRY
     BP_CHECK(y && count, "null argument");
+    BP_HIP(hipSetDevice(y->device));
     *count = y->net->take_xcd_errors((hipStream_t)stream);
     return 0;
     BP_CATCH
@@ -427,6 +429,7 @@ int bp_yolo_xcd_errors(bp_yolo* y, int* count, void* stream) {
 int bp_kpd_xcd_errors(bp_kpd* k, int* count, void* stream) {
     BP_TRY
     BP_CHECK(k && count, "null argument");
+    BP_HIP(hipSetDevice(k->device));
     *count = k->net->take_xcd_errors((hipStream_t)stream);
     return 0;
     BP_CATCH
@@ -784,18 +787,38 @@ int bp_pipeline_prepare(bp_pipeline* p) {
     BP_CATCH
 }
 
-int bp_pipeline_run(bp_pipeline* p, int use_graph, void* stream) {
-    BP_TRY
-    hipStream_t s = (hipStream_t)stream;
+static void pipeline_launch(bp_pipeline* p, int use_graph, hipStream_t s) {
     if (!use_graph) {
         pipeline_enqueue(p, s);
-        return 0;
+        return;
     }
     pipeline_capture(p);
     BP_HIP(hipGraphLaunch(p->exec, s));
+}
+
+int bp_pipeline_run(bp_pipeline* p, int use_graph, void* stream) {
+    BP_TRY
+    BP_CHECK(p, "null argument");
+    hipStream_t s = (hipStream_t)stream;
+    pipeline_launch(p, use_graph, s);
+    // Lone-frame latency mode (bp_*_set_prefetch): a launch that found a K slice on the wrong XCD raised the engine's error word and
+    // left its tile unstored, so the frame's record is void.  The mode is one-frame-at-a-time by definition: wait for the frame here,
+    // read the words, and on a fault clear them, switch the mode off for both engines and run the SAME frame again on the ordinary
+    // hand-off -- whoever drives the pipeline (FramePipeline.run, StreamedRunner, a C caller) gets a valid record or an error.
+    if (p->y->net->prefetch() || p->k->net->prefetch()) {
+        BP_HIP(hipSetDevice(p->y->device));
+        const int bad = p->y->net->take_xcd_errors(s) + p->k->net->take_xcd_errors(s);
+        if (bad) {
+            ++p->latency_faults;
+            p->y->net->set_prefetch(false);
+            p->k->net->set_prefetch(false);
+            pipeline_launch(p, use_graph, s);
+        }
+    }
     return 0;
     BP_CATCH
 }
+int bp_pipeline_latency_faults(const bp_pipeline* p) { return p ? p->latency_faults : -1; }
 
 // ------------------------------------------------------------------ xcd mode (mega.inc): prototype entry point, experimental library only
 #ifdef BP_EXPERIMENTAL

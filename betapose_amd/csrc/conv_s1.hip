@@ -332,9 +332,11 @@ static bool s1_plan(const ConvParams& p, long long M, int res_bytes, S1Args* out
     const int bpc = force_bpc ? force_bpc : (nch <= 8 ? 2 : 1);
     const int budget = (160 * 1024 - 192) / bpc;
     a.rq = res_bytes ? 2 : 0;
-    int nl = (budget - stg_b - bias_b - a.rq * a.rbuf) / tile_b;
-    if (nl < 2 && a.rq == 2) { a.rq = 1; nl = (budget - stg_b - bias_b - a.rq * a.rbuf) / tile_b; }
-    if (nl < 2) return false;     // (the hand-over needs two buffers: tile k + 1 lands while tile k is read)
+    const int nl = (budget - stg_b - bias_b - a.rq * a.rbuf) / tile_b;
+    // the hand-over needs two buffers of each kind: tile k + 1 (and its skip-connection rows) land while tile k is read.  A single
+    // skip-connection buffer would be refilled behind barrier B_k while the compute waves still read it in tile k's epilogue (the
+    // round-5 advisor's finding on the old rq == 1 fall-back, reachable through BP_S1_BPC): such a layer stays on the plane tile
+    if (nl < 2) return false;
     // look-ahead: TWO tiles.  More is slower (measured at batch 28, fp16 skip connections: 52x52 256 -> 128 17.2 us with two tiles, 18.0 with
     // three, 19.6 with four; 256 -> 1024 15.5 / 16.4 / 16.1): a block has 4-9 tiles in all, so deep look-ahead is every block asking for most of
     // its input at once -- the first tiles queue behind everybody's later ones
@@ -355,6 +357,7 @@ bool conv_s1_eligible(const ConvParams& p, long long M) {
     if (!(p.ksize == 1 && p.pad == 0 && (p.stride == 1 || p.stride == 2) && p.Kpad == p.Cin && p.store_mode == ST_NHWC)) return false;
     const int nch = p.nchunks;
     if (!(nch == 2 || nch == 4 || nch == 8 || nch == 12 || nch == 16 || nch == 32)) return false;      // K = 64, 128, 256, 384, 512, 1 024 (the instantiated forms)
+    if (M < 2048 || p.pool_out != nullptr) return false;       // (the cheap rejections first: choose_launch asks for every fp16 convolution of every eager pass)
     // K = 1 024 (64 columns per block, two K halves per column half), measured at batch 28 against the 64x64 plane tile on one box: 1 024 -> 256
     // ties (16.0 against 16.2 us), 13x13 1 024 -> 512 loses (17.4 against 16.3), 1 024 -> 2 048 / stride 2 wins (30.2 against 36.5): the wide
     // layers only.  (K = 512: 512 -> 128 16.7 against 20.8 us, 26x26 512 -> 256 17.2 against 18.8 -- all of them.)  BP_S1_K512=1 takes every
@@ -362,7 +365,6 @@ bool conv_s1_eligible(const ConvParams& p, long long M) {
     const bool k1024_all = std::getenv("BP_S1_K512") != nullptr;
     if (nch == 32 && p.CoutPad < 1024 && !k1024_all) return false;
     if (p.CoutPad < S1_BN || (p.Cout & 3) || (p.out_ld & 3) || p.OH * p.OW < S1_BM) return false;
-    if (M < 2048 || p.pool_out != nullptr) return false;
     if (p.res && ((p.res_ld & 7) != 0)) return false;
     if (p.res_scale && !p.res) return false;
     if (p.out16 != nullptr && p.out_np != 1) return false;

@@ -448,7 +448,8 @@ static bool plh_ok(const ConvParams& c) {
 static void choose_pl(const ConvParams& c, long long M, int mode, int sk_max, int* tile, int* splits) {
     for (const PlanEntry& e : plan_file_entries())
         if (e.M == (int)M && e.CoutPad == c.CoutPad && e.nchunks == c.nchunks && conv_tile_is_pl(e.tile) &&
-            (!conv_tile_is_plh(e.tile) || plh_ok(c))) { *tile = e.tile; *splits = e.splits; return; }
+            (!conv_tile_is_plh(e.tile) || plh_ok(c)) &&
+            (e.tile != TILE_S1 || (e.splits == 1 && conv_s1_eligible(c, M)))) { *tile = e.tile; *splits = e.splits; return; }   // (a plan-file row naming the streaming 1x1 kernel for a layer it cannot run is ignored, not a failed launch)
     for (const PlanEntry* e = (mode == PREC_F16 ? kPlanPL1 : kPlanPL3); e->M != 0; ++e)   // tables end with a zero row
         if (e->M == (int)M && e->CoutPad == c.CoutPad && e->nchunks == c.nchunks &&
             (!conv_tile_is_plh(e->tile) || plh_ok(c))) { *tile = e->tile; *splits = e->splits; return; }     // (a 3x3 row also matches stride-2 / 1x1 layers of the same K)
@@ -558,6 +559,7 @@ static void choose_launch(const Op& op, int batch, int force_tile, int sk_target
     int s = 1;
     if (mode != PREC_F32) {
         choose_h16(c, M, mode, sk_max, &t, &s, lone);
+        if (t == TILE_S1 && op.pool_out) t = TILE_PL64;     // (a plan-file row: the SE pool rides in the 64-row epilogue of the plane tile only)
         // round 5: the 1x1 layers of the batched fp16 runs (one K slice on a conv_pl tile, no SE pool in the epilogue) on the persistent
         // streaming kernel (conv_s1.hip); BP_NO_S1=1: the plane tiles as before (A/B runs)
         static const bool s1_off = std::getenv("BP_NO_S1") != nullptr;
@@ -1173,6 +1175,10 @@ void Net::run_op(const Op& op, int batch, hipStream_t s) {
             prepare_conv(ops_[g.pre], batch, a, ta);
             prepare_conv(ops_[g.c3], batch, b, tb);
             if (role == FR_HEAD3) prepare_conv(ops_[g.post], batch, c, tc);
+            // in-situ stamps: prepare_conv sized the last member's region by ITS OWN tile grid; the fused kernel stamps one slot per
+            // patch block (stamps[blockIdx.x * 8 + k]), which can be far more (28 x 676 patches against 4 732 tiles) and would run
+            // into the following convolutions' regions -- no marks for this launch unless its grid fits
+            if (stamps_ && conv_fused_blocks(a, b, role == FR_HEAD3 ? &c : nullptr) > stamp_slots_) b.stamps = c.stamps = nullptr;
             launch_conv_fused(a, b, role == FR_HEAD3 ? &c : nullptr, s);
             return;
         }

@@ -47,6 +47,7 @@ class FramePipeline:
                                                  self.results.data_ptr(),
                                                  self.heatmaps.data_ptr() if keep_heatmaps else None, C.byref(h)))
         self._h = h
+        self._faults_seen = 0
 
     def __del__(self):
         try:
@@ -68,6 +69,12 @@ class FramePipeline:
         """Launch the device part on ``stream`` (default: torch's current stream).  ``self.frames`` must
         already hold the batch; ``self.results`` is valid once the stream reaches this point."""
         _lib.check(_lib.lib().bp_pipeline_run(self._h, int(self.use_graph), stream if stream is not None else _lib.current_stream()))
+        if any(getattr(m, "_latency_mode", False) for m in (self.det, self.pose)):
+            self._latency_check()
+
+    def latency_faults(self) -> int:
+        """Frames this pipeline ran twice because the lone-frame latency mode's placement check failed (bp_pipeline_latency_faults)."""
+        return int(_lib.lib().bp_pipeline_latency_faults(self._h))
 
     def prepare(self):
         """Set-up: build the frame's hipGraph now (capture + instantiate, nothing executes) instead of inside the first ``enqueue``."""
@@ -86,18 +93,17 @@ class FramePipeline:
             f = f.unsqueeze(0)
         self.frames.copy_(f, non_blocking=True)
         self.enqueue()
-        rec = self.results.cpu().numpy()
-        if self._latency_check():        # the latency mode's placement check failed: its results are void -- same frame, ordinary hand-off
-            self.enqueue()
-            rec = self.results.cpu().numpy()
-        return rec
+        return self.results.cpu().numpy()
 
     def _latency_check(self) -> bool:
-        """Lone-frame latency mode only (Darknet.set_prefetch): True when a launch of this frame reported a K slice on the wrong XCD.
-        The mode is then switched off for both engines (the graph is rebuilt on the next enqueue) and stays off."""
-        bad = sum(m.xcd_errors() for m in (self.det, self.pose) if hasattr(m, "xcd_errors"))
-        if not bad:
+        """Lone-frame latency mode only (Darknet.set_prefetch).  ``bp_pipeline_run`` itself waits for the frame in that mode, reads the
+        engines' placement error words and -- when a launch reported a K slice on the wrong XCD, i.e. left a tile unstored -- switches
+        the mode off and runs the same frame again, whichever caller drove it (``run``, ``StreamedRunner``, a bare ``enqueue``).  This
+        mirrors that into the Python objects: a warning, and the engines' ``_latency_mode`` flags off (the mode stays off)."""
+        n = self.latency_faults()
+        if n == self._faults_seen:
             return False
+        self._faults_seen = n
         import warnings
         warnings.warn("betapose_amd: block placement is not the round robin the lone-frame latency mode relies on; mode switched off, frame re-run")
         for m in (self.det, self.pose):

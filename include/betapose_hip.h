@@ -203,6 +203,10 @@ float* bp_pipeline_results(bp_pipeline* p);     /* device [batch][BP_RESULT_FLOA
 float* bp_pipeline_heatmaps(bp_pipeline* p);    /* device [batch][50][80][64] */
 int bp_pipeline_set_fixed_box(bp_pipeline* p, const float* box_xyxy_or_null);
 int bp_pipeline_run(bp_pipeline* p, int use_graph, void* stream);
+/* While either engine is in the lone-frame latency mode (bp_*_set_prefetch) bp_pipeline_run waits for the frame, reads the engines'
+ * placement error words and, on a fault, clears them, switches the mode off for both engines and runs the same frame again on the
+ * ordinary hand-off: every caller gets a valid record.  bp_pipeline_latency_faults = frames re-run that way so far (-1: null). */
+int bp_pipeline_latency_faults(const bp_pipeline* p);
 /* Set-up step: capture and instantiate the frame's hipGraph now (records the launches, executes nothing), so that the first
  * bp_pipeline_run(use_graph = 1) is a plain graph launch.  Called again after a precision / policy change it rebuilds the graph.
  * (It creates the pipeline's capture stream: call it AFTER the caller's own streams have launched something -- HIP binds streams to

@@ -75,3 +75,23 @@ def test_two_rank_broadcast_and_gather(tmp_path):
     outs = [p.communicate(timeout=180)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "GATHER_OK" in outs[0]
+
+
+def test_bench_under_the_launcher_fails_loudly_without_a_gpu():
+    """The driver's scaling command on a box with no GPU (this container): every rank must stop at the product's own loud error --
+    no CPU fall-back, no rendezvous left hanging, nothing that looks like a bench line on stdout.  (With a GPU the same command is
+    covered by tests/test_gpu_multirank.py: 1 rank == the plain line, 2 ranks over gloo, 2 ranks over RCCL where 2 GPUs exist.)"""
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("a GPU is visible: the gpu-marked launcher tests cover this command")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, BP_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert "BetaposeHipError" in r.stderr or "no GPU" in r.stderr or "HIP" in r.stderr, r.stderr[-2000:]

@@ -45,6 +45,24 @@ def test_bench_two_ranks(cuda):
     assert out["rccl"]["weight_broadcast_ms"] > 0 and 0 < out["latency_ms"]["p50"] <= out["latency_ms"]["p95"]
 
 
+def test_bench_one_rank_under_the_launcher_equals_the_plain_line(cuda):
+    """Round-5 verdict item 8: the driver's SCALE run starts with N = 1 -- `python bench.py --gpus 1` -- and continues with the launcher.
+    The launcher's N = 1 (WORLD_SIZE 1: no process group, no `rccl` object) must be the same measurement as the plain line: same
+    schema, same step count, frames/s within the run-to-run noise of a 40-step region."""
+    flags = ["--gpus", "1", "--steps", "40", "--warmup", "10", "--no-cpu-baseline", "--no-roofline", "--no-served-legs",
+             "--no-flip-rate", "--no-side-runs", "--other-modes", "", "--repeats", "1"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    plain = subprocess.run([sys.executable, "bench.py"] + flags, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert plain.returncode == 0, plain.stdout[-3000:] + plain.stderr[-3000:]
+    a = json.loads([l for l in plain.stdout.splitlines() if l.startswith("{")][0])
+    r = _launch(1, ["bench.py"] + flags, backend="nccl")          # exactly the driver's command shape, backend left at its default
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    b = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert a["n_gpus"] == b["n_gpus"] == 1 and "rccl" not in a and "rccl" not in b
+    assert set(a) == set(b) and a["config"] == b["config"] and a["records_gathered"] == b["records_gathered"] == 40
+    assert abs(a["value"] - b["value"]) / a["value"] < 0.15, (a["value"], b["value"])
+
+
 def test_bench_two_ranks_rccl(cuda):
     """First contact with a multi-GPU node: the SAME command the driver's scaling run issues, collectives over RCCL
     (backend nccl, one rank per GPU).  Skips on a one-GPU box -- there the gloo test above covers everything but the

@@ -273,6 +273,38 @@ def test_latency_mode_placement_fault_raises_the_error_word_not_a_trap(yolo, kpd
     assert np.array_equal(pipe.run(frame), base)
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_latency_mode_fault_is_caught_on_every_driving_path(yolo, kpd, cuda, monkeypatch, use_graph):
+    """Round-5 advisor finding: only ``FramePipeline.run`` polled the placement error word, so a bare ``enqueue`` (what StreamedRunner,
+    bench.py and C callers of bp_pipeline_run use) returned a record with an unstored tile.  bp_pipeline_run now reads the words
+    itself in the latency mode and re-runs a faulted frame with the mode off: same record as the ordinary path, fault counted."""
+    import warnings
+    from betapose_amd.pipeline import FramePipeline
+    frame = helpers.frames(1)[0]
+    pipe = FramePipeline(yolo, kpd, 480, 640, batch=1, use_graph=use_graph)
+    base = pipe.run(frame).copy()
+    try:
+        monkeypatch.setenv("BP_XCD_FAULT", "1")
+        yolo.set_prefetch(True)
+        kpd.set_prefetch(True)
+        pipe.frames.copy_(torch.from_numpy(frame).unsqueeze(0))
+        pipe.results.zero_()
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            pipe.enqueue()                                      # the bare launch path
+        rec = pipe.results.cpu().numpy()
+        assert pipe.latency_faults() == 1
+        assert any("latency mode" in str(m.message) for m in w)
+        assert np.array_equal(rec, base)
+        assert not yolo._latency_mode and not kpd._latency_mode
+        assert yolo.xcd_errors() == 0 and kpd.xcd_errors() == 0
+    finally:
+        monkeypatch.delenv("BP_XCD_FAULT", raising=False)
+        yolo.set_prefetch(False)
+        kpd.set_prefetch(False)
+    assert np.array_equal(pipe.run(frame), base)
+
+
 # ---- fp16-MFMA mode (BASELINE configs[2]: batched inference, 28 crops / batch, fp16 MFMA conv path).  Operands of
 # every conv with Cin % 32 == 0 are rounded to fp16, accumulation and activations stay fp32.  Stated tolerances against
 # the fp32 oracle: heat-maps <= 1e-2 absolute (measured 1.4e-3 at a heat-map scale of 2.3), box centres <= 0.25 px,
