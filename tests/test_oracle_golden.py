@@ -147,3 +147,37 @@ def test_get_prediction_planted_cases_match_reference(edges):
     np.testing.assert_array_equal(a2, edges["gpe_preds_hm"])
     np.testing.assert_allclose(b2, edges["gpe_preds_img"], rtol=0, atol=1e-4)
     np.testing.assert_array_equal(c2, edges["gpe_maxval"])
+
+
+# ---- BASELINE configs[0] at its own size: tests/golden/sweep64.npz holds compact records of 64 frames through the reference's own stage
+# classes (tools/make_golden_sweep64.py).  The oracle is pinned to a spread of them here (the whole 64 run through the HIP pipeline in
+# tests/test_gpu_sweep64.py); ~1.5 s of torch-CPU per frame keeps it to six
+@pytest.mark.parametrize("i", [4, 17, 29, 41, 52, 63])
+def test_oracle_matches_reference_on_sweep64_frames(i):
+    g = helpers.golden("sweep64.npz")
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    blocks = helpers.yolo_blocks()
+    convs = W.split_darknet_stream(blocks, helpers.yolo_stream())
+    from betapose_amd import synth
+    fr = synth.synth_frame(helpers.FRAME_SEED + i)
+    pred = yolo_ref.darknet_forward(blocks, convs, helpers.yolo_input_from_frame(fr))
+    assert int(torch.argmax(pred[0, :, 4])) == int(g["obj_argmax"][i])
+    np.testing.assert_allclose(torch.topk(pred[0, :, 4], 2).values.numpy(), g["obj_top2"][i], rtol=0, atol=2e-6)
+    dets = yolo_ref.write_results(pred, 0.01, 80)
+    np.testing.assert_allclose(dets.numpy()[0], g["det_row"][i], rtol=1e-5, atol=1e-4)
+    boxes, scores = yolo_ref.rescale_boxes(dets, torch.tensor([[640.0, 480.0, 640.0, 480.0]]), 416)
+    np.testing.assert_allclose(boxes.numpy()[0], g["boxes"][i], rtol=1e-5, atol=1e-4)
+    inps, pt1, pt2 = post_ref.crop_from_dets_frame(fr, torch.from_numpy(g["boxes"][i:i + 1]))
+    np.testing.assert_array_equal(pt1.numpy()[0], g["pt1"][i])
+    np.testing.assert_array_equal(pt2.numpy()[0], g["pt2"][i])
+    hm = kpd_ref.fastpose_forward(helpers.kpd_state_dict(), inps)
+    flat = hm.view(50, -1)
+    sure = g["kp_margin"][i] > 4e-5          # (the restatement and the reference module differ by <= 2e-5 per heat-map value)
+    assert np.array_equal(flat.argmax(1).numpy()[sure], g["kp_idx"][i].astype(np.int64)[sure])
+    np.testing.assert_allclose(flat.max(1).values.numpy(), g["kp_max"][i], rtol=0, atol=2e-5)
+    _, preds_img, preds_scores = post_ref.get_prediction(hm, pt1, pt2)
+    np.testing.assert_allclose(preds_img.numpy()[0][sure], g["preds_img"][i][sure], rtol=1e-6, atol=1e-4)
+    res = post_ref.pose_nms(boxes, scores, torch.from_numpy(g["preds_img"][i:i + 1]), torch.from_numpy(g["preds_scores"][i:i + 1, :, None]))
+    assert len(res) == int(g["nms_n"][i]) == 1
+    np.testing.assert_allclose(res[0]["keypoints"].numpy(), g["nms_kp"][i], rtol=1e-6, atol=1e-5)
+    np.testing.assert_allclose(res[0]["kp_score"].numpy()[:, 0], g["nms_score"][i], rtol=1e-6, atol=1e-6)
