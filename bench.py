@@ -356,6 +356,8 @@ def roofline(det, pose, batch):
             return "bp::conv_fused_kernel<*>"                              # whole residual / bottleneck block in one launch (conv_fused.hip)
         if tile == 26:
             return "bp::conv_s1_kernel<*>"                                 # 1x1 layers of the batched fp16 runs: persistent streaming kernel (conv_s1.hip; * = K chunks, K halves)
+        if tile == 27:
+            return "bp::conv_p3_kernel<*>"                                 # 3x3 / stride-1 layers of the batched fp16 runs: persistent kernel (conv_p3.hip; * = map width, halo rows, skip-connection format)
         if tile == 24:
             return "bp::conv_igemm_bdk2_kernel"                            # filters direct, two K groups inside an eight-wave block
         if tile in (7, 8, 9):

@@ -172,7 +172,8 @@ enum ConvTile : int { TILE_64x64 = 0, TILE_128x64 = 1, TILE_W64_1x1 = 2, TILE_W6
                       TILE_BD_K2 = 24,      // the filters-direct 64x64 tile with 8 waves = 2 K groups of 2x2 waves (conv_igemm.hip, any kernel size / stride)
                       TILE_PLH128 = 25,     // conv_pl.hip 128x128 with the activations of a 3x3 / stride-1 layer from an LDS-resident halo (fp16; round 4)
                       TILE_S1 = 26,         // conv_s1.hip: the 1x1 layers of the batched fp16 runs as a persistent streaming kernel (32-row M-tiles resident in LDS, 128-column passes; round 5)
-                      TILE_LAST = 26,       // (the last id a policy may force)
+                      TILE_P3 = 27,         // conv_p3.hip: the 3x3 / stride-1 layers of the batched fp16 runs as a persistent kernel (128 pixels x 32 columns per wave, filter fragments global -> registers, zero-padded halo in LDS with the taps as instruction immediates, register-only epilogue; round 6)
+                      TILE_LAST = 27,       // (the last id a policy may force)
                       TILE_FUSED = 40 };    // reporting only (Net::profile): the op is the last member of a block fused into one launch (conv_fused.hip)
 
 // when non-null, launch_conv brackets the implicit-GEMM kernel itself (not the split-K reduce) with these events
@@ -201,6 +202,8 @@ bool conv_plh_eligible(const ConvParams& p);  // TILE_PLH128 can run the layer (
 bool conv_pl_eligible(const ConvParams& p);   // planes + wpl present, Cin % 32 == 0, taps fit the 32-bit mask
 bool conv_s1_eligible(const ConvParams& p, long long M);   // TILE_S1 can run the layer at M output pixels (fp16, 1x1 / stride 1 or 2, NHWC store, 64 <= K <= 1024, N >= 128, M >= 2048)
 void launch_conv_s1(const ConvParams& p, hipStream_t s);   // conv_s1.hip
+bool conv_p3_eligible(const ConvParams& p, long long M);   // TILE_P3 can run the layer at M output pixels (fp16, 3x3 / stride 1 / pad 1, NHWC store, W one of 13 / 16 / 26 / 32 / 52, M >= 4096)
+void launch_conv_p3(const ConvParams& p, hipStream_t s);   // conv_p3.hip
 // filters [CoutPad][Kpad] fp32 -> conv_pl.hip's LDS image, np = 1 (fp16) or 3 (exact bf16 split)
 void launch_pack_wpl(const float* in, unsigned short* out, int CoutPad, int Kpad, int Cin, int ksize, int np, hipStream_t s);
 // fp32 NHWC view -> its operand planes (producers that are not convolutions; tests)

@@ -585,7 +585,7 @@ int bp_conv2d_planes(const float* d_in, int N, int H, int W, int Cin, const floa
         sp = 1;
         while (blocks * sp < 512 && p.nchunks / (sp + 1) >= 4 && sp < 64) ++sp;
     }
-    if (t == bp::TILE_S1) sp = 1;     // (a persistent grid: no K slices)
+    if (t == bp::TILE_S1 || t == bp::TILE_P3) sp = 1;     // (a persistent grid: no K slices)
     int per = 0;
     bp::conv_split_plan(p, t, sp, &sp, &per);
     p.splits = sp; p.chunks_per_split = per;

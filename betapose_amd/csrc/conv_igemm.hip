@@ -947,7 +947,7 @@ int conv_grid_blocks(const ConvParams& q) {
 
 int conv_tile_bm(int tile) {
     switch (tile) {
-        case TILE_128x64: case TILE_W64_2x1: case TILE_W64_2x2: case TILE_PL128: case TILE_PL128x64: case TILE_PL128S: case TILE_PLH128: return 128;
+        case TILE_128x64: case TILE_W64_2x1: case TILE_W64_2x2: case TILE_PL128: case TILE_PL128x64: case TILE_PL128S: case TILE_PLH128: case TILE_P3: return 128;
         case TILE_PL256x128: return 256;
         case TILE_S1: return 32;
         default: return 64;
@@ -955,7 +955,7 @@ int conv_tile_bm(int tile) {
 }
 int conv_tile_bn(int tile) {
     switch (tile) {
-        case TILE_W64_1x2: case TILE_W64_2x2: case TILE_PL128: case TILE_PL256x128: case TILE_PL128S: case TILE_HALO128: case TILE_PLH128: case TILE_S1: return 128;
+        case TILE_W64_1x2: case TILE_W64_2x2: case TILE_PL128: case TILE_PL256x128: case TILE_PL128S: case TILE_HALO128: case TILE_PLH128: case TILE_S1: case TILE_P3: return 128;
         default: return 64;
     }
 }

@@ -1,0 +1,381 @@
+// The 3x3 / stride-1 convolutions of the BATCHED fp16 runs (BASELINE configs[2]: 28 frames per launch) as a PERSISTENT kernel (round 6).
+//
+// Same contract as conv_pl.hip's halo tile (TILE_PLH128) for the layers it takes (3x3, stride 1, pad 1, NHWC store; bias / LeakyReLU / ReLU /
+// skip connection before or after the activation; fp16 plane and / or fp32 tensor out; yolo/darknet.py:240-259 + the shortcut of :338-340,
+// SE_Resnet.py:12-14 conv2), same operands (the producer's fp16 plane, conv_pl.hip's packed filter image), the same MFMA sequence per output
+// element ((32-channel group, tap, k-step) in order, bias added to the finished fp32 sum) -- so its results are bit-identical to TILE_PLH128's.
+//
+// Why (round-5 verdict item 1; profiles/r05_per_op_b28_f16r.txt, r05_pmc_mfma_busy_batch28_f16r.json): at batch 28 these layers are the
+// compute-bound class (AI 740-2300) and ran at 25-33 % of the fp16 matrix roof.  A block of the halo plane tile lives ~25 us of which its 36-144
+// stages are 10-20: index math, first operands cold, an LDS-staged epilogue -- and inside the K loop every 8 MFMAs of a wave sit behind a
+// block-wide barrier, two filter LDS-DMAs (60-180 cycles of issue each, in order) and eight fragment reads (measured per stage: ~840 cycles
+// with one wave per SIMD, ~1 280 with three, for 256 cycles of matrix work).  The fp32-accurate halo kernel (conv_halo.hip) drives TWICE the matrix
+// work per second on the same layers with a different skeleton -- filter fragments global -> registers, one barrier per channel group -- so
+// this kernel is that skeleton for fp16 planes, made persistent:
+//   * block = 128 consecutive output pixels x 128 columns, four waves, each ALL 128 pixels x 32 columns (four 32x32 MFMA tiles): a filter
+//     fragment (global -> registers, three-deep ring two taps ahead, conv_pl.hip's packed image read in place) feeds four MFMAs and no two
+//     waves fetch the same fragment; the activations of a 32-channel group -- the 128 pixels' halo -- are fetched ONCE (global -> registers ->
+//     LDS under the previous group's MFMAs), the nine taps read them at compile-time immediate offsets;
+//   * the halo in LDS is ZERO-PADDED: position q = (image b, padded row, padded column) of a [N (H + 1) + 1][W + 2] grid (one shared zero row
+//     between images, a zero column either side), rows of 80 B (64 B of channels + 16: any 16 rows a ds_read_b128 lane group touches cover the
+//     64 banks once).  A tap is then the SAME shift of (ky (W + 2) + kx) positions for every pixel -- an instruction immediate, W being a
+//     template parameter: four address registers per lane for the whole K loop, no per-tap address math, no border masks;
+//   * ONE block-wide barrier per channel group (72 MFMAs per wave), nothing in the K loop waits for LDS-DMA (there is none);
+//   * the MFMA operands are SWAPPED (filters as the row operand): the accumulator then holds, per lane, four consecutive CHANNELS of one
+//     pixel -- the epilogue is wave-private and register-only (bias from LDS, activation, skip connection, 8-B fp16 / 16-B fp32 stores straight
+//     from the accumulators): no staging tile, no barrier, no LDS;
+//   * PERSISTENT over tiles (block -> XCD -> a contiguous range of tiles, N-tiles of an M-tile next to each other): the next tile's first
+//     filter fragments and first halo are requested during the current tile's last channel group and land while its epilogue runs; the
+//     skip-connection rows (fp16 plane) are requested four taps before the epilogue needs them.
+#include <algorithm>
+#include <cstdlib>
+
+#include "conv_dev.h"
+
+// timing ablations (tools/p3_variants.sh builds conv_p3.o with -DP3_ABL=n into its own library; WRONG results): 1 no filter loads in the K
+// loop, 2 no fragment reads, 4 no MFMAs, 8 no halo loads / parks, 16 no epilogue stores
+#ifndef P3_ABL
+#define P3_ABL 0
+#endif
+
+namespace bp {
+
+struct P3Args {
+    int NTN;      // N tiles of 128 columns
+    int T;        // tiles = M tiles x N tiles (tile t: M tile t / NTN, N tile t % NTN)
+    int G;        // 32-channel groups of the layer's K
+    int PX;       // blocks per XCD (grid = 8 PX): block (xcd, j) takes the tiles lo(xcd) + j, + PX, ... of the XCD's range [lo, hi)
+};
+
+static constexpr int P3_BM = 128, P3_BN = 128, P3_PITCH = 80;
+static constexpr int P3_SOOB = 0x40000000;      // a scalar offset beyond every descriptor (adding a few KB to it does not wrap)
+
+// W: map width (tap shifts are instruction immediates).  HRT: halo rows (positions) per stage.  RES: 0 no skip connection, 1 from its fp16
+// plane (ConvParams::res16), 2 from the fp32 tensor.
+template <int W, int HRT, int RES>
+__global__ __launch_bounds__(256, 2) void conv_p3_kernel(const ConvParams p, const P3Args a) {
+    constexpr int WP = W + 2, PITCH = P3_PITCH, STAGE = HRT * PITCH;
+    constexpr int NPASS = (HRT * 4 + 255) / 256;          // loader passes: 256 threads x 16 B = 64 halo rows each
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    float* const ldsBias = reinterpret_cast<float*>(lds + 2 * STAGE);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xcd = (int)blockIdx.x & 7, bj = (int)blockIdx.x >> 3;
+    const int t_lo = (int)((long long)xcd * a.T >> 3), t_hi = (int)((long long)(xcd + 1) * a.T >> 3);
+    int tile = t_lo + bj;
+    if (tile >= t_hi) return;
+
+    const int H = p.H, hw = H * W, H1 = H + 1;
+    const float rcp_hw = 1.0f / (float)hw, rcp_h1 = 1.0f / (float)H1;
+    const int G = a.G;
+
+    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned short*>(p.in16), 0, (int)min((long long)p.N * hw * p.in_ld * 2, (long long)OOB), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned short*>(p.wpl), 0, (int)((long long)p.CoutPad * p.Kpad * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcO =
+        __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)min((long long)p.M * p.out_ld * 4, (long long)OOB), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcR = __builtin_amdgcn_make_buffer_rsrc(
+        RES == 1 ? (void*)const_cast<unsigned short*>(p.res16) : (void*)const_cast<float*>(RES == 2 ? p.res : p.out), 0,
+        RES ? (int)min((long long)p.M * p.res_ld * (RES == 1 ? 2 : 4), (long long)OOB) : 0, 0x00020000);
+    const PlaneDesc pd = make_plane_desc(p);
+
+    // the layer's bias (padded to CoutPad by the engine) -> LDS, once per block
+    for (int i = tid; i < a.NTN * P3_BN; i += 256) ldsBias[i] = i < p.CoutPad ? p.bias[i] : 0.f;
+
+    // centre position of output pixel m = (b, oy, ox) in the padded grid
+    auto cpos = [&](int m) __attribute__((always_inline)) {
+        const int b = fast_div(m, hw, rcp_hw);
+        const int rem = m - b * hw;
+        const int oy = rem / W, ox = rem - oy * W;
+        return (b * H1 + oy + 1) * WP + ox + 1;
+    };
+    // ---- per tile: the loader's source offsets (halo row j <-> position q0 + j, q0 = the centre of the tile's first pixel - (W + 2) - 1),
+    // the lane's four fragment rows, the wave's filter base
+    const int lrow = tid >> 2, lgr = tid & 3;
+    auto tile_setup = [&](int t, bool live, int& m0, int& n0, unsigned (&avo)[NPASS], unsigned (&bse)[4], int& bsrc) __attribute__((always_inline)) {
+        const int tm = t / a.NTN, tn = t - tm * a.NTN;
+        m0 = tm * P3_BM;
+        n0 = tn * P3_BN;
+        const int q0 = cpos(min(m0, p.M - 1)) - WP - 1;
+#pragma unroll
+        for (int k = 0; k < NPASS; ++k) {
+            const int j = lrow + 64 * k, q = q0 + j;
+            const int qq = max(q, 0);
+            const int R = qq / WP, col = qq - R * WP;
+            const int b = fast_div(R, H1, rcp_h1), rr = R - b * H1;
+            const bool ok = live & (q >= 0) & (j < HRT) & (col >= 1) & (col <= W) & (rr >= 1) & (b < p.N);
+            const unsigned so = (unsigned)((((b * H + rr - 1) * W + col - 1) * p.in_ld + lgr * 8) * 2);
+            avo[k] = ok ? so : OOB;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = min(m0 + 32 * e + (lane & 31), p.M - 1);
+            // tap (ky, kx) of pixel m reads position cpos(m) + (ky - 1)(W + 2) + (kx - 1) = halo row (cpos(m) - (W + 2) - 1 - q0) + ky (W + 2) + kx
+            bse[e] = (unsigned)((cpos(m) - WP - 1 - q0) * PITCH + (lane >> 5) * 16);
+        }
+        const int col0 = n0 + 32 * wave;
+        bsrc = live ? ((col0 >> 6) * p.nchunks) * 4096 + ((col0 >> 5) & 1) * 2048 : P3_SOOB;
+    };
+    const unsigned a_woff = (unsigned)(lrow * PITCH + lgr * 16);
+
+    // filter fragment geometry (conv_pl.hip's packed image, [CoutPad / 64][chunk][64 rows][64 B], granule g of row r at slot g ^ ((r >> 2) & 3)):
+    // lane -> row (lane & 31) of the wave's 32, logical granule 2 ks + (lane >> 5)
+    const int fsw = ((lane & 31) >> 2) & 3;
+    const int bfr0 = (lane & 31) * 64 + (((lane >> 5) ^ fsw) << 4), bfr1 = bfr0 ^ 32;
+
+    u32x4 rb[3][2];                  // filter ring: [slot][k-step]
+    auto load_b = [&](auto slotc, int so) __attribute__((always_inline)) {
+        constexpr int slot = decltype(slotc)::value;
+        rb[slot][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrcB, bfr0, so, 0);
+        rb[slot][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrcB, bfr1, so, 0);
+    };
+    auto load_b_loop = [&](auto slotc, int so) __attribute__((always_inline)) {
+        if constexpr (!(P3_ABL & 1)) load_b(slotc, so);
+    };
+    u32x4 ra[NPASS];                 // the next group's halo on its way to LDS
+    auto load_a = [&](const unsigned (&avo)[NPASS], int so) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < NPASS; ++k) ra[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrcA, (int)avo[k], so, 0);
+    };
+    auto park_a = [&](auto kc, unsigned so) __attribute__((always_inline)) {
+        constexpr int k = decltype(kc)::value;
+        if (k < NPASS - 1 || lrow + 64 * k < HRT) *reinterpret_cast<u32x4*>(lds + so + a_woff + k * (64 * PITCH)) = ra[k];
+    };
+
+    int m0, n0, bsrc, m0n, n0n, bsrcn;
+    unsigned avo[NPASS], avon[NPASS], bse[4], bsen[4];
+    tile_setup(tile, true, m0, n0, avo, bse, bsrc);
+    // the first two taps' filters, the first group's halo
+    load_b(std::integral_constant<int, 0>{}, bsrc);
+    load_b(std::integral_constant<int, 1>{}, bsrc + 4096);
+    load_a(avo, 0);
+    __builtin_amdgcn_sched_barrier(0);
+
+    f16x8 fr[2][4];                  // activation fragments: [step parity][pixel sub-tile]
+    auto read_frags = [&](auto parc, auto tapc, auto ksc, unsigned so, const unsigned (&b4)[4]) __attribute__((always_inline)) {
+        constexpr int par = decltype(parc)::value, tap = decltype(tapc)::value, ks = decltype(ksc)::value;
+        constexpr int imm = ((tap / 3) * WP + (tap % 3)) * PITCH + ks * 32;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) fr[par][e] = *reinterpret_cast<const f16x8*>(lds + so + b4[e] + imm);
+    };
+
+    static_for<NPASS>([&](auto kc) __attribute__((always_inline)) { park_a(kc, 0u); });
+    __syncthreads();
+    read_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, 0u, bse);
+
+    f32x16 acc[4];
+    unsigned so_cur = 0u, so_nxt = (unsigned)STAGE;
+    // skip-connection rows of the tile, requested inside its last channel group: [pixel sub-tile][channel quad]
+    u32x2 rr16[RES == 1 ? 4 : 1][4];
+
+    // one channel group: nine taps; LAST = the tile's last group (the next item is the NEXT tile's group 0)
+    auto group = [&](auto lastc, int g) __attribute__((always_inline)) {
+        constexpr bool LAST = decltype(lastc)::value;
+        const int bs_cur = bsrc + g * (9 * 4096);
+        const int bs_nxt = LAST ? bsrcn : bs_cur + 9 * 4096;
+        if constexpr (!(P3_ABL & 8)) {
+            if constexpr (LAST) load_a(avon, 0);
+            else load_a(avo, (g + 1) * 64);
+        }
+        static_for<9>([&](auto tapc) __attribute__((always_inline)) {
+            constexpr int tap = decltype(tapc)::value;
+            if constexpr (tap < 7) load_b_loop(std::integral_constant<int, (tap + 2) % 3>{}, bs_cur + (tap + 2) * 4096);
+            else load_b_loop(std::integral_constant<int, (tap + 2) % 3>{}, bs_nxt + (tap - 7) * 4096);
+            if constexpr (LAST && RES == 1 && tap == 4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int m = m0 + 32 * e + (lane & 31);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int ch = n0 + 32 * wave + 8 * q + 4 * (lane >> 5);
+                        const bool ok = (m < p.M) & (ch < p.Cout);          // (bitwise: a short-circuit && became control flow around every load)
+                        const int ro = (m * p.res_ld + ch) * 2;
+                        rr16[e][q] = __builtin_amdgcn_raw_buffer_load_b64(rsrcR, ok ? ro : (int)OOB, 0, 0);
+                    }
+                }
+            }
+            static_for<2>([&](auto ksc) __attribute__((always_inline)) {
+                constexpr int ks = decltype(ksc)::value;
+                constexpr int step = tap * 2 + ks, par = step & 1;
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (step < 17) {
+                    if constexpr (!(P3_ABL & 2))
+                        read_frags(std::integral_constant<int, par ^ 1>{}, std::integral_constant<int, (step + 1) / 2>{},
+                                   std::integral_constant<int, (step + 1) & 1>{}, so_cur, bse);
+                } else {
+                    // everybody's next halo is parked and nobody reads this stage any more (the last step's fragments are in registers)
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    if constexpr (LAST) read_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, so_nxt, bsen);
+                    else read_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, so_nxt, bse);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const f16x8 bf = __builtin_bit_cast(f16x8, rb[tap % 3][ks]);
+                if constexpr (!(P3_ABL & 4)) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf, fr[par][e], acc[e], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e][0] += (float)bf[0] + (float)fr[par][e][0];      // (keeps the operands live)
+                }
+            });
+            if constexpr (tap <= 7 && tap >= 8 - NPASS && !(P3_ABL & 8)) park_a(std::integral_constant<int, tap - (8 - NPASS)>{}, so_nxt);
+        });
+        const unsigned t_ = so_cur; so_cur = so_nxt; so_nxt = t_;
+    };
+
+    for (;;) {
+        const int next = tile + a.PX;
+        const bool has_next = next < t_hi;
+        tile_setup(has_next ? next : tile, has_next, m0n, n0n, avon, bsen, bsrcn);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[e][r] = 0.f;
+        for (int g = 0; g < G - 1; ++g) group(std::false_type{}, g);
+        group(std::true_type{}, G - 1);
+
+        // ---- epilogue, wave-private, straight from the accumulators.  C/D layout of the 32x32 MFMA with the filters as the row operand:
+        // lane -> pixel (lane & 31) of the sub-tile, register r -> channel (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of the wave's 32.
+        // (activation and fp32-store as compile-time cases of one switch: as run-time tests inside the 16 (sub-tile, quad) bodies they were
+        // ~100 scalar branches per tile)
+        auto epilogue = [&](auto actc, auto f32c) __attribute__((always_inline)) {
+            constexpr int ACT = decltype(actc)::value;
+            constexpr bool F32 = decltype(f32c)::value;
+            const int cbase = n0 + 32 * wave + 4 * (lane >> 5);
+            const bool after = p.res_after_act != 0, plane = pd.np == 1;
+            f32x4 bias4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bias4[q] = *reinterpret_cast<const f32x4*>(ldsBias + cbase + 8 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = m0 + 32 * e + (lane & 31);
+                f32x4 r4[4];
+                if constexpr (RES == 2) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const bool ok = (m < p.M) & (cbase + 8 * q < p.Cout);
+                        const unsigned ro = (unsigned)((m * p.res_ld + cbase + 8 * q) * 4);
+                        r4[q] = buf_load4(rsrcR, ok ? ro : OOB, 0);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int ch = cbase + 8 * q;
+                    f32x4 v = {acc[e][4 * q], acc[e][4 * q + 1], acc[e][4 * q + 2], acc[e][4 * q + 3]};
+                    v += bias4[q];
+                    f32x4 r = {0.f, 0.f, 0.f, 0.f};
+                    if constexpr (RES == 1) r = __builtin_convertvector(__builtin_bit_cast(f16x4, rr16[e][q]), f32x4);
+                    if constexpr (RES == 2) r = r4[q];
+                    if constexpr (RES != 0) { if (!after) v += r; }
+                    if constexpr (ACT == ACT_LEAKY) {
+                        v.x = v.x > 0.f ? v.x : 0.1f * v.x; v.y = v.y > 0.f ? v.y : 0.1f * v.y;
+                        v.z = v.z > 0.f ? v.z : 0.1f * v.z; v.w = v.w > 0.f ? v.w : 0.1f * v.w;
+                    } else if constexpr (ACT == ACT_RELU) {
+                        v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
+                        v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+                    }
+                    if constexpr (RES != 0) { if (after) v += r; }
+                    // (rows past M and columns past Cout: out-of-range offsets, dropped by the hardware)
+                    const bool ok = (m < p.M) & (ch < p.Cout);
+                    const unsigned oo = (unsigned)(m * p.out_ld + ch);
+                    const unsigned off = ok ? oo : (OOB >> 2);
+                    if constexpr (P3_ABL & 16) { if (v.x == 123.456f) __builtin_amdgcn_raw_buffer_store_b64(u32x2{off, 0u}, pd.r0, 0, 0, 0); continue; }
+                    if constexpr (F32) {
+                        const u32x4 o = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+                        __builtin_amdgcn_raw_buffer_store_b128(o, rsrcO, (int)(off * 4), 0, 0);
+                    }
+                    if (plane) {
+                        const f16x4 h = __builtin_convertvector(v, f16x4);
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h), pd.r0, (int)(off * 2), 0, 0);
+                    }
+                }
+            }
+        };
+        {
+            const int sel = (p.act == ACT_LEAKY ? 0 : (p.act == ACT_RELU ? 1 : 2)) * 2 + (pd.f32 ? 1 : 0);
+            switch (sel) {
+                case 0: epilogue(std::integral_constant<int, ACT_LEAKY>{}, std::false_type{}); break;
+                case 1: epilogue(std::integral_constant<int, ACT_LEAKY>{}, std::true_type{}); break;
+                case 2: epilogue(std::integral_constant<int, ACT_RELU>{}, std::false_type{}); break;
+                case 3: epilogue(std::integral_constant<int, ACT_RELU>{}, std::true_type{}); break;
+                case 4: epilogue(std::integral_constant<int, ACT_LINEAR>{}, std::false_type{}); break;
+                default: epilogue(std::integral_constant<int, ACT_LINEAR>{}, std::true_type{}); break;
+            }
+        }
+        if (!has_next) break;
+        tile = next;
+        m0 = m0n; n0 = n0n; bsrc = bsrcn;
+#pragma unroll
+        for (int k = 0; k < NPASS; ++k) avo[k] = avon[k];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bse[e] = bsen[e];
+    }
+}
+
+// ---- host side
+static int p3_width_class(int W) { return (W == 13 || W == 16 || W == 26 || W == 32 || W == 52) ? W : 0; }
+static int p3_hrt(int W) { return (W == 13 || W == 16) ? 208 : (W == 52 ? 304 : 240); }
+
+// halo rows the layer's worst tile needs: centre span of its 128 pixels + a padded row and a pixel either side
+static int p3_rows_needed(const ConvParams& p, long long M) {
+    const int W = p.W, H = p.H, hw = H * W, WP = W + 2;
+    auto cpos = [&](long long m) { const long long b = m / hw, rem = m % hw; return (b * (H + 1) + rem / W + 1) * WP + rem % W + 1; };
+    long long need = 0;
+    for (long long m0 = 0; m0 < M; m0 += P3_BM) need = std::max(need, cpos(std::min(m0 + P3_BM - 1, M - 1)) - cpos(m0) + 2 * WP + 3);
+    return (int)need;
+}
+
+bool conv_p3_eligible(const ConvParams& p, long long M) {
+    if (!(conv_plh_eligible(p) && p.wpl != nullptr && p.mfma_mode == PREC_F16)) return false;
+    if (!p3_width_class(p.W) || p.store_mode != ST_NHWC || p.res_scale != nullptr || p.pool_out != nullptr) return false;
+    if ((p.Cout & 3) || (p.out_ld & 3) || p.CoutPad < P3_BN) return false;
+    if (p.res && (p.res_ld & 3)) return false;
+    if (p.out16 != nullptr && p.out_np != 1) return false;
+    if (M * p.out_ld * 4 >= (long long)OOB || (p.res && M * p.res_ld * 4 >= (long long)OOB)) return false;
+    if (M >= (1 << 24) || (long long)(p.N * (p.H + 1) + 1) * (p.W + 2) >= (1 << 24)) return false;       // (fast_div's range)
+    // a persistent grid pays its start-up over the work it walks: layers of the batched runs only
+    if (M < 4096) return false;
+    return p3_rows_needed(p, M) <= p3_hrt(p.W);
+}
+
+template <int W, int HRT>
+static void launch_p3_w(const ConvParams& p, const P3Args& a, int grid, int lds_bytes, hipStream_t s) {
+    const int res = p.res ? (p.res16 ? 1 : 2) : 0;
+#define P3_GO(RES_)                                                                                                                         \
+    do {                                                                                                                                    \
+        if (lds_bytes > 64 * 1024) allow_big_lds(reinterpret_cast<const void*>(conv_p3_kernel<W, HRT, RES_>));                              \
+        if (g_conv_prof)                                                                                                                    \
+            hipExtLaunchKernelGGL((conv_p3_kernel<W, HRT, RES_>), dim3(grid), dim3(256), lds_bytes, s, g_conv_prof->e0, g_conv_prof->e1, 0, p, a); \
+        else                                                                                                                                \
+            hipLaunchKernelGGL((conv_p3_kernel<W, HRT, RES_>), dim3(grid), dim3(256), lds_bytes, s, p, a);                                  \
+    } while (0)
+    if (res == 0) P3_GO(0);
+    else if (res == 1) P3_GO(1);
+    else P3_GO(2);
+#undef P3_GO
+}
+
+void launch_conv_p3(const ConvParams& p, hipStream_t s) {
+    BP_CHECK(conv_p3_eligible(p, p.M), "conv_p3: fp16 planes, 3x3 / stride 1 / pad 1, NHWC store, a width the kernel is built for, M >= 4096");
+    P3Args a{};
+    a.NTN = (p.CoutPad + P3_BN - 1) / P3_BN;
+    a.T = ((p.M + P3_BM - 1) / P3_BM) * a.NTN;
+    a.G = p.Cin / 32;
+    // two blocks per CU (register budget); BP_P3_BPC: blocks per CU of the grid (A/B runs)
+    static const int bpc = std::getenv("BP_P3_BPC") ? std::max(1, std::atoi(std::getenv("BP_P3_BPC"))) : 2;
+    a.PX = std::max(1, std::min((a.T + 7) / 8, 32 * bpc));
+    const int grid = 8 * a.PX;
+    const int lds_bytes = 2 * p3_hrt(p.W) * P3_PITCH + a.NTN * P3_BN * 4;     // two halo stages + the bias (a whole number of N tiles)
+    switch (p.W) {
+        case 13: launch_p3_w<13, 208>(p, a, grid, lds_bytes, s); break;
+        case 16: launch_p3_w<16, 208>(p, a, grid, lds_bytes, s); break;
+        case 26: launch_p3_w<26, 240>(p, a, grid, lds_bytes, s); break;
+        case 32: launch_p3_w<32, 240>(p, a, grid, lds_bytes, s); break;
+        case 52: launch_p3_w<52, 304>(p, a, grid, lds_bytes, s); break;
+        default: throw Error("conv_p3: width not instantiated");
+    }
+}
+
+}  // namespace bp

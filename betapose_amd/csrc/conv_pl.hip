@@ -614,7 +614,7 @@ bool conv_tile_is_pl(int tile) {
 #ifdef BP_EXPERIMENTAL
     if (tile == TILE_PL128S || tile == TILE_PL64K2 || tile == TILE_PL64BD) return true;
 #endif
-    return tile == TILE_PL64 || tile == TILE_PL128 || tile == TILE_PL128x64 || tile == TILE_PL256x128 || conv_tile_is_plh(tile) || tile == TILE_S1;
+    return tile == TILE_PL64 || tile == TILE_PL128 || tile == TILE_PL128x64 || tile == TILE_PL256x128 || conv_tile_is_plh(tile) || tile == TILE_S1 || tile == TILE_P3;
 }
 
 bool conv_plh_eligible(const ConvParams& p) {
@@ -698,6 +698,7 @@ void launch_conv_pl(const ConvParams& p, int tile, hipStream_t s) {
     BP_CHECK((long long)3 * p.CoutPad * p.Kpad * 2 < (long long)OOB, "filter planes too large for 32-bit offsets");
     BP_CHECK((long long)p.N * p.H * p.W * p.in_ld * 2 < (long long)OOB, "activation planes too large for 32-bit offsets");
     if (tile == TILE_S1) { launch_conv_s1(p, s); return; }     // conv_s1.hip
+    if (tile == TILE_P3) { launch_conv_p3(p, s); return; }     // conv_p3.hip
     if (p.mfma_mode == PREC_BF16X3) launch_pl_np<3>(p, tile, s);
     else if (p.mfma_mode == PREC_F16) launch_pl_np<1>(p, tile, s);
     else throw Error("conv_pl tiles need a 16-bit precision mode");

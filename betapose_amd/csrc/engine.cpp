@@ -449,7 +449,8 @@ static void choose_pl(const ConvParams& c, long long M, int mode, int sk_max, in
     for (const PlanEntry& e : plan_file_entries())
         if (e.M == (int)M && e.CoutPad == c.CoutPad && e.nchunks == c.nchunks && conv_tile_is_pl(e.tile) &&
             (!conv_tile_is_plh(e.tile) || plh_ok(c)) &&
-            (e.tile != TILE_S1 || (e.splits == 1 && conv_s1_eligible(c, M)))) { *tile = e.tile; *splits = e.splits; return; }   // (a plan-file row naming the streaming 1x1 kernel for a layer it cannot run is ignored, not a failed launch)
+            (e.tile != TILE_S1 || (e.splits == 1 && conv_s1_eligible(c, M))) &&
+            (e.tile != TILE_P3 || (e.splits == 1 && conv_p3_eligible(c, M)))) { *tile = e.tile; *splits = e.splits; return; }   // (a plan-file row naming the streaming 1x1 kernel for a layer it cannot run is ignored, not a failed launch)
     for (const PlanEntry* e = (mode == PREC_F16 ? kPlanPL1 : kPlanPL3); e->M != 0; ++e)   // tables end with a zero row
         if (e->M == (int)M && e->CoutPad == c.CoutPad && e->nchunks == c.nchunks &&
             (!conv_tile_is_plh(e->tile) || plh_ok(c))) { *tile = e->tile; *splits = e->splits; return; }     // (a 3x3 row also matches stride-2 / 1x1 layers of the same K)
@@ -534,6 +535,7 @@ static bool tile_runs(int tile, const ConvParams& c, long long M = 0) {
     const bool on_planes = c.in16 != nullptr && c.wpl != nullptr;
     if (tile == TILE_64x64 || tile == TILE_128x64) return !on_planes;
     if (tile == TILE_S1) return conv_s1_eligible(c, M);
+    if (tile == TILE_P3) return conv_p3_eligible(c, M);
     if (conv_tile_is_pl(tile)) return c.mfma_mode != PREC_F32 && conv_pl_eligible(c) && (!conv_tile_is_plh(tile) || conv_plh_eligible(c));
     if (tile == TILE_64x64_BD || tile == TILE_BD_K2) return c.mfma_mode == PREC_BF16X3 && conv_h16_eligible(c) && c.w16s != nullptr && !on_planes;
     if (conv_tile_is_halo(tile)) return c.mfma_mode == PREC_BF16X3 && c.in16 == nullptr && conv_halo_eligible(c, tile);
@@ -564,14 +566,18 @@ static void choose_launch(const Op& op, int batch, int force_tile, int sk_target
         // streaming kernel (conv_s1.hip); BP_NO_S1=1: the plane tiles as before (A/B runs)
         static const bool s1_off = std::getenv("BP_NO_S1") != nullptr;
         if (!s1_off && mode == PREC_F16 && s == 1 && conv_tile_is_pl(t) && !op.pool_out && conv_s1_eligible(c, M)) t = TILE_S1;
-        if (force_tile >= 0 && !(force_tile == TILE_S1 && op.pool_out) && tile_runs(force_tile, c, M)) t = force_tile;
+        // round 6: the 3x3 / stride-1 layers of the batched fp16 runs that were planned on the halo plane tile, on the persistent kernel
+        // (conv_p3.hip); BP_NO_P3=1: the halo plane tile as before (A/B runs)
+        static const bool p3_off = std::getenv("BP_NO_P3") != nullptr;
+        if (!p3_off && mode == PREC_F16 && s == 1 && t == TILE_PLH128 && !op.pool_out && conv_p3_eligible(c, M)) t = TILE_P3;
+        if (force_tile >= 0 && !((force_tile == TILE_S1 || force_tile == TILE_P3) && op.pool_out) && tile_runs(force_tile, c, M)) t = force_tile;
         if (!(sk_target == 512 && sk_min_chunks == 4 && sk_max == 8)) {   // explicit policy (tests, sweeps)
             const long long blocks = ((M + conv_tile_bm(t) - 1) / conv_tile_bm(t)) *
                                      ((c.CoutPad + conv_tile_bn(t) - 1) / conv_tile_bn(t));
             s = 1;
             while (blocks * s < sk_target && c.nchunks / (s + 1) >= sk_min_chunks && s < sk_max) ++s;
         }
-        if (t == TILE_S1) s = 1;     // (a persistent grid: no K slices)
+        if (t == TILE_S1 || t == TILE_P3) s = 1;     // (a persistent grid: no K slices)
     } else if (stem3_wanted(c, force_tile)) {
         t = TILE_STEM3;       // the RGB 3x3 stem: direct convolution, no K slices
     } else {

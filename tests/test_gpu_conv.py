@@ -326,6 +326,55 @@ def test_conv_s1_streaming_1x1_f16(cuda, shape, monkeypatch):
     _check(out.cpu().permute(0, 3, 1, 2), ref, tol=2e-5 * scale)
 
 
+P3_SHAPES = [
+    # N, H, W, Cin, Cout, act, res (None / before the activation / after it)
+    (28, 13, 13, 64, 128, "leaky", "post"),      # W = 13: tiles span ten rows and an image boundary (M = 4 732: 36 tiles + 124 rows)
+    (33, 13, 13, 96, 256, "leaky", None),        # ... three channel groups, two N tiles, an M tail
+    (14, 20, 16, 64, 256, "relu", None),         # W = 16 (the key-point detector's layer3 conv2 class)
+    (7, 26, 26, 64, 256, "leaky", "post"),       # W = 26
+    (4, 40, 32, 64, 136, "relu", "pre"),         # W = 32, Cout % 128 != 0 (CoutPad 192: the second N tile overhangs), skip connection before the activation
+    (2, 52, 52, 32, 128, "leaky", "post"),       # W = 52, ONE channel group (the tile's only group is its last)
+    (3, 52, 52, 128, 128, "linear", None),       # W = 52, four groups, linear
+    (28, 26, 26, 32, 128, "leaky", "post"),      # 148 tiles: several tiles per block (the persistent loop, the next tile's operands in flight through the epilogue)
+    (28, 52, 52, 32, 256, "relu", "pre"),        # 1 184 tiles on 512 blocks: two and three tiles per block
+]
+
+
+@pytest.mark.parametrize("shape", P3_SHAPES)
+def test_conv_p3_persistent_3x3_f16(cuda, shape):
+    """TILE_P3 (conv_p3.hip, round 6): the 3x3 / stride-1 layers of the batched fp16 runs as a persistent kernel -- zero-padded halo in LDS
+    with the nine taps as instruction immediates, filter fragments global -> registers, 128 pixels x 32 columns per wave with the MFMA operands
+    swapped so that the epilogue stores straight from the accumulators, the next tile's operands in flight through the epilogue.  Same operands
+    and the same MFMA sequence per output element as the halo plane tile: BIT-IDENTICAL to TILE_PLH128; against torch on the fp16-rounded
+    operands at the accumulation-order bar; planes = RNE of the output; bit-reproducible."""
+    N, H, W, Cin, Cout, act, rmode = shape
+    g = torch.Generator().manual_seed(9600 + Cin + Cout + H)
+    x = (torch.randn(N, H, W, Cin, generator=g) * torch.exp(0.5 * torch.randn(N, H, W, 1, generator=g))).half().float()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / np.sqrt(Cin * 9)).half().float()
+    b = torch.randn(Cout, generator=g)
+    res = torch.randn(N, H, W, Cout, generator=g) if rmode else None
+    ref = _ref(x, w, b, 1, 1, act, res, rmode == "post")
+    kw = dict(pad=1, act=act, res=res.to(cuda) if rmode else None, res_after_act=rmode == "post", splits=1)
+    out, pl = ops.conv2d_nhwc(x.to(cuda), w, b, tile="p3_f16", planes=True, **kw)
+    assert torch.equal(out, ops.conv2d_nhwc(x.to(cuda), w, b, tile="p3_f16", **kw))
+    assert torch.equal(_planes_to_f32(pl, "f16"), out.half().float())
+    base = ops.conv2d_nhwc(x.to(cuda), w, b, tile="plh128_f16", **kw)
+    assert torch.equal(out, base), "max |d| %.3e" % float((out - base).abs().max())
+    scale = max(1.0, float(ref.abs().mean()))
+    _check(out.cpu().permute(0, 3, 1, 2), ref, tol=2e-5 * scale)
+
+
+def test_conv_p3_refuses_other_layers(cuda):
+    """The persistent 3x3 tile takes 3x3 / stride-1 / pad-1 layers at the widths it is built for (13, 16, 26, 32, 52) with M >= 4 096 only."""
+    g = torch.Generator().manual_seed(6)
+    for (N, H, W, Cin, Cout, k, st) in [(1, 52, 52, 64, 128, 3, 1), (8, 20, 20, 64, 128, 3, 1), (8, 26, 26, 64, 128, 1, 1), (8, 52, 52, 64, 128, 3, 2),
+                                        (8, 26, 26, 48, 128, 3, 1)]:
+        x = torch.randn(N, H, W, Cin, generator=g)
+        w = torch.randn(Cout, Cin, k, k, generator=g)
+        with pytest.raises(Exception):
+            ops.conv2d_nhwc(x.to(cuda), w, None, stride=st, pad=k // 2, tile="p3_f16", splits=1)
+
+
 def test_conv_s1_refuses_other_layers(cuda):
     """The streaming tile takes 1x1 layers with M >= 2 048, N >= 128, K in {64, 128, 256, 384, 512, 1 024} only: anything else is refused loudly."""
     g = torch.Generator().manual_seed(5)
