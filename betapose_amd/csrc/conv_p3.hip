@@ -51,9 +51,10 @@ static constexpr int P3_BM = 128, P3_BN = 128, P3_PITCH = 80;
 static constexpr int P3_SOOB = 0x40000000;      // a scalar offset beyond every descriptor (adding a few KB to it does not wrap)
 
 // W: map width (tap shifts are instruction immediates).  HRT: halo rows (positions) per stage.  RES: 0 no skip connection, 1 from its fp16
-// plane (ConvParams::res16), 2 from the fp32 tensor.
-template <int W, int HRT, int RES>
-__global__ __launch_bounds__(256, 2) void conv_p3_kernel(const ConvParams p, const P3Args a) {
+// plane (ConvParams::res16), 2 from the fp32 tensor.  BPC: blocks per CU the register budget is asked for (2: <= 256 registers, the fp16 skip
+// connection requested four taps ahead of the epilogue; 3: <= 168, requested inside the epilogue one pixel sub-tile ahead).
+template <int W, int HRT, int RES, int BPC>
+__global__ __launch_bounds__(256, BPC) void conv_p3_kernel(const ConvParams p, const P3Args a) {
     constexpr int WP = W + 2, PITCH = P3_PITCH, STAGE = HRT * PITCH;
     constexpr int NPASS = (HRT * 4 + 255) / 256;          // loader passes: 256 threads x 16 B = 64 halo rows each
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -143,8 +144,8 @@ __global__ __launch_bounds__(256, 2) void conv_p3_kernel(const ConvParams p, con
         if (k < NPASS - 1 || lrow + 64 * k < HRT) *reinterpret_cast<u32x4*>(lds + so + a_woff + k * (64 * PITCH)) = ra[k];
     };
 
-    int m0, n0, bsrc, m0n, n0n, bsrcn;
-    unsigned avo[NPASS], avon[NPASS], bse[4], bsen[4];
+    int m0, n0, bsrc, m0n = 0, n0n = 0, bsrcn = P3_SOOB;
+    unsigned avo[NPASS], bse[4], bsen[4];
     tile_setup(tile, true, m0, n0, avo, bse, bsrc);
     // the first two taps' filters, the first group's halo
     load_b(std::integral_constant<int, 0>{}, bsrc);
@@ -166,34 +167,41 @@ __global__ __launch_bounds__(256, 2) void conv_p3_kernel(const ConvParams p, con
 
     f32x16 acc[4];
     unsigned so_cur = 0u, so_nxt = (unsigned)STAGE;
-    // skip-connection rows of the tile, requested inside its last channel group: [pixel sub-tile][channel quad]
-    u32x2 rr16[RES == 1 ? 4 : 1][4];
+    // skip-connection rows of the tile (fp16 plane): [pixel sub-tile][pair of channel quads], 16 B = the lane's pixel x 8 consecutive channels
+    // (the same lane-half exchange as the stores, see the epilogue).  BPC == 2: requested inside the tile's last channel group
+    constexpr bool RPRE = RES == 1 && BPC == 2;
+    u32x4 rr16[RPRE ? 4 : 1][2];
+    auto load_res16 = [&](int e, int j) __attribute__((always_inline)) {
+        const int m = m0 + 32 * e + (lane & 31), ch = n0 + 32 * wave + 8 * (2 * j + (lane >> 5));
+        const bool ok = (m < p.M) & (ch < p.Cout);          // (bitwise: a short-circuit && became control flow around every load)
+        const int ro = (m * p.res_ld + ch) * 2;
+        return __builtin_amdgcn_raw_buffer_load_b128(rsrcR, ok ? ro : (int)OOB, 0, 0);
+    };
+    int next = 0;
+    bool has_next = false;
 
     // one channel group: nine taps; LAST = the tile's last group (the next item is the NEXT tile's group 0)
     auto group = [&](auto lastc, int g) __attribute__((always_inline)) {
         constexpr bool LAST = decltype(lastc)::value;
+        if constexpr (LAST) {
+            // the next tile's geometry: this tile's halos have all been requested, so the loader offsets are rebuilt in place
+            tile_setup(has_next ? next : tile, has_next, m0n, n0n, avo, bsen, bsrcn);
+        }
         const int bs_cur = bsrc + g * (9 * 4096);
         const int bs_nxt = LAST ? bsrcn : bs_cur + 9 * 4096;
         if constexpr (!(P3_ABL & 8)) {
-            if constexpr (LAST) load_a(avon, 0);
+            if constexpr (LAST) load_a(avo, 0);
             else load_a(avo, (g + 1) * 64);
         }
         static_for<9>([&](auto tapc) __attribute__((always_inline)) {
             constexpr int tap = decltype(tapc)::value;
             if constexpr (tap < 7) load_b_loop(std::integral_constant<int, (tap + 2) % 3>{}, bs_cur + (tap + 2) * 4096);
             else load_b_loop(std::integral_constant<int, (tap + 2) % 3>{}, bs_nxt + (tap - 7) * 4096);
-            if constexpr (LAST && RES == 1 && tap == 4) {
+            if constexpr (LAST && RPRE && tap == 4) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int m = m0 + 32 * e + (lane & 31);
+                for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int ch = n0 + 32 * wave + 8 * q + 4 * (lane >> 5);
-                        const bool ok = (m < p.M) & (ch < p.Cout);          // (bitwise: a short-circuit && became control flow around every load)
-                        const int ro = (m * p.res_ld + ch) * 2;
-                        rr16[e][q] = __builtin_amdgcn_raw_buffer_load_b64(rsrcR, ok ? ro : (int)OOB, 0, 0);
-                    }
-                }
+                    for (int j = 0; j < 2; ++j) rr16[e][j] = load_res16(e, j);
             }
             static_for<2>([&](auto ksc) __attribute__((always_inline)) {
                 constexpr int ks = decltype(ksc)::value;
@@ -226,9 +234,8 @@ __global__ __launch_bounds__(256, 2) void conv_p3_kernel(const ConvParams p, con
     };
 
     for (;;) {
-        const int next = tile + a.PX;
-        const bool has_next = next < t_hi;
-        tile_setup(has_next ? next : tile, has_next, m0n, n0n, avon, bsen, bsrcn);
+        next = tile + a.PX;
+        has_next = next < t_hi;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -248,6 +255,9 @@ __global__ __launch_bounds__(256, 2) void conv_p3_kernel(const ConvParams p, con
             f32x4 bias4[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) bias4[q] = *reinterpret_cast<const f32x4*>(ldsBias + cbase + 8 * q);
+            // (RES == 1, BPC == 3: the skip-connection rows are requested here, one pixel sub-tile ahead of their use)
+            u32x4 rl[2][2];
+            if constexpr (RES == 1 && !RPRE) { rl[0][0] = load_res16(0, 0); rl[0][1] = load_res16(0, 1); }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int m = m0 + 32 * e + (lane & 31);
@@ -260,15 +270,26 @@ __global__ __launch_bounds__(256, 2) void conv_p3_kernel(const ConvParams p, con
                         r4[q] = buf_load4(rsrcR, ok ? ro : OOB, 0);
                     }
                 }
+                if constexpr (RES == 1) {
+                    if constexpr (!RPRE) { if (e < 3) { rl[(e + 1) & 1][0] = load_res16(e + 1, 0); rl[(e + 1) & 1][1] = load_res16(e + 1, 1); } }
+                    // 16 B of the plane = 8 consecutive channels of the lane's pixel: lanes 0-31 hold the quads (2 j, low half | high half), lanes
+                    // 32-63 the quads (2 j + 1, low | high); one v_permlane32_swap per dword hands every lane its own two quads' halves
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const u32x4 t = RPRE ? rr16[RPRE ? e : 0][j] : rl[e & 1][j];
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(t.x, t.z, false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(t.y, t.w, false, false);
+                        r4[2 * j] = __builtin_convertvector(__builtin_bit_cast(f16x4, u32x2{s0[0], s1[0]}), f32x4);
+                        r4[2 * j + 1] = __builtin_convertvector(__builtin_bit_cast(f16x4, u32x2{s0[1], s1[1]}), f32x4);
+                    }
+                }
+                u32x2 hq[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int ch = cbase + 8 * q;
                     f32x4 v = {acc[e][4 * q], acc[e][4 * q + 1], acc[e][4 * q + 2], acc[e][4 * q + 3]};
                     v += bias4[q];
-                    f32x4 r = {0.f, 0.f, 0.f, 0.f};
-                    if constexpr (RES == 1) r = __builtin_convertvector(__builtin_bit_cast(f16x4, rr16[e][q]), f32x4);
-                    if constexpr (RES == 2) r = r4[q];
-                    if constexpr (RES != 0) { if (!after) v += r; }
+                    if constexpr (RES != 0) { if (!after) v += r4[q]; }
                     if constexpr (ACT == ACT_LEAKY) {
                         v.x = v.x > 0.f ? v.x : 0.1f * v.x; v.y = v.y > 0.f ? v.y : 0.1f * v.y;
                         v.z = v.z > 0.f ? v.z : 0.1f * v.z; v.w = v.w > 0.f ? v.w : 0.1f * v.w;
@@ -276,19 +297,30 @@ __global__ __launch_bounds__(256, 2) void conv_p3_kernel(const ConvParams p, con
                         v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
                         v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
                     }
-                    if constexpr (RES != 0) { if (after) v += r; }
-                    // (rows past M and columns past Cout: out-of-range offsets, dropped by the hardware)
-                    const bool ok = (m < p.M) & (ch < p.Cout);
-                    const unsigned oo = (unsigned)(m * p.out_ld + ch);
-                    const unsigned off = ok ? oo : (OOB >> 2);
-                    if constexpr (P3_ABL & 16) { if (v.x == 123.456f) __builtin_amdgcn_raw_buffer_store_b64(u32x2{off, 0u}, pd.r0, 0, 0, 0); continue; }
+                    if constexpr (RES != 0) { if (after) v += r4[q]; }
+                    hq[q] = __builtin_bit_cast(u32x2, __builtin_convertvector(v, f16x4));
+                    if constexpr (P3_ABL & 16) { if (v.x == 123.456f) __builtin_amdgcn_raw_buffer_store_b64(hq[q], pd.r0, 0, 0, 0); continue; }
                     if constexpr (F32) {
+                        // (rows past M and columns past Cout: out-of-range offsets, dropped by the hardware)
+                        const bool ok = (m < p.M) & (ch < p.Cout);
+                        const unsigned oo = (unsigned)(m * p.out_ld + ch);
                         const u32x4 o = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-                        __builtin_amdgcn_raw_buffer_store_b128(o, rsrcO, (int)(off * 4), 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(o, rsrcO, (int)((ok ? oo : (OOB >> 2)) * 4), 0, 0);
                     }
+                }
+                if constexpr (!(P3_ABL & 16)) {
                     if (plane) {
-                        const f16x4 h = __builtin_convertvector(v, f16x4);
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h), pd.r0, (int)(off * 2), 0, 0);
+                        // the fp16 plane as 16-B stores (the same exchange: 8 stores per tile and wave instead of 16 -- the store tail of such an
+                        // epilogue is issue-bound, MI355X_MICROARCH.md price list)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const auto s0 = __builtin_amdgcn_permlane32_swap(hq[2 * j].x, hq[2 * j + 1].x, false, false);
+                            const auto s1 = __builtin_amdgcn_permlane32_swap(hq[2 * j].y, hq[2 * j + 1].y, false, false);
+                            const int ch = n0 + 32 * wave + 8 * (2 * j + (lane >> 5));
+                            const bool ok = (m < p.M) & (ch < p.Cout);
+                            const unsigned oo = (unsigned)(m * p.out_ld + ch);
+                            __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, pd.r0, (int)((ok ? oo : (OOB >> 2)) * 2), 0, 0);
+                        }
                     }
                 }
             }
@@ -307,8 +339,6 @@ __global__ __launch_bounds__(256, 2) void conv_p3_kernel(const ConvParams p, con
         if (!has_next) break;
         tile = next;
         m0 = m0n; n0 = n0n; bsrc = bsrcn;
-#pragma unroll
-        for (int k = 0; k < NPASS; ++k) avo[k] = avon[k];
 #pragma unroll
         for (int e = 0; e < 4; ++e) bse[e] = bsen[e];
     }
@@ -330,8 +360,8 @@ static int p3_rows_needed(const ConvParams& p, long long M) {
 bool conv_p3_eligible(const ConvParams& p, long long M) {
     if (!(conv_plh_eligible(p) && p.wpl != nullptr && p.mfma_mode == PREC_F16)) return false;
     if (!p3_width_class(p.W) || p.store_mode != ST_NHWC || p.res_scale != nullptr || p.pool_out != nullptr) return false;
-    if ((p.Cout & 3) || (p.out_ld & 3) || p.CoutPad < P3_BN) return false;
-    if (p.res && (p.res_ld & 3)) return false;
+    if ((p.Cout & 7) || (p.out_ld & 7) || p.CoutPad < P3_BN) return false;       // (16-B stores of 8 fp16 channels)
+    if (p.res && (p.res_ld & 7)) return false;
     if (p.out16 != nullptr && p.out_np != 1) return false;
     if (M * p.out_ld * 4 >= (long long)OOB || (p.res && M * p.res_ld * 4 >= (long long)OOB)) return false;
     if (M >= (1 << 24) || (long long)(p.N * (p.H + 1) + 1) * (p.W + 2) >= (1 << 24)) return false;       // (fast_div's range)
@@ -340,16 +370,16 @@ bool conv_p3_eligible(const ConvParams& p, long long M) {
     return p3_rows_needed(p, M) <= p3_hrt(p.W);
 }
 
-template <int W, int HRT>
+template <int W, int HRT, int BPC>
 static void launch_p3_w(const ConvParams& p, const P3Args& a, int grid, int lds_bytes, hipStream_t s) {
     const int res = p.res ? (p.res16 ? 1 : 2) : 0;
 #define P3_GO(RES_)                                                                                                                         \
     do {                                                                                                                                    \
-        if (lds_bytes > 64 * 1024) allow_big_lds(reinterpret_cast<const void*>(conv_p3_kernel<W, HRT, RES_>));                              \
+        if (lds_bytes > 64 * 1024) allow_big_lds(reinterpret_cast<const void*>(conv_p3_kernel<W, HRT, RES_, BPC>));                         \
         if (g_conv_prof)                                                                                                                    \
-            hipExtLaunchKernelGGL((conv_p3_kernel<W, HRT, RES_>), dim3(grid), dim3(256), lds_bytes, s, g_conv_prof->e0, g_conv_prof->e1, 0, p, a); \
+            hipExtLaunchKernelGGL((conv_p3_kernel<W, HRT, RES_, BPC>), dim3(grid), dim3(256), lds_bytes, s, g_conv_prof->e0, g_conv_prof->e1, 0, p, a); \
         else                                                                                                                                \
-            hipLaunchKernelGGL((conv_p3_kernel<W, HRT, RES_>), dim3(grid), dim3(256), lds_bytes, s, p, a);                                  \
+            hipLaunchKernelGGL((conv_p3_kernel<W, HRT, RES_, BPC>), dim3(grid), dim3(256), lds_bytes, s, p, a);                             \
     } while (0)
     if (res == 0) P3_GO(0);
     else if (res == 1) P3_GO(1);
@@ -363,19 +393,25 @@ void launch_conv_p3(const ConvParams& p, hipStream_t s) {
     a.NTN = (p.CoutPad + P3_BN - 1) / P3_BN;
     a.T = ((p.M + P3_BM - 1) / P3_BM) * a.NTN;
     a.G = p.Cin / 32;
-    // two blocks per CU (register budget); BP_P3_BPC: blocks per CU of the grid (A/B runs)
-    static const int bpc = std::getenv("BP_P3_BPC") ? std::max(1, std::atoi(std::getenv("BP_P3_BPC"))) : 2;
+    const int lds_bytes = 2 * p3_hrt(p.W) * P3_PITCH + a.NTN * P3_BN * 4;     // two halo stages + the bias (a whole number of N tiles)
+    // blocks per CU: two.  Three (<= 168 registers: the skip connection requested inside the epilogue, a few spills there) tie one launch at a
+    // time and LOSE 3 % with three streams in flight (5 550 against 5 380 frames/s, configs[2] f16r on one box): these layers run AT the socket
+    // power cap (profiles/r06_p3_clock_probe.txt), a third resident block adds register-file and LDS traffic, not matrix work.
+    // BP_P3_BPC = 2 | 3 (A/B runs; read per call)
+    int bpc = 2;
+    if (const char* e = std::getenv("BP_P3_BPC")) bpc = std::atoi(e) == 3 ? 3 : 2;
     a.PX = std::max(1, std::min((a.T + 7) / 8, 32 * bpc));
     const int grid = 8 * a.PX;
-    const int lds_bytes = 2 * p3_hrt(p.W) * P3_PITCH + a.NTN * P3_BN * 4;     // two halo stages + the bias (a whole number of N tiles)
+#define P3_W(W_, HRT_) do { if (bpc == 3) launch_p3_w<W_, HRT_, 3>(p, a, grid, lds_bytes, s); else launch_p3_w<W_, HRT_, 2>(p, a, grid, lds_bytes, s); } while (0)
     switch (p.W) {
-        case 13: launch_p3_w<13, 208>(p, a, grid, lds_bytes, s); break;
-        case 16: launch_p3_w<16, 208>(p, a, grid, lds_bytes, s); break;
-        case 26: launch_p3_w<26, 240>(p, a, grid, lds_bytes, s); break;
-        case 32: launch_p3_w<32, 240>(p, a, grid, lds_bytes, s); break;
-        case 52: launch_p3_w<52, 304>(p, a, grid, lds_bytes, s); break;
+        case 13: P3_W(13, 208); break;
+        case 16: P3_W(16, 208); break;
+        case 26: P3_W(26, 240); break;
+        case 32: P3_W(32, 240); break;
+        case 52: P3_W(52, 304); break;
         default: throw Error("conv_p3: width not instantiated");
     }
+#undef P3_W
 }
 
 }  // namespace bp
