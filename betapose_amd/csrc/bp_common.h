@@ -202,7 +202,7 @@ bool conv_plh_eligible(const ConvParams& p);  // TILE_PLH128 can run the layer (
 bool conv_pl_eligible(const ConvParams& p);   // planes + wpl present, Cin % 32 == 0, taps fit the 32-bit mask
 bool conv_s1_eligible(const ConvParams& p, long long M);   // TILE_S1 can run the layer at M output pixels (fp16, 1x1 / stride 1 or 2, NHWC store, 64 <= K <= 1024, N >= 128, M >= 2048)
 void launch_conv_s1(const ConvParams& p, hipStream_t s);   // conv_s1.hip
-bool conv_p3_eligible(const ConvParams& p, long long M);   // TILE_P3 can run the layer at M output pixels (fp16, 3x3 / stride 1 / pad 1, NHWC store, W one of 13 / 16 / 26 / 32 / 52, M >= 4096)
+bool conv_p3_eligible(const ConvParams& p, long long M);   // TILE_P3 can run the layer at M output pixels (fp16, 3x3 / stride 1 / pad 1, NHWC store, W one of 13 / 16 / 26 / 32 / 52 / 104, M >= 4096)
 void launch_conv_p3(const ConvParams& p, hipStream_t s);   // conv_p3.hip
 // filters [CoutPad][Kpad] fp32 -> conv_pl.hip's LDS image, np = 1 (fp16) or 3 (exact bf16 split)
 void launch_pack_wpl(const float* in, unsigned short* out, int CoutPad, int Kpad, int Cin, int ksize, int np, hipStream_t s);

@@ -579,6 +579,17 @@ int bp_conv2d_planes(const float* d_in, int N, int H, int W, int Cin, const floa
         if (store_mode == bp::ST_UP2) out_elems *= 4;
         p.out16 = d_out_planes; p.out16_plane = out_elems; p.out_np = np;
     }
+    // BP_CONV_F16R=1 (bench tools): the launch as the engine's 'f16r' plan makes it -- the skip connection read from an fp16 plane of the
+    // residual tensor (ConvParams::res16) and, when output planes are asked for, the fp32 store dropped (ConvParams::skip_f32)
+    if (prec == bp::PREC_F16 && std::getenv("BP_CONV_F16R")) {
+        if (p.res) {
+            const long long n_res = (long long)N * OH * OW;
+            unsigned short* r16 = (unsigned short*)net.arena_.alloc_bytes((size_t)n_res * p.res_ld * 2);
+            bp::launch_f32_to_planes(p.res, p.res_ld, n_res, Cout, r16, n_res * p.res_ld, 1, s);
+            p.res16 = r16;
+        }
+        if (p.out16) p.skip_f32 = 1;
+    }
     int sp = splits;
     if (sp <= 0) {
         const long long blocks = bp::conv_tiles(p, t);

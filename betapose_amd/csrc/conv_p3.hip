@@ -45,6 +45,7 @@ struct P3Args {
     int T;        // tiles = M tiles x N tiles (tile t: M tile t / NTN, N tile t % NTN)
     int G;        // 32-channel groups of the layer's K
     int PX;       // blocks per XCD (grid = 8 PX): block (xcd, j) takes the tiles lo(xcd) + j, + PX, ... of the XCD's range [lo, hi)
+    int skew;     // start skew: block j of its XCD sleeps (j % 8) x skew x 64 cycles before its first request (0: none)
 };
 
 static constexpr int P3_BM = 128, P3_BN = 128, P3_PITCH = 80;
@@ -60,11 +61,15 @@ __global__ __launch_bounds__(256, BPC) void conv_p3_kernel(const ConvParams p, c
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float* const ldsBias = reinterpret_cast<float*>(lds + 2 * STAGE);
     const int tid = threadIdx.x, lane = tid & 63;
+    const unsigned long long t_entry = p.stamps ? bp_clock() : 0ull;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int xcd = (int)blockIdx.x & 7, bj = (int)blockIdx.x >> 3;
     const int t_lo = (int)((long long)xcd * a.T >> 3), t_hi = (int)((long long)(xcd + 1) * a.T >> 3);
     int tile = t_lo + bj;
     if (tile >= t_hi) return;
+    // every block of a launch streams the SAME filter chunks in the same order; started together they ask one L2 channel for one line at
+    // the same moment, tap after tap, until the blocks drift apart (in-kernel marks: a block's first tile 18.3 us, its second 13.3)
+    for (int i = (bj & 7) * a.skew; i > 0; --i) __builtin_amdgcn_s_sleep(1);     // (BP_P3_SKEW = 1 .. 8, measured: no difference -- these launches sit at the power cap)
 
     const int H = p.H, hw = H * W, H1 = H + 1;
     const float rcp_hw = 1.0f / (float)hw, rcp_h1 = 1.0f / (float)H1;
@@ -165,6 +170,11 @@ __global__ __launch_bounds__(256, BPC) void conv_p3_kernel(const ConvParams p, c
     __syncthreads();
     read_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, 0u, bse);
 
+    // debug marks (ConvParams::stamps, tools/bench_pl.py-style BP_CONV_STAMPS=1 through bp_conv2d): per BLOCK, 10-ns ticks -- 0 entry | 1 first
+    // fragments read | 2 first group done | 3 first tile's K loop done | 7 its epilogue issued | 5 / 6 the same for the block's second tile | 4 end
+    unsigned long long* const stm = (p.stamps && tid == 0) ? p.stamps + (long long)blockIdx.x * 8 : nullptr;
+    if (stm) { stm[0] = t_entry; stm[1] = bp_clock(); }
+    int tiles_done = 0;
     f32x16 acc[4];
     unsigned so_cur = 0u, so_nxt = (unsigned)STAGE;
     // skip-connection rows of the tile (fp16 plane): [pixel sub-tile][pair of channel quads], 16 B = the lane's pixel x 8 consecutive channels
@@ -176,6 +186,14 @@ __global__ __launch_bounds__(256, BPC) void conv_p3_kernel(const ConvParams p, c
         const bool ok = (m < p.M) & (ch < p.Cout);          // (bitwise: a short-circuit && became control flow around every load)
         const int ro = (m * p.res_ld + ch) * 2;
         return __builtin_amdgcn_raw_buffer_load_b128(rsrcR, ok ? ro : (int)OOB, 0, 0);
+    };
+    // fp32 skip connection (RES == 2): a pixel sub-tile's four quads, requested one sub-tile ahead (the first inside the last channel group)
+    f32x4 rq[RES == 2 ? 2 : 1][4];
+    auto load_res32 = [&](int e, int q) __attribute__((always_inline)) {
+        const int m = m0 + 32 * e + (lane & 31), ch = n0 + 32 * wave + 8 * q + 4 * (lane >> 5);
+        const bool ok = (m < p.M) & (ch < p.Cout);
+        const unsigned ro = (unsigned)((m * p.res_ld + ch) * 4);
+        return buf_load4(rsrcR, ok ? ro : OOB, 0);
     };
     int next = 0;
     bool has_next = false;
@@ -202,6 +220,10 @@ __global__ __launch_bounds__(256, BPC) void conv_p3_kernel(const ConvParams p, c
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) rr16[e][j] = load_res16(e, j);
+            }
+            if constexpr (LAST && RES == 2 && tap == 5) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) rq[0][q] = load_res32(0, q);
             }
             static_for<2>([&](auto ksc) __attribute__((always_inline)) {
                 constexpr int ks = decltype(ksc)::value;
@@ -240,8 +262,12 @@ __global__ __launch_bounds__(256, BPC) void conv_p3_kernel(const ConvParams p, c
         for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[e][r] = 0.f;
-        for (int g = 0; g < G - 1; ++g) group(std::false_type{}, g);
+        for (int g = 0; g < G - 1; ++g) {
+            group(std::false_type{}, g);
+            if (stm && g == 0 && tiles_done == 0) stm[2] = bp_clock();
+        }
         group(std::true_type{}, G - 1);
+        if (stm && tiles_done < 2) stm[tiles_done == 0 ? 3 : 5] = bp_clock();
 
         // ---- epilogue, wave-private, straight from the accumulators.  C/D layout of the 32x32 MFMA with the filters as the row operand:
         // lane -> pixel (lane & 31) of the sub-tile, register r -> channel (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of the wave's 32.
@@ -263,12 +289,12 @@ __global__ __launch_bounds__(256, BPC) void conv_p3_kernel(const ConvParams p, c
                 const int m = m0 + 32 * e + (lane & 31);
                 f32x4 r4[4];
                 if constexpr (RES == 2) {
+                    if (e < 3) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const bool ok = (m < p.M) & (cbase + 8 * q < p.Cout);
-                        const unsigned ro = (unsigned)((m * p.res_ld + cbase + 8 * q) * 4);
-                        r4[q] = buf_load4(rsrcR, ok ? ro : OOB, 0);
+                        for (int q = 0; q < 4; ++q) rq[RES == 2 ? (e + 1) & 1 : 0][q] = load_res32(e + 1, q);
                     }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) r4[q] = rq[RES == 2 ? e & 1 : 0][q];
                 }
                 if constexpr (RES == 1) {
                     if constexpr (!RPRE) { if (e < 3) { rl[(e + 1) & 1][0] = load_res16(e + 1, 0); rl[(e + 1) & 1][1] = load_res16(e + 1, 1); } }
@@ -336,17 +362,20 @@ __global__ __launch_bounds__(256, BPC) void conv_p3_kernel(const ConvParams p, c
                 default: epilogue(std::integral_constant<int, ACT_LINEAR>{}, std::true_type{}); break;
             }
         }
+        if (stm && tiles_done < 2) stm[tiles_done == 0 ? 7 : 6] = bp_clock();
+        ++tiles_done;
         if (!has_next) break;
         tile = next;
         m0 = m0n; n0 = n0n; bsrc = bsrcn;
 #pragma unroll
         for (int e = 0; e < 4; ++e) bse[e] = bsen[e];
     }
+    if (stm) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stm[4] = bp_clock(); }
 }
 
 // ---- host side
-static int p3_width_class(int W) { return (W == 13 || W == 16 || W == 26 || W == 32 || W == 52) ? W : 0; }
-static int p3_hrt(int W) { return (W == 13 || W == 16) ? 208 : (W == 52 ? 304 : 240); }
+static int p3_width_class(int W) { return (W == 13 || W == 16 || W == 26 || W == 32 || W == 52 || W == 104) ? W : 0; }
+static int p3_hrt(int W) { return (W == 13 || W == 16) ? 208 : (W == 52 ? 304 : (W == 104 ? 464 : 240)); }
 
 // halo rows the layer's worst tile needs: centre span of its 128 pixels + a padded row and a pixel either side
 static int p3_rows_needed(const ConvParams& p, long long M) {
@@ -401,6 +430,7 @@ void launch_conv_p3(const ConvParams& p, hipStream_t s) {
     int bpc = 2;
     if (const char* e = std::getenv("BP_P3_BPC")) bpc = std::atoi(e) == 3 ? 3 : 2;
     a.PX = std::max(1, std::min((a.T + 7) / 8, 32 * bpc));
+    if (const char* e = std::getenv("BP_P3_SKEW")) a.skew = std::atoi(e);
     const int grid = 8 * a.PX;
 #define P3_W(W_, HRT_) do { if (bpc == 3) launch_p3_w<W_, HRT_, 3>(p, a, grid, lds_bytes, s); else launch_p3_w<W_, HRT_, 2>(p, a, grid, lds_bytes, s); } while (0)
     switch (p.W) {
@@ -409,6 +439,7 @@ void launch_conv_p3(const ConvParams& p, hipStream_t s) {
         case 26: P3_W(26, 240); break;
         case 32: P3_W(32, 240); break;
         case 52: P3_W(52, 304); break;
+        case 104: P3_W(104, 464); break;
         default: throw Error("conv_p3: width not instantiated");
     }
 #undef P3_W

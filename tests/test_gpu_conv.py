@@ -337,6 +337,7 @@ P3_SHAPES = [
     (3, 52, 52, 128, 128, "linear", None),       # W = 52, four groups, linear
     (28, 26, 26, 32, 128, "leaky", "post"),      # 148 tiles: several tiles per block (the persistent loop, the next tile's operands in flight through the epilogue)
     (28, 52, 52, 32, 256, "relu", "pre"),        # 1 184 tiles on 512 blocks: two and three tiles per block
+    (1, 104, 104, 64, 128, "leaky", "post"),     # W = 104 (464 halo rows, eight loader passes)
 ]
 
 
@@ -365,7 +366,7 @@ def test_conv_p3_persistent_3x3_f16(cuda, shape):
 
 
 def test_conv_p3_refuses_other_layers(cuda):
-    """The persistent 3x3 tile takes 3x3 / stride-1 / pad-1 layers at the widths it is built for (13, 16, 26, 32, 52) with M >= 4 096 only."""
+    """The persistent 3x3 tile takes 3x3 / stride-1 / pad-1 layers at the widths it is built for (13, 16, 26, 32, 52, 104) with M >= 4 096 only."""
     g = torch.Generator().manual_seed(6)
     for (N, H, W, Cin, Cout, k, st) in [(1, 52, 52, 64, 128, 3, 1), (8, 20, 20, 64, 128, 3, 1), (8, 26, 26, 64, 128, 1, 1), (8, 52, 52, 64, 128, 3, 2),
                                         (8, 26, 26, 48, 128, 3, 1)]:
