@@ -51,13 +51,21 @@ struct P3Args {
 static constexpr int P3_BM = 128, P3_BN = 128, P3_PITCH = 80;
 static constexpr int P3_SOOB = 0x40000000;      // a scalar offset beyond every descriptor (adding a few KB to it does not wrap)
 
-// W: map width (tap shifts are instruction immediates).  HRT: halo rows (positions) per stage.  RES: 0 no skip connection, 1 from its fp16
-// plane (ConvParams::res16), 2 from the fp32 tensor.  BPC: blocks per CU the register budget is asked for (2: <= 256 registers, the fp16 skip
-// connection requested four taps ahead of the epilogue; 3: <= 168, requested inside the epilogue one pixel sub-tile ahead).
-template <int W, int HRT, int RES, int BPC>
+// KSZ: 3 (3x3 / stride 1 / pad 1) or 1 (1x1 / stride 1: the "halo" of a 128-channel group is the tile's own 128 pixels, the "taps" are its four
+// 32-channel chunks).  W: map width of the 3x3 form (tap shifts are instruction immediates).  HRT: halo rows (positions) per stage.
+// RES: 0 no skip connection, 1 from its fp16 plane (ConvParams::res16), 2 from the fp32 tensor.  BPC: blocks per CU the register budget is asked
+// for (2: <= 256 registers, the fp16 skip connection requested four taps ahead of the epilogue; 3: <= 168, requested inside the epilogue).
+template <int KSZ, int W, int HRT, int RES, int BPC>
 __global__ __launch_bounds__(256, BPC) void conv_p3_kernel(const ConvParams p, const P3Args a) {
-    constexpr int WP = W + 2, PITCH = P3_PITCH, STAGE = HRT * PITCH;
-    constexpr int NPASS = (HRT * 4 + 255) / 256;          // loader passes: 256 threads x 16 B = 64 halo rows each
+    constexpr bool K3 = KSZ == 3;
+    constexpr int WP = W + 2;
+    constexpr int TAPS = K3 ? 9 : 4;                      // 32-k chunks per group
+    constexpr int GR = K3 ? 4 : 16;                       // 16-B granules of a halo row (32 / 128 channels)
+    constexpr int PITCH = K3 ? P3_PITCH : 272;            // row bytes + 16: conflict-free for any 16 rows of a ds_read_b128 lane group
+    constexpr int STAGE = HRT * PITCH;
+    constexpr int RPP = 256 / GR;                         // halo rows per loader pass (256 threads x 16 B)
+    constexpr int NPASS = (HRT + RPP - 1) / RPP;
+    constexpr int LASTSTEP = 2 * TAPS - 1;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     float* const ldsBias = reinterpret_cast<float*>(lds + 2 * STAGE);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -67,11 +75,9 @@ __global__ __launch_bounds__(256, BPC) void conv_p3_kernel(const ConvParams p, c
     const int t_lo = (int)((long long)xcd * a.T >> 3), t_hi = (int)((long long)(xcd + 1) * a.T >> 3);
     int tile = t_lo + bj;
     if (tile >= t_hi) return;
-    // every block of a launch streams the SAME filter chunks in the same order; started together they ask one L2 channel for one line at
-    // the same moment, tap after tap, until the blocks drift apart (in-kernel marks: a block's first tile 18.3 us, its second 13.3)
     for (int i = (bj & 7) * a.skew; i > 0; --i) __builtin_amdgcn_s_sleep(1);     // (BP_P3_SKEW = 1 .. 8, measured: no difference -- these launches sit at the power cap)
 
-    const int H = p.H, hw = H * W, H1 = H + 1;
+    const int H = p.H, hw = p.H * p.W, H1 = H + 1;
     const float rcp_hw = 1.0f / (float)hw, rcp_h1 = 1.0f / (float)H1;
     const int G = a.G;
 
@@ -89,36 +95,48 @@ __global__ __launch_bounds__(256, BPC) void conv_p3_kernel(const ConvParams p, c
     // the layer's bias (padded to CoutPad by the engine) -> LDS, once per block
     for (int i = tid; i < a.NTN * P3_BN; i += 256) ldsBias[i] = i < p.CoutPad ? p.bias[i] : 0.f;
 
-    // centre position of output pixel m = (b, oy, ox) in the padded grid
+    // centre position of output pixel m = (b, oy, ox) in the padded grid (3x3 form)
     auto cpos = [&](int m) __attribute__((always_inline)) {
         const int b = fast_div(m, hw, rcp_hw);
         const int rem = m - b * hw;
-        const int oy = rem / W, ox = rem - oy * W;
+        const int oy = rem / (K3 ? W : 1), ox = rem - oy * (K3 ? W : 1);
         return (b * H1 + oy + 1) * WP + ox + 1;
     };
-    // ---- per tile: the loader's source offsets (halo row j <-> position q0 + j, q0 = the centre of the tile's first pixel - (W + 2) - 1),
-    // the lane's four fragment rows, the wave's filter base
-    const int lrow = tid >> 2, lgr = tid & 3;
+    // ---- per tile: the loader's source offsets (3x3: halo row j <-> position q0 + j, q0 = the centre of the tile's first pixel - (W + 2) - 1;
+    // 1x1: halo row j = pixel m0 + j), the lane's four fragment rows, the wave's filter base
+    const int lrow = tid / GR, lgr = tid % GR;
     auto tile_setup = [&](int t, bool live, int& m0, int& n0, unsigned (&avo)[NPASS], unsigned (&bse)[4], int& bsrc) __attribute__((always_inline)) {
         const int tm = t / a.NTN, tn = t - tm * a.NTN;
         m0 = tm * P3_BM;
         n0 = tn * P3_BN;
-        const int q0 = cpos(min(m0, p.M - 1)) - WP - 1;
+        if constexpr (K3) {
+            const int q0 = cpos(min(m0, p.M - 1)) - WP - 1;
 #pragma unroll
-        for (int k = 0; k < NPASS; ++k) {
-            const int j = lrow + 64 * k, q = q0 + j;
-            const int qq = max(q, 0);
-            const int R = qq / WP, col = qq - R * WP;
-            const int b = fast_div(R, H1, rcp_h1), rr = R - b * H1;
-            const bool ok = live & (q >= 0) & (j < HRT) & (col >= 1) & (col <= W) & (rr >= 1) & (b < p.N);
-            const unsigned so = (unsigned)((((b * H + rr - 1) * W + col - 1) * p.in_ld + lgr * 8) * 2);
-            avo[k] = ok ? so : OOB;
-        }
+            for (int k = 0; k < NPASS; ++k) {
+                const int j = lrow + RPP * k, q = q0 + j;
+                const int qq = max(q, 0);
+                const int R = qq / WP, col = qq - R * WP;
+                const int b = fast_div(R, H1, rcp_h1), rr = R - b * H1;
+                const bool ok = live & (q >= 0) & (j < HRT) & (col >= 1) & (col <= W) & (rr >= 1) & (b < p.N);
+                const unsigned so = (unsigned)((((b * H + rr - 1) * W + col - 1) * p.in_ld + lgr * 8) * 2);
+                avo[k] = ok ? so : OOB;
+            }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int m = min(m0 + 32 * e + (lane & 31), p.M - 1);
-            // tap (ky, kx) of pixel m reads position cpos(m) + (ky - 1)(W + 2) + (kx - 1) = halo row (cpos(m) - (W + 2) - 1 - q0) + ky (W + 2) + kx
-            bse[e] = (unsigned)((cpos(m) - WP - 1 - q0) * PITCH + (lane >> 5) * 16);
+            for (int e = 0; e < 4; ++e) {
+                const int m = min(m0 + 32 * e + (lane & 31), p.M - 1);
+                // tap (ky, kx) of pixel m reads position cpos(m) + (ky - 1)(W + 2) + (kx - 1) = halo row (cpos(m) - (W + 2) - 1 - q0) + ky (W + 2) + kx
+                bse[e] = (unsigned)((cpos(m) - WP - 1 - q0) * PITCH + (lane >> 5) * 16);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NPASS; ++k) {
+                const int m = m0 + lrow + RPP * k;
+                const bool ok = live & (m < p.M);
+                const unsigned so = (unsigned)((m * p.in_ld + lgr * 8) * 2);
+                avo[k] = ok ? so : OOB;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bse[e] = (unsigned)((32 * e + (lane & 31)) * PITCH + (lane >> 5) * 16);
         }
         const int col0 = n0 + 32 * wave;
         bsrc = live ? ((col0 >> 6) * p.nchunks) * 4096 + ((col0 >> 5) & 1) * 2048 : P3_SOOB;
@@ -130,7 +148,8 @@ __global__ __launch_bounds__(256, BPC) void conv_p3_kernel(const ConvParams p, c
     const int fsw = ((lane & 31) >> 2) & 3;
     const int bfr0 = (lane & 31) * 64 + (((lane >> 5) ^ fsw) << 4), bfr1 = bfr0 ^ 32;
 
-    u32x4 rb[3][2];                  // filter ring: [slot][k-step]
+    constexpr int NSLOT = K3 ? 3 : 4;         // filter ring, two taps ahead: tap t of a group in slot t % NSLOT (9 % 3 == 0, 4 % 4 == 0: every group starts at slot 0)
+    u32x4 rb[NSLOT][2];              // [slot][k-step]
     auto load_b = [&](auto slotc, int so) __attribute__((always_inline)) {
         constexpr int slot = decltype(slotc)::value;
         rb[slot][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrcB, bfr0, so, 0);
@@ -139,14 +158,14 @@ __global__ __launch_bounds__(256, BPC) void conv_p3_kernel(const ConvParams p, c
     auto load_b_loop = [&](auto slotc, int so) __attribute__((always_inline)) {
         if constexpr (!(P3_ABL & 1)) load_b(slotc, so);
     };
-    u32x4 ra[NPASS];                 // the next group's halo on its way to LDS
+    u32x4 ra[NPASS];                 // a group's halo on its way to LDS
     auto load_a = [&](const unsigned (&avo)[NPASS], int so) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < NPASS; ++k) ra[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrcA, (int)avo[k], so, 0);
     };
     auto park_a = [&](auto kc, unsigned so) __attribute__((always_inline)) {
         constexpr int k = decltype(kc)::value;
-        if (k < NPASS - 1 || lrow + 64 * k < HRT) *reinterpret_cast<u32x4*>(lds + so + a_woff + k * (64 * PITCH)) = ra[k];
+        if (k < NPASS - 1 || lrow + RPP * k < HRT) *reinterpret_cast<u32x4*>(lds + so + a_woff + k * (RPP * PITCH)) = ra[k];
     };
 
     int m0, n0, bsrc, m0n = 0, n0n = 0, bsrcn = P3_SOOB;
@@ -161,12 +180,15 @@ __global__ __launch_bounds__(256, BPC) void conv_p3_kernel(const ConvParams p, c
     f16x8 fr[2][4];                  // activation fragments: [step parity][pixel sub-tile]
     auto read_frags = [&](auto parc, auto tapc, auto ksc, unsigned so, const unsigned (&b4)[4]) __attribute__((always_inline)) {
         constexpr int par = decltype(parc)::value, tap = decltype(tapc)::value, ks = decltype(ksc)::value;
-        constexpr int imm = ((tap / 3) * WP + (tap % 3)) * PITCH + ks * 32;
+        constexpr int imm = K3 ? ((tap / 3) * WP + (tap % 3)) * PITCH + ks * 32 : tap * 64 + ks * 32;
 #pragma unroll
         for (int e = 0; e < 4; ++e) fr[par][e] = *reinterpret_cast<const f16x8*>(lds + so + b4[e] + imm);
     };
 
     static_for<NPASS>([&](auto kc) __attribute__((always_inline)) { park_a(kc, 0u); });
+    // 1x1 form: a group is four taps (~0.5-1.5 us), shorter than a cold fetch -- the halo of group g + 2 is requested at the start of group g,
+    // waits in registers for a whole group and is parked at the start of group g + 1 (two LDS stages, as in the 3x3 form)
+    if constexpr (!K3) load_a(avo, G > 1 ? 256 : (int)OOB);
     __syncthreads();
     read_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, 0u, bse);
 
@@ -198,30 +220,41 @@ __global__ __launch_bounds__(256, BPC) void conv_p3_kernel(const ConvParams p, c
     int next = 0;
     bool has_next = false;
 
-    // one channel group: nine taps; LAST = the tile's last group (the next item is the NEXT tile's group 0)
-    auto group = [&](auto lastc, int g) __attribute__((always_inline)) {
-        constexpr bool LAST = decltype(lastc)::value;
-        if constexpr (LAST) {
+    // one channel group: TAPS taps.  POS = 2: the tile's last group (the next item is the NEXT tile's group 0); POS = 1: the one before it
+    // (1x1 form: the next tile's first halo is requested here); POS = 0: any other.
+    auto group = [&](auto posc, int g) __attribute__((always_inline)) {
+        constexpr int POS = decltype(posc)::value;
+        constexpr bool LAST = POS == 2;
+        if constexpr (K3 ? LAST : (POS == 1)) {
             // the next tile's geometry: this tile's halos have all been requested, so the loader offsets are rebuilt in place
             tile_setup(has_next ? next : tile, has_next, m0n, n0n, avo, bsen, bsrcn);
         }
-        const int bs_cur = bsrc + g * (9 * 4096);
-        const int bs_nxt = LAST ? bsrcn : bs_cur + 9 * 4096;
+        const int bs_cur = bsrc + g * (TAPS * 4096);
+        const int bs_nxt = LAST ? bsrcn : bs_cur + TAPS * 4096;
         if constexpr (!(P3_ABL & 8)) {
-            if constexpr (LAST) load_a(avo, 0);
-            else load_a(avo, (g + 1) * 64);
+            if constexpr (K3) {
+                if constexpr (LAST) load_a(avo, 0);
+                else load_a(avo, (g + 1) * 64);
+            } else {
+                // park group g + 1 (requested a group ago), then request group g + 2
+                static_for<NPASS>([&](auto kc) __attribute__((always_inline)) { park_a(kc, so_nxt); });
+                if constexpr (POS == 0) load_a(avo, (g + 2) * 256);
+                else if constexpr (POS == 1) load_a(avo, 0);                            // the next tile's group 0 (avo rebuilt above)
+                else load_a(avo, a.G > 1 ? 256 : (int)OOB);                             // ... its group 1
+            }
         }
-        static_for<9>([&](auto tapc) __attribute__((always_inline)) {
+        static_for<TAPS>([&](auto tapc) __attribute__((always_inline)) {
             constexpr int tap = decltype(tapc)::value;
-            if constexpr (tap < 7) load_b_loop(std::integral_constant<int, (tap + 2) % 3>{}, bs_cur + (tap + 2) * 4096);
-            else load_b_loop(std::integral_constant<int, (tap + 2) % 3>{}, bs_nxt + (tap - 7) * 4096);
-            if constexpr (LAST && RPRE && tap == 4) {
+            constexpr int slot = tap % NSLOT, slot2 = (tap + 2) % NSLOT;
+            if constexpr (tap < TAPS - 2) load_b_loop(std::integral_constant<int, slot2>{}, bs_cur + (tap + 2) * 4096);
+            else load_b_loop(std::integral_constant<int, slot2>{}, bs_nxt + (tap - (TAPS - 2)) * 4096);
+            if constexpr (LAST && RPRE && tap == (TAPS > 4 ? 4 : 1)) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) rr16[e][j] = load_res16(e, j);
             }
-            if constexpr (LAST && RES == 2 && tap == 5) {
+            if constexpr (LAST && RES == 2 && tap == (TAPS > 5 ? 5 : 2)) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) rq[0][q] = load_res32(0, q);
             }
@@ -229,7 +262,7 @@ __global__ __launch_bounds__(256, BPC) void conv_p3_kernel(const ConvParams p, c
                 constexpr int ks = decltype(ksc)::value;
                 constexpr int step = tap * 2 + ks, par = step & 1;
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (step < 17) {
+                if constexpr (step < LASTSTEP) {
                     if constexpr (!(P3_ABL & 2))
                         read_frags(std::integral_constant<int, par ^ 1>{}, std::integral_constant<int, (step + 1) / 2>{},
                                    std::integral_constant<int, (step + 1) & 1>{}, so_cur, bse);
@@ -241,7 +274,7 @@ __global__ __launch_bounds__(256, BPC) void conv_p3_kernel(const ConvParams p, c
                     else read_frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, so_nxt, bse);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                const f16x8 bf = __builtin_bit_cast(f16x8, rb[tap % 3][ks]);
+                const f16x8 bf = __builtin_bit_cast(f16x8, rb[slot][ks]);
                 if constexpr (!(P3_ABL & 4)) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf, fr[par][e], acc[e], 0, 0, 0);
@@ -250,11 +283,10 @@ __global__ __launch_bounds__(256, BPC) void conv_p3_kernel(const ConvParams p, c
                     for (int e = 0; e < 4; ++e) acc[e][0] += (float)bf[0] + (float)fr[par][e][0];      // (keeps the operands live)
                 }
             });
-            if constexpr (tap <= 7 && tap >= 8 - NPASS && !(P3_ABL & 8)) park_a(std::integral_constant<int, tap - (8 - NPASS)>{}, so_nxt);
+            if constexpr (K3 && tap <= 7 && tap >= 8 - NPASS && !(P3_ABL & 8)) park_a(std::integral_constant<int, tap - (8 - NPASS)>{}, so_nxt);
         });
         const unsigned t_ = so_cur; so_cur = so_nxt; so_nxt = t_;
     };
-
     for (;;) {
         next = tile + a.PX;
         has_next = next < t_hi;
@@ -262,11 +294,20 @@ __global__ __launch_bounds__(256, BPC) void conv_p3_kernel(const ConvParams p, c
         for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[e][r] = 0.f;
-        for (int g = 0; g < G - 1; ++g) {
-            group(std::false_type{}, g);
-            if (stm && g == 0 && tiles_done == 0) stm[2] = bp_clock();
+        if constexpr (K3) {
+            for (int g = 0; g < G - 1; ++g) {
+                group(std::integral_constant<int, 0>{}, g);
+                if (stm && g == 0 && tiles_done == 0) stm[2] = bp_clock();
+            }
+            group(std::integral_constant<int, 2>{}, G - 1);
+        } else {
+            for (int g = 0; g < G - 2; ++g) {
+                group(std::integral_constant<int, 0>{}, g);
+                if (stm && g == 0 && tiles_done == 0) stm[2] = bp_clock();
+            }
+            group(std::integral_constant<int, 1>{}, G - 2);
+            group(std::integral_constant<int, 2>{}, G - 1);
         }
-        group(std::true_type{}, G - 1);
         if (stm && tiles_done < 2) stm[tiles_done == 0 ? 3 : 5] = bp_clock();
 
         // ---- epilogue, wave-private, straight from the accumulators.  C/D layout of the 32x32 MFMA with the filters as the row operand:
@@ -387,8 +428,8 @@ static int p3_rows_needed(const ConvParams& p, long long M) {
 }
 
 bool conv_p3_eligible(const ConvParams& p, long long M) {
-    if (!(conv_plh_eligible(p) && p.wpl != nullptr && p.mfma_mode == PREC_F16)) return false;
-    if (!p3_width_class(p.W) || p.store_mode != ST_NHWC || p.res_scale != nullptr || p.pool_out != nullptr) return false;
+    if (!(conv_pl_eligible(p) && p.wpl != nullptr && p.mfma_mode == PREC_F16)) return false;
+    if (p.store_mode != ST_NHWC || p.res_scale != nullptr || p.pool_out != nullptr) return false;
     if ((p.Cout & 7) || (p.out_ld & 7) || p.CoutPad < P3_BN) return false;       // (16-B stores of 8 fp16 channels)
     if (p.res && (p.res_ld & 7)) return false;
     if (p.out16 != nullptr && p.out_np != 1) return false;
@@ -396,19 +437,21 @@ bool conv_p3_eligible(const ConvParams& p, long long M) {
     if (M >= (1 << 24) || (long long)(p.N * (p.H + 1) + 1) * (p.W + 2) >= (1 << 24)) return false;       // (fast_div's range)
     // a persistent grid pays its start-up over the work it walks: layers of the batched runs only
     if (M < 4096) return false;
-    return p3_rows_needed(p, M) <= p3_hrt(p.W);
+    if (p.ksize == 1)      // the 1x1 form: stride 1, whole 128-channel groups, at least two of them
+        return p.stride == 1 && p.pad == 0 && p.OH == p.H && p.OW == p.W && p.Kpad == p.Cin && p.Cin % 128 == 0 && p.Cin >= 256;
+    return conv_plh_eligible(p) && p3_width_class(p.W) && p3_rows_needed(p, M) <= p3_hrt(p.W);
 }
 
-template <int W, int HRT, int BPC>
+template <int KSZ, int W, int HRT, int BPC>
 static void launch_p3_w(const ConvParams& p, const P3Args& a, int grid, int lds_bytes, hipStream_t s) {
     const int res = p.res ? (p.res16 ? 1 : 2) : 0;
 #define P3_GO(RES_)                                                                                                                         \
     do {                                                                                                                                    \
-        if (lds_bytes > 64 * 1024) allow_big_lds(reinterpret_cast<const void*>(conv_p3_kernel<W, HRT, RES_, BPC>));                         \
+        if (lds_bytes > 64 * 1024) allow_big_lds(reinterpret_cast<const void*>(conv_p3_kernel<KSZ, W, HRT, RES_, BPC>));                    \
         if (g_conv_prof)                                                                                                                    \
-            hipExtLaunchKernelGGL((conv_p3_kernel<W, HRT, RES_, BPC>), dim3(grid), dim3(256), lds_bytes, s, g_conv_prof->e0, g_conv_prof->e1, 0, p, a); \
+            hipExtLaunchKernelGGL((conv_p3_kernel<KSZ, W, HRT, RES_, BPC>), dim3(grid), dim3(256), lds_bytes, s, g_conv_prof->e0, g_conv_prof->e1, 0, p, a); \
         else                                                                                                                                \
-            hipLaunchKernelGGL((conv_p3_kernel<W, HRT, RES_, BPC>), dim3(grid), dim3(256), lds_bytes, s, p, a);                             \
+            hipLaunchKernelGGL((conv_p3_kernel<KSZ, W, HRT, RES_, BPC>), dim3(grid), dim3(256), lds_bytes, s, p, a);                        \
     } while (0)
     if (res == 0) P3_GO(0);
     else if (res == 1) P3_GO(1);
@@ -417,22 +460,24 @@ static void launch_p3_w(const ConvParams& p, const P3Args& a, int grid, int lds_
 }
 
 void launch_conv_p3(const ConvParams& p, hipStream_t s) {
-    BP_CHECK(conv_p3_eligible(p, p.M), "conv_p3: fp16 planes, 3x3 / stride 1 / pad 1, NHWC store, a width the kernel is built for, M >= 4096");
+    BP_CHECK(conv_p3_eligible(p, p.M), "conv_p3: fp16 planes, NHWC store, M >= 4096; 3x3 / stride 1 / pad 1 at a width the kernel is built for, or 1x1 / stride 1 with Cin % 128 == 0");
+    const bool k3 = p.ksize == 3;
     P3Args a{};
     a.NTN = (p.CoutPad + P3_BN - 1) / P3_BN;
     a.T = ((p.M + P3_BM - 1) / P3_BM) * a.NTN;
-    a.G = p.Cin / 32;
-    const int lds_bytes = 2 * p3_hrt(p.W) * P3_PITCH + a.NTN * P3_BN * 4;     // two halo stages + the bias (a whole number of N tiles)
+    a.G = k3 ? p.Cin / 32 : p.Cin / 128;
+    const int lds_bytes = 2 * (k3 ? p3_hrt(p.W) * P3_PITCH : 128 * 272) + a.NTN * P3_BN * 4;     // two halo stages + the bias (a whole number of N tiles)
     // blocks per CU: two.  Three (<= 168 registers: the skip connection requested inside the epilogue, a few spills there) tie one launch at a
     // time and LOSE 3 % with three streams in flight (5 550 against 5 380 frames/s, configs[2] f16r on one box): these layers run AT the socket
     // power cap (profiles/r06_p3_clock_probe.txt), a third resident block adds register-file and LDS traffic, not matrix work.
-    // BP_P3_BPC = 2 | 3 (A/B runs; read per call)
+    // BP_P3_BPC = 2 | 3 (A/B runs; read per call; 3x3 form only)
     int bpc = 2;
-    if (const char* e = std::getenv("BP_P3_BPC")) bpc = std::atoi(e) == 3 ? 3 : 2;
+    if (const char* e = std::getenv("BP_P3_BPC")) bpc = (std::atoi(e) == 3 && k3) ? 3 : 2;
     a.PX = std::max(1, std::min((a.T + 7) / 8, 32 * bpc));
     if (const char* e = std::getenv("BP_P3_SKEW")) a.skew = std::atoi(e);
     const int grid = 8 * a.PX;
-#define P3_W(W_, HRT_) do { if (bpc == 3) launch_p3_w<W_, HRT_, 3>(p, a, grid, lds_bytes, s); else launch_p3_w<W_, HRT_, 2>(p, a, grid, lds_bytes, s); } while (0)
+    if (!k3) { launch_p3_w<1, 0, 128, 2>(p, a, grid, lds_bytes, s); return; }
+#define P3_W(W_, HRT_) do { if (bpc == 3) launch_p3_w<3, W_, HRT_, 3>(p, a, grid, lds_bytes, s); else launch_p3_w<3, W_, HRT_, 2>(p, a, grid, lds_bytes, s); } while (0)
     switch (p.W) {
         case 13: P3_W(13, 208); break;
         case 16: P3_W(16, 208); break;

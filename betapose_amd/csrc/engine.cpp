@@ -570,6 +570,14 @@ static void choose_launch(const Op& op, int batch, int force_tile, int sk_target
         // (conv_p3.hip); BP_NO_P3=1: the halo plane tile as before (A/B runs)
         static const bool p3_off = std::getenv("BP_NO_P3") != nullptr;
         if (!p3_off && mode == PREC_F16 && s == 1 && t == TILE_PLH128 && !op.pool_out && conv_p3_eligible(c, M)) t = TILE_P3;
+        // ... and its 1x1 form (128-channel groups as the "halo", four chunks as the "taps") for the 1x1 layers with K >= 512, whether they were
+        // planned on the plane tile or on the streaming kernel (28 frames, f16r, one launch at a time, profiles/r06_bench_p1.txt: 20x16 1 024 -> 256
+        // 15.1 / 16.4 -> 12.3 us, 13x13 1 024 -> 512 15.0 / 16.4 -> 12.5, 26x26 512 -> 256 17.2 / 16.5 -> 13.4, 40x32 512 -> 128 17.7 / 16.8 -> 15.5;
+        // at K = 256 the streaming kernel keeps its layers: 256 -> 1 024 16.3 against 17.9, 52x52 256 -> 128 15.7 against 16.4)
+        // BP_P3_K1 = 0: off; 2: every eligible 1x1 layer (sweeps)
+        static const int p3_k1 = std::getenv("BP_P3_K1") ? std::atoi(std::getenv("BP_P3_K1")) : 1;
+        if (!p3_off && p3_k1 && mode == PREC_F16 && s == 1 && c.ksize == 1 && conv_tile_is_pl(t) && !op.pool_out && conv_p3_eligible(c, M) &&
+            (p3_k1 == 2 || c.Cin >= 512)) t = TILE_P3;
         if (force_tile >= 0 && !((force_tile == TILE_S1 || force_tile == TILE_P3) && op.pool_out) && tile_runs(force_tile, c, M)) t = force_tile;
         if (!(sk_target == 512 && sk_min_chunks == 4 && sk_max == 8)) {   // explicit policy (tests, sweeps)
             const long long blocks = ((M + conv_tile_bm(t) - 1) / conv_tile_bm(t)) *

@@ -365,11 +365,44 @@ def test_conv_p3_persistent_3x3_f16(cuda, shape):
     _check(out.cpu().permute(0, 3, 1, 2), ref, tol=2e-5 * scale)
 
 
+P1_SHAPES = [
+    # N, H, W, Cin, Cout, act, res: the 1x1 form of TILE_P3 (128-channel groups, four chunks per group)
+    (28, 20, 16, 1024, 256, "relu", None),       # the key-point detector's layer3 conv1 class: eight groups, 140 tiles, one per block
+    (28, 13, 13, 1024, 512, "leaky", "post"),    # YOLO 13x13 class, M tail (4 732 = 36 tiles + 124 rows), skip connection behind the activation
+    (9, 26, 26, 256, 136, "relu", "pre"),        # TWO groups (the shortest K it takes), Cout % 128 != 0, skip connection before the activation
+    (28, 40, 32, 512, 128, "linear", None),      # 280 tiles: one N tile, four groups
+    (28, 52, 52, 256, 384, "leaky", "post"),     # 1 776 tiles on 512 blocks: three and four tiles per block (the next tile's first halo in the last two groups)
+]
+
+
+@pytest.mark.parametrize("shape", P1_SHAPES)
+def test_conv_p3_1x1_form_f16(cuda, shape):
+    """TILE_P3 on 1x1 / stride-1 layers (conv_p3.hip KSZ = 1): the same persistent skeleton with the tile's own 128 pixels x 128 channels as the
+    LDS stage and the four 32-channel chunks of a group as the taps; a group's rows wait in registers for a whole group before they are parked.
+    Same chunk order and MFMA sequence as the 64x64 plane tile: BIT-IDENTICAL to TILE_PL64; torch at the accumulation-order bar; planes = RNE."""
+    N, H, W, Cin, Cout, act, rmode = shape
+    g = torch.Generator().manual_seed(9700 + Cin + Cout + H)
+    x = (torch.randn(N, H, W, Cin, generator=g) * torch.exp(0.5 * torch.randn(N, H, W, 1, generator=g))).half().float()
+    w = (torch.randn(Cout, Cin, 1, 1, generator=g) / np.sqrt(Cin)).half().float()
+    b = torch.randn(Cout, generator=g)
+    res = torch.randn(N, H, W, Cout, generator=g) if rmode else None
+    ref = _ref(x, w, b, 1, 0, act, res, rmode == "post")
+    kw = dict(pad=0, act=act, res=res.to(cuda) if rmode else None, res_after_act=rmode == "post", splits=1)
+    out, pl = ops.conv2d_nhwc(x.to(cuda), w, b, tile="p3_f16", planes=True, **kw)
+    assert torch.equal(out, ops.conv2d_nhwc(x.to(cuda), w, b, tile="p3_f16", **kw))
+    assert torch.equal(_planes_to_f32(pl, "f16"), out.half().float())
+    base = ops.conv2d_nhwc(x.to(cuda), w, b, tile="pl64_f16", **kw)
+    assert torch.equal(out, base), "max |d| %.3e" % float((out - base).abs().max())
+    scale = max(1.0, float(ref.abs().mean()))
+    _check(out.cpu().permute(0, 3, 1, 2), ref, tol=2e-5 * scale)
+
+
 def test_conv_p3_refuses_other_layers(cuda):
-    """The persistent 3x3 tile takes 3x3 / stride-1 / pad-1 layers at the widths it is built for (13, 16, 26, 32, 52, 104) with M >= 4 096 only."""
+    """The persistent tile takes 3x3 / stride-1 / pad-1 layers at the widths it is built for (13, 16, 26, 32, 52, 104) and 1x1 / stride-1 layers
+    with Cin a multiple of 128 and at least 256, M >= 4 096 -- nothing else."""
     g = torch.Generator().manual_seed(6)
     for (N, H, W, Cin, Cout, k, st) in [(1, 52, 52, 64, 128, 3, 1), (8, 20, 20, 64, 128, 3, 1), (8, 26, 26, 64, 128, 1, 1), (8, 52, 52, 64, 128, 3, 2),
-                                        (8, 26, 26, 48, 128, 3, 1)]:
+                                        (8, 26, 26, 48, 128, 3, 1), (8, 26, 26, 128, 128, 1, 1), (8, 26, 26, 256, 128, 1, 2), (8, 26, 26, 320, 128, 1, 1)]:
         x = torch.randn(N, H, W, Cin, generator=g)
         w = torch.randn(Cout, Cin, k, k, generator=g)
         with pytest.raises(Exception):
