@@ -467,6 +467,10 @@ void launch_conv_p3(const ConvParams& p, hipStream_t s) {
     a.T = ((p.M + P3_BM - 1) / P3_BM) * a.NTN;
     a.G = k3 ? p.Cin / 32 : p.Cin / 128;
     const int lds_bytes = 2 * (k3 ? p3_hrt(p.W) * P3_PITCH : 128 * 272) + a.NTN * P3_BN * 4;     // two halo stages + the bias (a whole number of N tiles)
+    // (Built, parity-green at the accumulation-order bar, and removed in round 6: two K teams inside an eight-wave block for launches of at most
+    // one tile per CU -- 20x16 256 -> 256: 140 tiles, 19.2 -> 18.7 us; 1 024 -> 256: 12.2 -> 12.2.  A lone wave already drives 74 % of its SIMD's
+    // matrix pipe inside the K loop, so a second wave on the same SIMD can add a quarter at most, and the LDS hand-over takes it back; what these
+    // launches lack is the other 116 CUs, i.e. a cross-CU reduction, which costs more than it saves: profiles/r06_plh_splits.txt.)
     // blocks per CU: two.  Three (<= 168 registers: the skip connection requested inside the epilogue, a few spills there) tie one launch at a
     // time and LOSE 3 % with three streams in flight (5 550 against 5 380 frames/s, configs[2] f16r on one box): these layers run AT the socket
     // power cap (profiles/r06_p3_clock_probe.txt), a third resident block adds register-file and LDS traffic, not matrix work.
