@@ -467,6 +467,10 @@ void launch_conv_p3(const ConvParams& p, hipStream_t s) {
     a.T = ((p.M + P3_BM - 1) / P3_BM) * a.NTN;
     a.G = k3 ? p.Cin / 32 : p.Cin / 128;
     const int lds_bytes = 2 * (k3 ? p3_hrt(p.W) * P3_PITCH : 128 * 272) + a.NTN * P3_BN * 4;     // two halo stages + the bias (a whole number of N tiles)
+    // (Also built and removed in round 6: the 3x3 / STRIDE-2 layers on the same position grid over the input map (centres at (2 oy, 2 ox), taps still
+    // immediates, two-way bank conflicts, 736 / 960 halo rows = one block per CU, 12-15 loader passes): 104x104 -> 52x52 63.0 against 67.1 us on the
+    // 128x128 plane tile, 52x52 -> 26x26 66.2 against 70.3, 26x26 -> 13x13 83.1 against 70.1 -- one lone-wave block per CU is no better than the tile
+    // it would replace; those layers want a 2-D patch / row-segment halo)
     // (Built, parity-green at the accumulation-order bar, and removed in round 6: two K teams inside an eight-wave block for launches of at most
     // one tile per CU -- 20x16 256 -> 256: 140 tiles, 19.2 -> 18.7 us; 1 024 -> 256: 12.2 -> 12.2.  A lone wave already drives 74 % of its SIMD's
     // matrix pipe inside the K loop, so a second wave on the same SIMD can add a quarter at most, and the LDS hand-over takes it back; what these
