@@ -374,7 +374,7 @@ def roofline(det, pose, batch):
     for k_, g_ in sorted(groups.items(), key=lambda kv: -kv[1]["ms"]):
         m_ = {2: "f16", 3: "bf16x3"}.get(k_[1], "f32")
         tf_ = g_["flops"] / (g_["ms"] * 1e-3) / 1e12
-        per_kernel.append({"kernel": kernel_name(k_[0], m_) if m_ != "f32" else ("bp::stem3x3_kernel" if k_[0] == 20 else "bp::conv_igemm_kernel<1, 1, %d>" % k_[1]),
+        per_kernel.append({"kernel": kernel_name(k_[0], m_) if m_ != "f32" else ("bp::stem3x3_kernel" if k_[0] == 20 else ("bp::stem7x7_f16_kernel" if k_[0] == 28 else "bp::conv_igemm_kernel<1, 1, %d>" % k_[1])),
                            "launches": g_["launches"], "us_per_step": round(g_["ms"] * 1e3, 1), "avg_launch_us": round(g_["ms"] / g_["launches"] * 1e3, 2),
                            "gflop": round(g_["flops"] / 1e9, 2), "achieved_TFLOPs": round(tf_, 1), "frac": round(tf_ / peak_of[m_], 4),
                            # (per-op bytes are the batch-1 figure -- fp32 operands and results, weights once: not scaled to batched runs)

@@ -103,6 +103,8 @@ struct ConvParams {
     int skip_f32;                 // 1: every reader of `out` takes the planes -- the fp32 store is dropped (engine.cpp plan_planes)
     const unsigned short* res16;  // fp16 plane of the residual view `res` (same ld): the epilogue reads the residual from it instead of the
                                   // fp32 tensor (fp16 mode with fp16 skip connections, Net::set_f16_residuals; `res` stays set: it selects the epilogue)
+    int net_prec;                 // the ENGINE's precision mode (Net::set_precision) -- for the layers the 16-bit modes do not cover by themselves (the
+                                  // RGB stems keep mfma_mode == PREC_F32): which of their kernels fits the mode the rest of the network runs in
     int abl;                      // timing ablations, experimental builds only (-DBP_EXPERIMENTAL; tools/abl_pl.sh): 0 in the product
     const unsigned short* wbd;    // filters as stage-packed fragments in conv_pl.hip's K order (TILE_PL64BD: launch_f32_to_bf16x3_staged with Cin)
     const unsigned short* wpl;    // filters as conv_pl.hip's LDS image: [CoutPad/64][nchunks][plane][64 rows][64 B swizzled]
@@ -173,6 +175,7 @@ enum ConvTile : int { TILE_64x64 = 0, TILE_128x64 = 1, TILE_W64_1x1 = 2, TILE_W6
                       TILE_PLH128 = 25,     // conv_pl.hip 128x128 with the activations of a 3x3 / stride-1 layer from an LDS-resident halo (fp16; round 4)
                       TILE_S1 = 26,         // conv_s1.hip: the 1x1 layers of the batched fp16 runs as a persistent streaming kernel (32-row M-tiles resident in LDS, 128-column passes; round 5)
                       TILE_P3 = 27,         // conv_p3.hip: the 3x3 / stride-1 layers of the batched fp16 runs as a persistent kernel (128 pixels x 32 columns per wave, filter fragments global -> registers, zero-padded halo in LDS with the taps as instruction immediates, register-only epilogue; round 6)
+                      TILE_STEM7 = 28,      // the key-point detector's 7x7 / stride-2 RGB stem on the fp16 matrix pipe (conv_igemm.hip stem7x7_f16_kernel; fp16 modes only; round 6)
                       TILE_LAST = 27,       // (the last id a policy may force)
                       TILE_FUSED = 40 };    // reporting only (Net::profile): the op is the last member of a block fused into one launch (conv_fused.hip)
 
@@ -219,6 +222,7 @@ int conv_fused_blocks(const ConvParams& pre, const ConvParams& c3, const ConvPar
 void launch_conv_fused(const ConvParams& pre, const ConvParams& c3, const ConvParams* post, hipStream_t s);
 int conv_tiles(const ConvParams& p, int tile);   // blocks per K-slice
 bool conv_stem3_eligible(const ConvParams& p);   // conv_igemm.hip: the layer can run on TILE_STEM3
+bool conv_stem7_eligible(const ConvParams& p);   // ... on TILE_STEM7 (7x7 / stride 2 / pad 3, 4-channel-packed RGB in, 64 channels out)
 void conv_grid_setup(ConvParams& q, int bm, int bn);   // fills mtiles / n_tiles / work_blocks / pf_first from M, CoutPad, splits, xcd_home
 int conv_grid_blocks(const ConvParams& q);
 int xcc_base();                                                // engine.cpp: XCC_ID of block 0 (round-robin dispatch), -1: unusable

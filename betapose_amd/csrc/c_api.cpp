@@ -539,7 +539,7 @@ int bp_conv2d_planes(const float* d_in, int N, int H, int W, int Cin, const floa
 #endif
     } else {
         if (t < 0 && bp::conv_stem3_eligible(net.ops_[0].conv)) t = bp::TILE_STEM3;      // as the engine plans it
-        BP_CHECK(t <= bp::TILE_128x64 || (t == bp::TILE_STEM3 && bp::conv_stem3_eligible(net.ops_[0].conv)),
+        BP_CHECK(t <= bp::TILE_128x64 || (t == bp::TILE_STEM3 && bp::conv_stem3_eligible(net.ops_[0].conv)) || (t == bp::TILE_STEM7 && bp::conv_stem7_eligible(net.ops_[0].conv)),
                  "this tile needs a 16-bit precision mode (tile + 256 / + 512), or the layer is not a 3x3 / stride-1 / 4-channel-packed stem");
     }
     bp::ConvParams p = net.ops_[0].conv;

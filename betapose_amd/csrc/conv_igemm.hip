@@ -887,6 +887,150 @@ __global__ __launch_bounds__(256) void stem3x3_f16_kernel(const ConvParams p) {
     }
 }
 
+// =====================================================================================================================
+// The key-point detector's 7x7 / stride-2 / pad-3 RGB stem in the fp16 modes (round 6; KPD/src/models/layers/SE_Resnet.py:58-60 conv1 + bn1 +
+// relu).  On the fp32 MFMA kernel the layer is COMPUTE-bound at 28 frames per launch -- 10.8 GFLOP at 68 TFLOP/s, 45 % of that pipe's roof:
+// 159 us, 2.7 % of configs[2] -- while its bytes (28 MB of crops in, 147 MB of fp32 out) are a 30 us pass.  Same recipe as the detector's stem above:
+// a block owns 64 consecutive output pixels per group, every tap is ONE 16-B load per pixel (the packed RGB crop: red, green, blue, a zero),
+// converted to four fp16 and parked as the pixel's im2col row in LDS -- 49 taps x 4 = 196 of 224 k, rows of 464 B (an odd multiple of 16 B) --
+// four threads per pixel, 12-13 taps each; each wave multiplies 32 pixels by 32 of the 64 filters (fp16 from the packed fp32 filters,
+// k = tap 4 + channel as they are stored; 56 registers for the whole kernel) with fourteen v_mfma_f32_32x32x16_f16; bias / activation and 16-B
+// stores through a staging tile.  A block walks G groups with the next group's taps in flight.  fp16 operands, fp32 accumulation: the
+// arithmetic of the mode; the fp32-accurate modes keep the fp32 MFMA kernel.
+// =====================================================================================================================
+__global__ __launch_bounds__(256, 2) void stem7x7_f16_kernel(const ConvParams p) {
+    constexpr int RB = 464, LDT = 68, GP = 64, NT = 13;     // im2col row bytes; staging row floats; pixels per group; taps per thread
+    __shared__ __attribute__((aligned(16))) char rows[GP * RB];
+    __shared__ __attribute__((aligned(16))) float S[GP * LDT];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = wave >> 1, wc = wave & 1;               // the wave's 32 pixels / 32 channels of the group
+    // the filters of this lane's channel, k half lane >> 5 of the fourteen k-steps: fp32 -> fp16 once per block
+    f16x8 fb[14];
+    {
+        const float* w = p.w + (long long)(32 * wc + (lane & 31)) * p.Kpad + 8 * (lane >> 5);
+#pragma unroll
+        for (int ks = 0; ks < 14; ++ks) {
+            const f32x4 lo = *reinterpret_cast<const f32x4*>(w + 16 * ks), hi = *reinterpret_cast<const f32x4*>(w + 16 * ks + 4);
+            const f16x4 l = __builtin_convertvector(lo, f16x4), h = __builtin_convertvector(hi, f16x4);
+            fb[ks] = __builtin_shufflevector(l, h, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+    }
+    const int pix = tid >> 2, tq = tid & 3;                // thread -> pixel tid >> 2 of the group, taps tq, tq + 4, ...
+    const int c0 = tq * 16;                                // ... and, in the stores, channels 16 tq .. + 15
+    const f32x4 b4a = *reinterpret_cast<const f32x4*>(p.bias + c0), b4b = *reinterpret_cast<const f32x4*>(p.bias + c0 + 4),
+                b4c = *reinterpret_cast<const f32x4*>(p.bias + c0 + 8), b4d = *reinterpret_cast<const f32x4*>(p.bias + c0 + 12);
+    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.in), 0, (int)min((long long)p.N * p.H * p.W * p.in_ld * 4, (long long)OOB), 0x00020000);
+    const int hw = p.OH * p.OW;
+    const float rcp_hw = 1.0f / (float)hw, rcp_ow = 1.0f / (float)p.OW;
+    // k 196 .. 223 of every row: zeros, once (the taps never write there; the filters are zero there, but 0 x garbage may be NaN)
+    if (tq == 0) {
+        *reinterpret_cast<u32x2*>(rows + pix * RB + 392) = u32x2{0u, 0u};
+        *reinterpret_cast<u32x4*>(rows + pix * RB + 400) = u32x4{0u, 0u, 0u, 0u};
+        *reinterpret_cast<u32x4*>(rows + pix * RB + 416) = u32x4{0u, 0u, 0u, 0u};
+        *reinterpret_cast<u32x4*>(rows + pix * RB + 432) = u32x4{0u, 0u, 0u, 0u};
+    }
+    auto load_taps = [&](int m0, f32x4* x) __attribute__((always_inline)) {
+        const int m = min(m0 + pix, p.M - 1);
+        const int b = fast_div(m, hw, rcp_hw), rem = m - b * hw;
+        const int oy = fast_div(rem, p.OW, rcp_ow), ox = rem - oy * p.OW;
+        const int base = (b * p.H + 2 * oy - 3) * p.W + 2 * ox - 3;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int t = 4 * i + tq;
+            const int ky = (t * 37) >> 8, kx = t - 7 * ky;      // t / 7 for t < 49
+            const int iy = 2 * oy - 3 + ky, ix = 2 * ox - 3 + kx;
+            const bool ok = (t < 49) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+            const unsigned off = (unsigned)((base + ky * p.W + kx) * p.in_ld * 4);
+            x[i] = buf_load4(rsrcA, ok ? off : OOB, 0);
+        }
+    };
+    const int groups = (p.M + GP - 1) / GP, G = (groups + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int g0 = (int)blockIdx.x * G;
+    f32x4 xn[NT];
+    load_taps(g0 * GP, xn);
+    for (int g = 0; g < G; ++g) {
+        const int m0 = (g0 + g) * GP;
+        if (m0 >= p.M) break;                            // (block-uniform)
+        f32x4 x[NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) x[i] = xn[i];
+        if (g + 1 < G && m0 + GP < p.M) load_taps(m0 + GP, xn);     // the next group's taps travel while this one is processed
+        {
+            char* const row = rows + pix * RB;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int t = 4 * i + tq;
+                f32x4 v = x[i];
+                if (p.Cin < 4) v.w = 0.f;                    // (the neighbour pixel's red: its filter entry is zero, but keep the product finite)
+                if (t < 49) *reinterpret_cast<f16x4*>(row + 8 * t) = __builtin_convertvector(v, f16x4);
+            }
+        }
+        __syncthreads();
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        {
+            const char* const arow = rows + (32 * wp + (lane & 31)) * RB + (lane >> 5) * 16;
+#pragma unroll
+            for (int ks = 0; ks < 14; ++ks)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(arow + 32 * ks), fb[ks], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            S[(32 * wp + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDT + 32 * wc + (lane & 31)] = acc[r];
+        __syncthreads();                                     // the tile is staged; the im2col rows are free for the next group
+        const int m = m0 + pix;
+        if (m < p.M && c0 < p.Cout) {
+            const float* srow = S + pix * LDT + c0;
+            f32x4 v[4] = {*reinterpret_cast<const f32x4*>(srow) + b4a, *reinterpret_cast<const f32x4*>(srow + 4) + b4b,
+                          *reinterpret_cast<const f32x4*>(srow + 8) + b4c, *reinterpret_cast<const f32x4*>(srow + 12) + b4d};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (p.act == ACT_LEAKY) {
+                    v[q].x = v[q].x > 0.f ? v[q].x : 0.1f * v[q].x; v[q].y = v[q].y > 0.f ? v[q].y : 0.1f * v[q].y;
+                    v[q].z = v[q].z > 0.f ? v[q].z : 0.1f * v[q].z; v[q].w = v[q].w > 0.f ? v[q].w : 0.1f * v[q].w;
+                } else if (p.act == ACT_RELU) {
+                    v[q].x = v[q].x > 0.f ? v[q].x : 0.f; v[q].y = v[q].y > 0.f ? v[q].y : 0.f;
+                    v[q].z = v[q].z > 0.f ? v[q].z : 0.f; v[q].w = v[q].w > 0.f ? v[q].w : 0.f;
+                }
+            }
+            const long long e = (long long)m * p.out_ld + c0;
+            if (!(p.out16 && p.skip_f32)) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(p.out + e + 4 * q) = v[q];
+            }
+            if (p.out16 && p.out_np == 1) {
+                const f16x4 h0 = __builtin_convertvector(v[0], f16x4), h1 = __builtin_convertvector(v[1], f16x4),
+                            h2 = __builtin_convertvector(v[2], f16x4), h3 = __builtin_convertvector(v[3], f16x4);
+                *reinterpret_cast<f16x8*>(p.out16 + e) = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+                *reinterpret_cast<f16x8*>(p.out16 + e + 8) = __builtin_shufflevector(h2, h3, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+        }
+        // (the next group's staging writes sit behind its own first barrier, after every thread's reads of S above)
+    }
+}
+
+bool conv_stem7_eligible(const ConvParams& p) {
+    return p.cin_pack == 4 && p.Cin <= 4 && p.in_ld == 4 && p.ksize == 7 && p.stride == 2 && p.pad == 3 && p.Cout == 64 && p.CoutPad == 64 &&
+           p.Kpad == 224 && p.store_mode == ST_NHWC && p.res == nullptr && p.res_scale == nullptr && p.pool_out == nullptr && (p.out_ld & 7) == 0 &&
+           (p.out16 == nullptr || p.out_np == 1) && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.out16) & 15) == 0 &&
+           (long long)p.M * p.out_ld * 4 < (long long)OOB && (long long)p.N * p.H * p.W * 16 < (long long)OOB && p.M < (1 << 24);
+}
+
+static void launch_stem7(const ConvParams& p, hipStream_t s) {
+    BP_CHECK(conv_stem7_eligible(p) && p.splits == 1, "not the 7x7 / stride-2 / packed-RGB stem");
+    // groups of 64 pixels per block: 8 (BP_STEM7_G for the sweep), fewer where that would leave less than two blocks per CU
+    static const int g_env = std::getenv("BP_STEM7_G") ? std::atoi(std::getenv("BP_STEM7_G")) : 0;
+    const int groups = (p.M + 63) / 64;
+    int per = g_env > 0 ? g_env : 8;
+    while (per > 1 && groups / per < 512) --per;
+    const dim3 g((groups + per - 1) / per);
+    if (g_conv_prof) hipExtLaunchKernelGGL(stem7x7_f16_kernel, g, dim3(256), 0, s, g_conv_prof->e0, g_conv_prof->e1, 0, p);
+    else hipLaunchKernelGGL(stem7x7_f16_kernel, g, dim3(256), 0, s, p);
+}
+
 // the fp16 modes' stem: 32 output channels, an fp16 plane wanted by the next layer (BP_NO_STEM_F16=1: the direct convolution, A/B runs)
 static bool stem3_f16_wanted(const ConvParams& p) {
     static const bool off = std::getenv("BP_NO_STEM_F16") != nullptr;
@@ -1029,6 +1173,8 @@ void launch_conv(const ConvParams& p, int tile, hipStream_t s) {
              "output / residual tensor too large for 32-bit offsets");
     if (tile == TILE_STEM3) {
         launch_stem3(p, s);
+    } else if (tile == TILE_STEM7) {
+        launch_stem7(p, s);
     } else if (conv_tile_is_pl(tile)) {
         launch_conv_pl(p, tile, s);
     } else if (conv_tile_is_halo(tile)) {

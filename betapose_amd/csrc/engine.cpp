@@ -552,6 +552,13 @@ static bool stem3_wanted(const ConvParams& c, int force_tile) {
     return !off && (force_tile < 0 || force_tile == TILE_STEM3) && conv_stem3_eligible(c);
 }
 
+// the 7x7 / stride-2 RGB stem runs on the fp16 matrix pipe when the ENGINE is in an fp16 mode (the layer itself is not 16-bit eligible: 3 input
+// channels); BP_NO_STEM7=1: on the fp32 MFMA kernel as before (A/B runs)
+static bool stem7_wanted(const ConvParams& c, int force_tile) {
+    static const bool off = std::getenv("BP_NO_STEM7") != nullptr;
+    return !off && force_tile < 0 && c.net_prec == PREC_F16 && conv_stem7_eligible(c);
+}
+
 static void choose_launch(const Op& op, int batch, int force_tile, int sk_target, int sk_min_chunks, int sk_max,
                           int* tile, int* splits, int* cps, bool lone = false) {
     const int mode = op.conv.mfma_mode;
@@ -588,6 +595,8 @@ static void choose_launch(const Op& op, int batch, int force_tile, int sk_target
         if (t == TILE_S1 || t == TILE_P3) s = 1;     // (a persistent grid: no K slices)
     } else if (stem3_wanted(c, force_tile)) {
         t = TILE_STEM3;       // the RGB 3x3 stem: direct convolution, no K slices
+    } else if (stem7_wanted(c, force_tile)) {
+        t = TILE_STEM7;       // the 7x7 / stride-2 RGB stem in the fp16 modes: fp16 MFMA over im2col rows in LDS, no K slices
     } else {
         if ((force_tile == TILE_64x64 || force_tile == TILE_128x64) && tile_runs(force_tile, c)) t = force_tile;
         const int bm = conv_tile_bm(t);
@@ -657,7 +666,7 @@ int Net::add_conv(const std::string& name, const Tensor& in, const Tensor& out_v
     c.tickets = nullptr;
     c.stamps = nullptr;
     c.w16 = nullptr; c.w16s = nullptr;
-    c.in16 = nullptr; c.out16 = nullptr; c.wpl = nullptr; c.wbd = nullptr; c.in16_plane = c.out16_plane = 0; c.out_np = 0; c.abl = 0; c.skip_f32 = 0; c.res16 = nullptr;
+    c.in16 = nullptr; c.out16 = nullptr; c.wpl = nullptr; c.wbd = nullptr; c.in16_plane = c.out16_plane = 0; c.out_np = 0; c.abl = 0; c.skip_f32 = 0; c.res16 = nullptr; c.net_prec = PREC_F32;
     c.pool_out = nullptr; c.hy_full = c.hy_splits = c.hy_cps = 0;
     c.pf_ptr = nullptr; c.xcd_home = 0; c.xcc_of = nullptr; c.err_word = nullptr; c.tickets_local = nullptr; c.mtiles = c.n_tiles = c.work_blocks = c.pf_first = 0;
     c.pf_ntn = c.pf_splits = c.pf_cps = c.pf_nchunks = c.pf_tile_stride = c.pf_chunk_bytes = c.pf_cap = 0;
@@ -815,7 +824,7 @@ void Net::set_precision(int prec) {
     //             holds 72 KB of LDS per block against 24.5 KB, and runs the pipeline 5 % SLOWER at batch 1 and at batch 28;
     //             BP_B3_PLANES=1 puts this mode on the plane path too (tests, A/B runs).
     for (Op& op : ops_)
-        if (op.type == OP_CONV) { op.conv.w16 = nullptr; op.conv.w16s = nullptr; }
+        if (op.type == OP_CONV) { op.conv.w16 = nullptr; op.conv.w16s = nullptr; op.conv.net_prec = prec; }
     static const bool b3_planes = std::getenv("BP_B3_PLANES") != nullptr;
     const bool plane_path = prec == PREC_F16 || (prec == PREC_BF16X3 && b3_planes);
     if (prec != PREC_F32) {

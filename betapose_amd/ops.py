@@ -15,7 +15,7 @@ STORE = {"nhwc": 0, "up2": 1, "pixshuf": 2, "nchw": 3}
 # + 256: fp16 operands, + 512: bf16x3 (fp32-accurate) operands.  pl<BM>[x<BN>] = conv_pl.hip (operand planes + LDS-DMA);
 # w<WM>x<WN> = conv_w64.hip with WM x WN waves of 64x64; kg / rd / bd: the round-2 experiments (csrc/bp_common.h ConvTile)
 _F16, _B3 = 256, 512
-TILE = {"auto": -1, "64x64": 0, "128x64": 1, "stem3": 20, "64x64_f16": _F16, "128x64_f16": _F16 + 1, "64x64_b3": _B3, "bd_b3": _B3 + 12,
+TILE = {"auto": -1, "64x64": 0, "128x64": 1, "stem3": 20, "stem7": 28, "64x64_f16": _F16, "128x64_f16": _F16 + 1, "64x64_b3": _B3, "bd_b3": _B3 + 12,
         "bd_f16": _F16 + 12, "halo64_b3": _B3 + 21, "halo128_b3": _B3 + 22, "halo64k2_b3": _B3 + 23, "bdk2_b3": _B3 + 24}
 for _n, _i in (("w1x1", 2), ("w1x2", 3), ("w2x1", 5), ("w2x2", 6), ("pl64", 13), ("pl128", 14), ("pl128x64", 15), ("pl256x128", 16), ("pl128s", 17), ("pl64k2", 18), ("pl64bd", 19), ("plh128", 25), ("s1", 26), ("p3", 27)):
     TILE[_n + "_f16"] = _F16 + _i
