@@ -605,7 +605,7 @@ def insitu_layers(dets, poses, run, S, batch, path, precision):
     return summary
 
 
-def served_leg(ys, ks, local, batch, streams, precision, steps, kp3d, cam_K, label, detail=False):
+def served_leg(ys, ks, local, batch, streams, precision, steps, kp3d, cam_K, label, detail=False, power=False):
     """One more line of the same hot path with `batch` frames per launch on `n_streams` streams (the reference's --detbatch,
     dataloader.py:284-289): its own engines (max_batch = batch), frames resident in HBM, host tail inside the timed region,
     barrier-free single-GPU timing (synchronize both sides).  Returns frames/s, ms per step and the convolution GFLOP per frame."""
@@ -661,16 +661,27 @@ def served_leg(ys, ks, local, batch, streams, precision, steps, kp3d, cam_K, lab
     torch.cuda.synchronize()
     tw = (time.perf_counter() - tw) / max(2 * S, 8)
     steps = int(min(max(steps, 1.5 / max(tw, 1e-6)), 4000))
+    cs = ClockSampler(period=0.25) if power else None
+    if cs:
+        cs.__enter__()
     t0 = time.perf_counter()
     run(steps)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    if cs:
+        cs.__exit__(None, None, None)
     gflop = sum(float(n_.op_stats()[0].sum()) for n_ in (det, pose)) / 1e9          # conv FLOPs per frame (op_stats is per image)
     alg_bytes = sum(float(n_.op_stats()[1].sum()) for n_ in (det, pose))
     if precision in ("f16", "f16r"):   # the bytes of the mode that ran: fp16 planes, filters once per launch
         alg_bytes = mode_bytes_per_frame((det, pose), batch, 2.0)
     res = {"label": label, "value": round(steps * batch / el, 2), "unit": "frames/sec", "batch": batch, "streams": S, "precision": precision,
            "steps": steps, "ms_per_step": round(el / steps * 1e3, 4), "poses": got["poses"], "graph_nodes": pipes[0].kernel_count()}
+    if cs:       # shader clock / socket power / SMU limiter / joules per frame DURING this leg's timed region (round 6: the batched fp16 legs sit on
+        # the socket power cap -- frames/s there is 1 / joules per frame)
+        pw = dict(cs.summary() or {})
+        pw.update(cs.limits(steps * batch) or {})
+        pw["power_cap_W"] = _power_cap_w()
+        res["power"] = pw
     if detail:   # the leg's own kernel table and layer classes (eager pass, every launch alone between HIP events) at ITS batch size and precision
         rf = roofline(det, pose, batch)
         res["detail"] = {"kernels": rf["kernels"], "isolated": rf["isolated"], "layer_classes": rf["layer_classes"]}
@@ -994,13 +1005,13 @@ def main():
         # BASELINE configs[2] on the driver's clock: fp16 MFMA operands, 28 crops / frames per launch, 3 streams
         c2, gf, ab = served_leg(ys, ks, local, 28, streams[:3], "f16", max(30, min(a.steps, 60)), kp3d, cam_K,
                                 "BASELINE configs[2]: batched inference, 28 frames per launch x 3 streams, fp16 MFMA conv path "
-                                "(fp16 operands, fp32 accumulation, fp32 activations and skip connections)", detail=True)
+                                "(fp16 operands, fp32 accumulation, fp32 activations and skip connections)", detail=True, power=True)
         c2_detail = c2.pop("detail")
         # the same leg with fp16 skip connections ('f16r': residuals read from the fp16 operand planes, fp32 copies of block outputs
         # dropped -- a further stated-tolerance step, tests/test_gpu_nets.py::test_f16r_mode_fp16_skip_connections)
         c2r, _, _ = served_leg(ys, ks, local, 28, streams[:3], "f16r", max(30, min(a.steps, 60)), kp3d, cam_K,
-                               "configs[2] with fp16 skip connections (precision 'f16r')")
-        c2["with_fp16_skip_connections"] = {k_: c2r[k_] for k_ in ("label", "value", "unit", "steps", "ms_per_step", "precision")}
+                               "configs[2] with fp16 skip connections (precision 'f16r')", power=True)
+        c2["with_fp16_skip_connections"] = {k_: c2r[k_] for k_ in ("label", "value", "unit", "steps", "ms_per_step", "precision", "power") if k_ in c2r}
         c2["with_fp16_skip_connections"]["roofline_frac"] = round(gf * c2r["value"] / 1e3 / PEAK_F16_MFMA_TFLOPS, 4)
         tf = gf * c2["value"] / 1e3
         c2["roofline"] = {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_F16_MFMA_TFLOPS, 4),
