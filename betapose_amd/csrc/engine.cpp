@@ -827,6 +827,11 @@ void Net::set_precision(int prec) {
         if (op.type == OP_CONV) { op.conv.w16 = nullptr; op.conv.w16s = nullptr; op.conv.net_prec = prec; }
     static const bool b3_planes = std::getenv("BP_B3_PLANES") != nullptr;
     const bool plane_path = prec == PREC_F16 || (prec == PREC_BF16X3 && b3_planes);
+    // BP_B3_MIX=<pixels>: the per-layer form of that switch (round-5 verdict item 6) -- the 3x3 / stride-1 layers whose map has at most that many
+    // pixels per image (the 22 layer-3 bottlenecks of the key-point detector: 20x16) read bf16x3 planes their 1x1 producers write, so that an
+    // activation is split once instead of once per tap and N tile; every other layer stays on the fp32-activation kernels
+    static const int b3_mix = std::getenv("BP_B3_MIX") ? std::atoi(std::getenv("BP_B3_MIX")) : 0;
+    const bool mixed = prec == PREC_BF16X3 && !plane_path && b3_mix > 0;
     if (prec != PREC_F32) {
         std::lock_guard<std::mutex> lk(store_->f16_mutex);
         bool made = false;
@@ -883,7 +888,7 @@ void Net::set_precision(int prec) {
             if (op.type == OP_CONV && op.conv.w16s) op.conv.w16s = big;
     }
 #endif
-    plan_planes(plane_path ? prec : PREC_F32);
+    plan_planes(plane_path || mixed ? prec : PREC_F32, mixed ? b3_mix : 0);
     for (Op& op : ops_)
         if (op.type == OP_CONV) op.conv.mfma_mode = (prec != PREC_F32 && (conv_h16_eligible(op.conv) || conv_pl_eligible(op.conv))) ? prec : PREC_F32;
     precision_ = prec;
@@ -906,18 +911,21 @@ Net::ActAlloc* Net::find_act(const float* p) {
 // conv_tail.inc, the pooling / shuffle / copy kernels through a conversion launch -- is pointed at them, and the
 // filters are packed into the kernel's LDS image.  Planes are allocated once per engine (first 16-bit mode), outside any
 // graph capture.
-void Net::plan_planes(int prec) {
+void Net::plan_planes(int prec, int mix_hw) {
     for (Op& op : ops_) {
         op.out16 = nullptr; op.out16_plane = 0;
         if (op.type == OP_CONV) { op.conv.in16 = nullptr; op.conv.out16 = nullptr; op.conv.wpl = nullptr; op.conv.wbd = nullptr; op.conv.out_np = 0; op.conv.in16_plane = op.conv.out16_plane = 0; op.conv.skip_f32 = 0; op.conv.res16 = nullptr; }
     }
-    for (ActAlloc& a : acts_) a.f32_read = true;
+    for (ActAlloc& a : acts_) { a.f32_read = true; a.wanted = false; }
     if (prec == PREC_F32) return;
 #ifdef BP_EXPERIMENTAL
     if (std::getenv("BP_LEGACY")) return;   // A/B runs: the fp32-activation data path in every mode
 #endif
     const int np = prec == PREC_F16 ? 1 : 3;
-    auto pl_shape_ok = [](const ConvParams& c) { return (c.Cin % 32 == 0) && (c.in_ld % 8 == 0) && c.ksize * c.ksize <= 32; };
+    auto pl_shape_ok = [mix_hw](const ConvParams& c) {
+        if (mix_hw > 0 && !(c.ksize == 3 && c.stride == 1 && c.OH * c.OW <= mix_hw)) return false;   // (BP_B3_MIX: only the small 3x3 layers)
+        return (c.Cin % 32 == 0) && (c.in_ld % 8 == 0) && c.ksize * c.ksize <= 32;
+    };
     bool made = false;
     for (Op& op : ops_) {
         if (op.type != OP_CONV || !pl_shape_ok(op.conv)) continue;
@@ -942,14 +950,14 @@ void Net::plan_planes(int prec) {
     for (Op& op : ops_) {
         if (op.type == OP_CONV) {
             ConvParams& c = op.conv;
-            if (ActAlloc* o = find_act(c.out); o && o->planes) {
+            if (ActAlloc* o = find_act(c.out); o && o->planes && o->wanted) {
                 c.out16 = o->planes + (c.out - o->base);
                 c.out16_plane = (long long)o->elems;
                 c.out_np = np;
             }
             if (!pl_shape_ok(c)) continue;
             ActAlloc* a = find_act(c.in);
-            if (!a || !a->planes || (c.in - a->base) % 8 != 0) continue;
+            if (!a || !a->planes || !a->wanted || (c.in - a->base) % 8 != 0) continue;
             c.in16 = a->planes + (c.in - a->base);
             c.in16_plane = (long long)a->elems;
             auto it = packed.find(c.w);
@@ -973,7 +981,7 @@ void Net::plan_planes(int prec) {
             }
 #endif
         } else if (op.out) {
-            if (ActAlloc* o = find_act(op.out); o && o->planes) {
+            if (ActAlloc* o = find_act(op.out); o && o->planes && o->wanted) {
                 op.out16 = o->planes + (op.out - o->base);
                 op.out16_plane = (long long)o->elems;
             }
@@ -988,7 +996,7 @@ void Net::plan_planes(int prec) {
     // its producers drop the fp32 store (4 of 10 bytes per element in the bf16x3 mode, 4 of 6 in the fp16 mode; the
     // dirty lines a kernel leaves behind are written back before its successor starts).  BP_KEEP_F32=1 keeps them all.
     static const bool keep_all = std::getenv("BP_KEEP_F32") != nullptr;
-    for (ActAlloc& a : acts_) a.f32_read = keep_all || a.planes == nullptr;
+    for (ActAlloc& a : acts_) a.f32_read = keep_all || a.planes == nullptr || !a.wanted;
     auto mark = [&](const float* q) { if (q) if (ActAlloc* a = find_act(q)) a->f32_read = true; };
     // fp16 skip connections (PREC_F16_RES): a residual whose tensor has an fp16 plane -- some convolution reads it as input, so its
     // producer writes the plane anyway -- is read from that plane (2 B per element instead of 4) and does not keep the fp32 tensor alive

@@ -138,7 +138,7 @@ protected:
                       bool f32_read = true; };   // f32_read: something reads the fp32 tensor (a residual, a pooling kernel, a head)
     std::vector<ActAlloc> acts_;
     ActAlloc* find_act(const float* p);
-    void plan_planes(int prec);   // allocate the planes 16-bit consumers need, point every producer / consumer at them
+    void plan_planes(int prec, int mix_hw = 0);   // allocate the planes 16-bit consumers need, point every producer / consumer at them
     int max_batch_;
     std::shared_ptr<WeightStore> store_;
     bool reuse_;
