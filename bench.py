@@ -336,7 +336,7 @@ def roofline(det, pose, batch):
     achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12
     # HBM traffic per launch of that kernel: not measurable from inside the process -- taken from the committed
     # rocprofv3 PMC passes (profiles/*_pmc_traffic.json, collected with tools/pmc_traffic.sh, corrections inside)
-    traffic, traffic_src = None, None
+    traffic, traffic_src, traffic_rw = None, None, None
     mode = {2: "f16", 3: "bf16x3"}.get(key[1], "f32")
     def kernel_name(tile, mode):
         if mode == "f32":
@@ -385,6 +385,7 @@ def roofline(det, pose, batch):
             t = json.load(open(f))
             if t.get("kernel", "").startswith(want):
                 traffic, traffic_src = t["traffic_bytes_per_launch"], os.path.relpath(f, ROOT)
+                traffic_rw = {"fetch": t.get("fetch_bytes_per_launch"), "write": t.get("write_bytes_per_launch")}
                 break
     except Exception:
         pass
@@ -397,6 +398,7 @@ def roofline(det, pose, batch):
     return {
         "bound": "mfma", "peak": round(peak, 1), "unit": "TFLOP/s",
         "traffic": traffic, "traffic_source": traffic_src,
+        "traffic_fetch_write_bytes_per_launch": traffic_rw,     # (HBM-side bytes of the dominant kernel per launch, the two PMC passes apart)
         "algorithmic_bytes_per_launch": g["bytes"] / g["launches"],
         "kernel": name, "launches_per_step": g["launches"], "flops_per_launch": g["flops"] / g["launches"],
         # the dominant kernel ALONE (eager pass, hipExtLaunchKernelGGL start/stop events around every launch): its
