@@ -478,7 +478,6 @@ bool conv_halo_eligible(const ConvParams& p, int tile) {
     if (!conv_tile_is_halo(tile)) return false;
     if (!(p.ksize == 3 && p.stride == 1 && p.pad == 1 && p.OH == p.H && p.OW == p.W)) return false;
     if (!(p.w16s != nullptr && p.Cin % 32 == 0 && p.in_ld % 4 == 0 && p.Kpad == 9 * p.Cin)) return false;
-    if (p.out16 != nullptr) return false;   // (this kernel's epilogue writes fp32 only: a layer whose consumer reads operand planes -- BP_B3_MIX -- stays on the filters-direct kernel)
     if (p.CoutPad % (tile == TILE_HALO64K2 ? 64 : 32 * halo_nw(tile)) != 0) return false;
     const int np = halo_passes(p, tile);
     return tile == TILE_HALO128 ? (np >= 2 && np <= 4) : (np >= 3 && np <= 7);

@@ -923,6 +923,7 @@ __global__ __launch_bounds__(256, 2) void stem7x7_f16_kernel(const ConvParams p)
     const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.in), 0, (int)min((long long)p.N * p.H * p.W * p.in_ld * 4, (long long)OOB), 0x00020000);
     const int hw = p.OH * p.OW;
+    const bool ld3 = p.in_ld == 3;                         // (uniform)
     const float rcp_hw = 1.0f / (float)hw, rcp_ow = 1.0f / (float)p.OW;
     // k 196 .. 223 of every row: zeros, once (the taps never write there; the filters are zero there, but 0 x garbage may be NaN)
     if (tq == 0) {
@@ -943,7 +944,13 @@ __global__ __launch_bounds__(256, 2) void stem7x7_f16_kernel(const ConvParams p)
             const int iy = 2 * oy - 3 + ky, ix = 2 * ox - 3 + kx;
             const bool ok = (t < 49) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
             const unsigned off = (unsigned)((base + ky * p.W + kx) * p.in_ld * 4);
-            x[i] = buf_load4(rsrcA, ok ? off : OOB, 0);
+            if (ld3) {      // three floats per pixel (the engine's crop tensor): a 12-B load, nothing read past the last pixel
+                typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+                const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rsrcA, (int)(ok ? off : OOB), 0, 0);
+                x[i] = f32x4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), 0.f};     // (not __builtin_bit_cast(float, v.y): this hipcc reads element 0 for every swizzle there)
+            } else {
+                x[i] = buf_load4(rsrcA, ok ? off : OOB, 0);
+            }
         }
     };
     const int groups = (p.M + GP - 1) / GP, G = (groups + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -1013,7 +1020,7 @@ __global__ __launch_bounds__(256, 2) void stem7x7_f16_kernel(const ConvParams p)
 }
 
 bool conv_stem7_eligible(const ConvParams& p) {
-    return p.cin_pack == 4 && p.Cin <= 4 && p.in_ld == 4 && p.ksize == 7 && p.stride == 2 && p.pad == 3 && p.Cout == 64 && p.CoutPad == 64 &&
+    return p.cin_pack == 4 && p.Cin <= 4 && (p.in_ld == 4 || (p.in_ld == 3 && p.Cin == 3)) && p.ksize == 7 && p.stride == 2 && p.pad == 3 && p.Cout == 64 && p.CoutPad == 64 &&
            p.Kpad == 224 && p.store_mode == ST_NHWC && p.res == nullptr && p.res_scale == nullptr && p.pool_out == nullptr && (p.out_ld & 7) == 0 &&
            (p.out16 == nullptr || p.out_np == 1) && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.out16) & 15) == 0 &&
            (long long)p.M * p.out_ld * 4 < (long long)OOB && (long long)p.N * p.H * p.W * 16 < (long long)OOB && p.M < (1 << 24);

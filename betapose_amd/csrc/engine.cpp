@@ -1757,6 +1757,9 @@ void KpdNet::forward(const float* d_inps, bool nhwc_input, int batch, float* d_h
     } else {
         launch_nchw_to_nhwc(d_inps, in_nhwc_, batch, 3, inH_, inW_, s);
     }
+    // the head writes straight into the caller's tensor -- for THIS pass only: a pointer left bound would be written by the next profile() /
+    // tap pass at whatever batch size that one runs (round 6: profile(28) behind a one-crop forward wrote 28 maps into a one-map tensor)
+    struct Rebind { float*& slot; float* own; ~Rebind() { slot = own; } } rebind{ops_[hm_op_].conv.out, hm_};
     ops_[hm_op_].conv.out = d_hm ? d_hm : hm_;
     run_ops(batch, s);
     if (d_kp) launch_heatmap_argmax(d_hm ? d_hm : hm_, batch, outC_, out_h(), out_w(), d_kp, s, kp_ld);

@@ -526,15 +526,17 @@ def test_conv_stem3_direct(cuda, shape):
     _check(out.cpu().permute(0, 3, 1, 2), mfma.cpu().permute(0, 3, 1, 2))
 
 
+@pytest.mark.parametrize("cin", [3, 4])
 @pytest.mark.parametrize("shape", [(2, 320, 256, "relu"), (3, 46, 38, "leaky"), (1, 14, 10, "linear"), (28, 64, 48, "relu")])
-def test_conv_stem7_f16(cuda, shape):
+def test_conv_stem7_f16(cuda, shape, cin):
     """The key-point detector's 7x7 / stride-2 / pad-3 RGB stem on the fp16 matrix pipe (TILE_STEM7, what the engine plans for it in the fp16
     modes): fp16 operands, fp32 accumulation -- against torch and against the fp32 MFMA kernel on the same fp16-rounded operands at the
-    accumulation-order bar; bit-reproducible; odd output sizes, an M tail, 8 groups per block."""
+    accumulation-order bar; bit-reproducible; odd output sizes, an M tail, 8 groups per block.  cin = 3 is the ENGINE's layout (the crop
+    kernel writes three floats per pixel: 12-byte tap loads, the last pixel of the tensor included), cin = 4 a padded one."""
     N, H, W, act = shape
     g = torch.Generator().manual_seed(7700 + H)
-    x = torch.randn(N, H, W, 4, generator=g).half().float()
-    w = (torch.randn(64, 4, 7, 7, generator=g) / 14).half().float()
+    x = torch.randn(N, H, W, cin, generator=g).half().float()
+    w = (torch.randn(64, cin, 7, 7, generator=g) / 14).half().float()
     b = torch.randn(64, generator=g)
     ref = _ref(x, w, b, 2, 3, act, None, False)
     out = ops.conv2d_nhwc(x.to(cuda), w, b, stride=2, pad=3, act=act, tile="stem7")

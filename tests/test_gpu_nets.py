@@ -492,6 +492,15 @@ def test_f16_mode_kpd_batch28(cuda, pipe_gold):
     assert np.array_equal(a32[:4].numpy(), gold)
     assert int((a16[:4].numpy() != gold).sum()) <= 4                     # <= 2 % of the 200 golden key points
     _f16_heatmaps_vs_oracle(hm16, inps, (0, 27), "f16 batch 28", 2)
+    # ... and the plan that produced them is the round-6 one: the 7x7 RGB stem on the fp16 matrix pipe (tile 28; the engine's crop tensor has
+    # three floats per pixel), the 3x3 / stride-1 and the long-K 1x1 layers on the persistent kernel (tile 27)
+    _, info = kpd16.profile(28, 1)
+    stem = [i for i, (n, _) in enumerate(kpd16.op_names()) if n.startswith("stem k7")][0]
+    assert int(info[stem, 1]) == 28, info[stem]
+    assert int((info[:, 1] == 27).sum()) >= 40, int((info[:, 1] == 27).sum())
+    kpd16.set_precision("bf16x3")
+    _, info = kpd16.profile(28, 1)
+    assert int(info[stem, 1]) not in (27, 28) and int((info[:, 1] == 27).sum()) == 0     # fp16 kernels stay in the fp16 modes
 
 
 # ---- bf16x3 mode: fp32 operands split exactly into three bf16 terms, six partial products on the bf16 MFMA, fp32
@@ -518,8 +527,11 @@ def test_bf16x3_mode_meets_the_fp32_parity_bar(cuda, pipe_gold):
         assert np.array_equal(hm.view(50, -1).argmax(1).numpy(), pipe_gold["f%d_kp_idx" % i])
 
 
-def test_bf16x3_on_the_operand_plane_path_meets_the_fp32_parity_bar(cuda):
-    """The plane path (conv_pl.hip: producers write three bf16 planes, both operands by LDS-DMA) is the fp16 mode's planned
+@pytest.mark.parametrize("switch", ["BP_B3_PLANES=1", "BP_B3_MIX=320"])
+def test_bf16x3_on_the_operand_plane_path_meets_the_fp32_parity_bar(cuda, switch):
+    """(``BP_B3_MIX=320``: the per-layer form of the switch -- only the 3x3 / stride-1 layers with maps up to 320 pixels read planes; measured
+    slower, off by default, profiles/r06_ab_b3_mix.txt.)
+    The plane path (conv_pl.hip: producers write three bf16 planes, both operands by LDS-DMA) is the fp16 mode's planned
     path; ``BP_B3_PLANES=1`` puts the bf16x3 mode on it too (slower there).  It is the same arithmetic -- an
     exact 3-way split, six products, fp32 accumulation -- so it is held to the same bars as the default path: YOLO arg-max
     index and KPD arg-max pixels of the golden frames, rows and heat-maps within the fp32 tolerances.  Own process: the
@@ -554,10 +566,15 @@ for i in range(2):
     hm = kpd(crop.cuda()).cpu()
     assert float((hm - kpd_ref.fastpose_forward(sd, crop)).abs().max()) <= 2e-4
     assert np.array_equal(hm.view(50, -1).argmax(1).numpy(), gold["f%d_kp_idx" % i])
+import os
 ms, info = net.profile(1, 1)
-assert (info[:, 1] == 13).sum() > 60, "the plane kernels did not run"
+if os.environ.get("BP_B3_MIX"):
+    ms, infok = kpd.profile(1, 1)
+    assert 5 <= (info[:, 1] == 13).sum() < 30 and (infok[:, 1] == 13).sum() >= 22, "the small 3x3 layers did not run on the plane kernels"
+else:
+    assert (info[:, 1] == 13).sum() > 60, "the plane kernels did not run"
 print("PLANE-PATH-OK")
 '''
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT,
-                       env=dict(os.environ, BP_B3_PLANES="1"))
+                       env=dict(os.environ, **dict([switch.split("=")])))
     assert r.returncode == 0 and "PLANE-PATH-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
