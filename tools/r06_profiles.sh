@@ -25,6 +25,7 @@ python tools/bench_p1.py 28 > $OUT/r06_bench_p1.txt 2>/dev/null
 python tools/bench_stem7.py > $OUT/r06_bench_stem7.txt 2>/dev/null
 tools/energy_configs2.sh > $OUT/r06_energy_configs2.txt 2>&1
 tools/energy_modes.sh > $OUT/r06_energy_modes.txt 2>&1
+tools/ab_stem7.sh > $OUT/r06_ab_stem7.txt 2>&1
 python bench.py --no-cpu-baseline --no-served-legs --no-flip-rate --other-modes= --steps 200 --warmup 20 --insitu $OUT/r06_insitu_layer_times.txt > $OUT/r06_bench_insitu.json 2>/dev/null
 rm -rf $OUT/trace_headline $OUT/trace_b28 $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmcf_* $OUT/pmc_stalls $OUT/pmc_mfma* $OUT/pmc_busy* 2>/dev/null
 ls $OUT | grep r06
