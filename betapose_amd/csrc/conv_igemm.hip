@@ -923,7 +923,6 @@ __global__ __launch_bounds__(256, 2) void stem7x7_f16_kernel(const ConvParams p)
     const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(p.in), 0, (int)min((long long)p.N * p.H * p.W * p.in_ld * 4, (long long)OOB), 0x00020000);
     const int hw = p.OH * p.OW;
-    const bool ld3 = p.in_ld == 3;                         // (uniform)
     const float rcp_hw = 1.0f / (float)hw, rcp_ow = 1.0f / (float)p.OW;
     // k 196 .. 223 of every row: zeros, once (the taps never write there; the filters are zero there, but 0 x garbage may be NaN)
     if (tq == 0) {
@@ -944,13 +943,10 @@ __global__ __launch_bounds__(256, 2) void stem7x7_f16_kernel(const ConvParams p)
             const int iy = 2 * oy - 3 + ky, ix = 2 * ox - 3 + kx;
             const bool ok = (t < 49) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
             const unsigned off = (unsigned)((base + ky * p.W + kx) * p.in_ld * 4);
-            if (ld3) {      // three floats per pixel (the engine's crop tensor): a 12-B load, nothing read past the last pixel
-                typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
-                const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(rsrcA, (int)(ok ? off : OOB), 0, 0);
-                x[i] = f32x4{__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), 0.f};     // (not __builtin_bit_cast(float, v.y): this hipcc reads element 0 for every swizzle there)
-            } else {
-                x[i] = buf_load4(rsrcA, ok ? off : OOB, 0);
-            }
+            // one 16-B load per tap also where a pixel is three floats (the engine's crop tensor: 12-B strides, dword-aligned -- 88 us against
+            // 144 us with 12-B loads at 28 frames); the fourth dword is the neighbour's red and is dropped below; behind the LAST pixel of the
+            // tensor it is out of the descriptor's range, which a raw buffer load checks per dword: it reads as zero, nothing is touched
+            x[i] = buf_load4(rsrcA, ok ? off : OOB, 0);
         }
     };
     const int groups = (p.M + GP - 1) / GP, G = (groups + (int)gridDim.x - 1) / (int)gridDim.x;
