@@ -503,6 +503,22 @@ def test_f16_mode_kpd_batch28(cuda, pipe_gold):
     assert int(info[stem, 1]) not in (27, 28) and int((info[:, 1] == 27).sum()) == 0     # fp16 kernels stay in the fp16 modes
 
 
+def test_profile_behind_a_smaller_forward_leaves_the_callers_tensor_alone(cuda):
+    """KpdNet::forward lets the head convolution write straight into the caller's heat-map tensor -- for that pass only (round 6: the pointer
+    stayed bound, and profile(28) behind a one-crop forward wrote 28 maps through it: a memory fault, or silently the neighbours of a
+    one-map tensor).  The per-op timing pass must run on the engine's own buffers."""
+    kpd4 = FastPoseHIP(helpers.kpd_state_dict(), n_classes=50, max_batch=4).cuda().eval()
+    x = (torch.rand(4, 3, 320, 256, generator=torch.Generator().manual_seed(5)) - 0.45).to(cuda)
+    kpd4(x)
+    out = kpd4(x[:1])                                             # the LAST forward is the one-crop one
+    guard = torch.full((3, 50, 80, 64), 7.0, device=cuda)        # (allocated right behind `out`: where three more maps would land)
+    keep = out.clone()
+    ms, info = kpd4.profile(4, 1)
+    torch.cuda.synchronize()
+    assert torch.equal(out, keep) and bool((guard == 7.0).all())
+    assert len(ms) == len(info) and float(ms.sum()) > 0
+
+
 # ---- bf16x3 mode: fp32 operands split exactly into three bf16 terms, six partial products on the bf16 MFMA, fp32
 # accumulation.  It is an fp32-accurate mode, so it is held to the SAME tolerances and integer-exactness as the fp32-MFMA
 # path against the oracle and the reference's golden vectors.
