@@ -4,7 +4,7 @@
 # occupancy (verdict item 4); PMC traffic per launch of the dominant kernel and per frame at batch 1; in-situ layer table; per-op tables.
 REPO="$(cd "$(dirname "$0")/.." && pwd)"; OUT=$REPO/gpurun_out; cd $REPO
 tools/trace_headline.sh r06 > $OUT/r06_trace_summary_stdout.txt 2>&1
-for P in f16 f16r; do tools/trace_batch28.sh $P r06 > /dev/null 2>&1; done
+for P in f16 f16r bf16x3; do tools/trace_batch28.sh $P r06 > /dev/null 2>&1; done
 tools/pmc_frame_traffic.sh 1 --batch 28 --precision f16 --steps 6 --warmup 2 > $OUT/r06_pmc_frame_traffic_batch28_f16.json 2>/dev/null
 tools/pmc_frame_traffic.sh 1 --batch 28 --precision f16r --steps 6 --warmup 2 > $OUT/r06_pmc_frame_traffic_batch28_f16r.json 2>/dev/null
 tools/pmc_mfma_busy.sh --precision f16r --batch 28 --steps 3 --warmup 1 > /dev/null 2>&1 && cp $OUT/pmc_mfma_busy.json $OUT/r06_pmc_mfma_busy_batch28_f16r.json
