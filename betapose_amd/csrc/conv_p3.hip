@@ -48,7 +48,10 @@ struct P3Args {
     int skew;     // start skew: block j of its XCD sleeps (j % 8) x skew x 64 cycles before its first request (0: none)
 };
 
-static constexpr int P3_BM = 128, P3_BN = 128, P3_PITCH = 80;
+#ifndef P3_ROWX_B
+#define P3_ROWX_B 96      // (-DP3_ROWX_B=0: the 3x3 form's halo without the per-row skew, A/B builds of tools/p3_variants.sh)
+#endif
+static constexpr int P3_BM = 128, P3_BN = 128, P3_PITCH = 80, P3_ROWX = P3_ROWX_B;
 static constexpr int P3_SOOB = 0x40000000;      // a scalar offset beyond every descriptor (adding a few KB to it does not wrap)
 
 // KSZ: 3 (3x3 / stride 1 / pad 1) or 1 (1x1 / stride 1: the "halo" of a 128-channel group is the tile's own 128 pixels, the "taps" are its four
@@ -62,7 +65,12 @@ __global__ __launch_bounds__(256, BPC) void conv_p3_kernel(const ConvParams p, c
     constexpr int TAPS = K3 ? 9 : 4;                      // 32-k chunks per group
     constexpr int GR = K3 ? 4 : 16;                       // 16-B granules of a halo row (32 / 128 channels)
     constexpr int PITCH = K3 ? P3_PITCH : 272;            // row bytes + 16: conflict-free for any 16 rows of a ds_read_b128 lane group
-    constexpr int STAGE = HRT * PITCH;
+    // 3x3 form: a halo position's LDS address is position x 80 B + grid row x 96 B.  Consecutive positions are 5 bank groups (of 16 B) apart, so
+    // any 16 positions that differ mod 16 -- a ds_read_b128 lane group's, whatever the lanes -- cover the 64 banks once; the two pad columns a
+    // row change skips would break that (+ 10 groups), the 96 B per row restore it (+ 16: round 6, PMC: SQ_LDS_BANK_CONFLICT was half of the
+    // LDS-array cycles at W = 13 / 16 / 26, profiles/r06_pmc_p3.txt)
+    constexpr int ROWX = K3 ? P3_ROWX : 0;
+    constexpr int STAGE = HRT * PITCH + (K3 ? (HRT / WP + 2) * ROWX : 0);
     constexpr int RPP = 256 / GR;                         // halo rows per loader pass (256 threads x 16 B)
     constexpr int NPASS = (HRT + RPP - 1) / RPP;
     constexpr int LASTSTEP = 2 * TAPS - 1;
@@ -105,17 +113,19 @@ __global__ __launch_bounds__(256, BPC) void conv_p3_kernel(const ConvParams p, c
     // ---- per tile: the loader's source offsets (3x3: halo row j <-> position q0 + j, q0 = the centre of the tile's first pixel - (W + 2) - 1;
     // 1x1: halo row j = pixel m0 + j), the lane's four fragment rows, the wave's filter base
     const int lrow = tid / GR, lgr = tid % GR;
-    auto tile_setup = [&](int t, bool live, int& m0, int& n0, unsigned (&avo)[NPASS], unsigned (&bse)[4], int& bsrc) __attribute__((always_inline)) {
+    auto tile_setup = [&](int t, bool live, int& m0, int& n0, unsigned (&avo)[NPASS], unsigned (&awo)[NPASS], unsigned (&bse)[4], int& bsrc) __attribute__((always_inline)) {
         const int tm = t / a.NTN, tn = t - tm * a.NTN;
         m0 = tm * P3_BM;
         n0 = tn * P3_BN;
         if constexpr (K3) {
             const int q0 = cpos(min(m0, p.M - 1)) - WP - 1;
+            const int R0 = q0 / WP;
 #pragma unroll
             for (int k = 0; k < NPASS; ++k) {
                 const int j = lrow + RPP * k, q = q0 + j;
                 const int qq = max(q, 0);
                 const int R = qq / WP, col = qq - R * WP;
+                awo[k] = (unsigned)(j * PITCH + (R - R0) * ROWX + lgr * 16);
                 const int b = fast_div(R, H1, rcp_h1), rr = R - b * H1;
                 const bool ok = live & (q >= 0) & (j < HRT) & (col >= 1) & (col <= W) & (rr >= 1) & (b < p.N);
                 const unsigned so = (unsigned)((((b * H + rr - 1) * W + col - 1) * p.in_ld + lgr * 8) * 2);
@@ -125,7 +135,8 @@ __global__ __launch_bounds__(256, BPC) void conv_p3_kernel(const ConvParams p, c
             for (int e = 0; e < 4; ++e) {
                 const int m = min(m0 + 32 * e + (lane & 31), p.M - 1);
                 // tap (ky, kx) of pixel m reads position cpos(m) + (ky - 1)(W + 2) + (kx - 1) = halo row (cpos(m) - (W + 2) - 1 - q0) + ky (W + 2) + kx
-                bse[e] = (unsigned)((cpos(m) - WP - 1 - q0) * PITCH + (lane >> 5) * 16);
+                const int P = cpos(m) - WP - 1;
+                bse[e] = (unsigned)((P - q0) * PITCH + (P / WP - R0) * ROWX + (lane >> 5) * 16);
             }
         } else {
 #pragma unroll
@@ -141,7 +152,6 @@ __global__ __launch_bounds__(256, BPC) void conv_p3_kernel(const ConvParams p, c
         const int col0 = n0 + 32 * wave;
         bsrc = live ? ((col0 >> 6) * p.nchunks) * 4096 + ((col0 >> 5) & 1) * 2048 : P3_SOOB;
     };
-    const unsigned a_woff = (unsigned)(lrow * PITCH + lgr * 16);
 
     // filter fragment geometry (conv_pl.hip's packed image, [CoutPad / 64][chunk][64 rows][64 B], granule g of row r at slot g ^ ((r >> 2) & 3)):
     // lane -> row (lane & 31) of the wave's 32, logical granule 2 ks + (lane >> 5)
@@ -158,6 +168,8 @@ __global__ __launch_bounds__(256, BPC) void conv_p3_kernel(const ConvParams p, c
     auto load_b_loop = [&](auto slotc, int so) __attribute__((always_inline)) {
         if constexpr (!(P3_ABL & 1)) load_b(slotc, so);
     };
+    const unsigned a_woff = (unsigned)(lrow * PITCH + lgr * 16);
+    unsigned awo[NPASS];             // 3x3 form: LDS offsets of the thread's halo rows (tile_setup)
     u32x4 ra[NPASS];                 // a group's halo on its way to LDS
     auto load_a = [&](const unsigned (&avo)[NPASS], int so) __attribute__((always_inline)) {
 #pragma unroll
@@ -165,12 +177,14 @@ __global__ __launch_bounds__(256, BPC) void conv_p3_kernel(const ConvParams p, c
     };
     auto park_a = [&](auto kc, unsigned so) __attribute__((always_inline)) {
         constexpr int k = decltype(kc)::value;
-        if (k < NPASS - 1 || lrow + RPP * k < HRT) *reinterpret_cast<u32x4*>(lds + so + a_woff + k * (RPP * PITCH)) = ra[k];
+        // (3x3 form: the row's LDS offset carries its grid row's 96 B, rebuilt per tile; 1x1 form: rows are the tile's pixels, a fixed stride)
+        const unsigned wo = K3 ? awo[k] : a_woff + k * (RPP * PITCH);
+        if (k < NPASS - 1 || lrow + RPP * k < HRT) *reinterpret_cast<u32x4*>(lds + so + wo) = ra[k];
     };
 
     int m0, n0, bsrc, m0n = 0, n0n = 0, bsrcn = P3_SOOB;
     unsigned avo[NPASS], bse[4], bsen[4];
-    tile_setup(tile, true, m0, n0, avo, bse, bsrc);
+    tile_setup(tile, true, m0, n0, avo, awo, bse, bsrc);
     // the first two taps' filters, the first group's halo
     load_b(std::integral_constant<int, 0>{}, bsrc);
     load_b(std::integral_constant<int, 1>{}, bsrc + 4096);
@@ -180,7 +194,7 @@ __global__ __launch_bounds__(256, BPC) void conv_p3_kernel(const ConvParams p, c
     f16x8 fr[2][4];                  // activation fragments: [step parity][pixel sub-tile]
     auto read_frags = [&](auto parc, auto tapc, auto ksc, unsigned so, const unsigned (&b4)[4]) __attribute__((always_inline)) {
         constexpr int par = decltype(parc)::value, tap = decltype(tapc)::value, ks = decltype(ksc)::value;
-        constexpr int imm = K3 ? ((tap / 3) * WP + (tap % 3)) * PITCH + ks * 32 : tap * 64 + ks * 32;
+        constexpr int imm = K3 ? ((tap / 3) * WP + (tap % 3)) * PITCH + (tap / 3) * ROWX + ks * 32 : tap * 64 + ks * 32;
 #pragma unroll
         for (int e = 0; e < 4; ++e) fr[par][e] = *reinterpret_cast<const f16x8*>(lds + so + b4[e] + imm);
     };
@@ -227,7 +241,7 @@ __global__ __launch_bounds__(256, BPC) void conv_p3_kernel(const ConvParams p, c
         constexpr bool LAST = POS == 2;
         if constexpr (K3 ? LAST : (POS == 1)) {
             // the next tile's geometry: this tile's halos have all been requested, so the loader offsets are rebuilt in place
-            tile_setup(has_next ? next : tile, has_next, m0n, n0n, avo, bsen, bsrcn);
+            tile_setup(has_next ? next : tile, has_next, m0n, n0n, avo, awo, bsen, bsrcn);
         }
         const int bs_cur = bsrc + g * (TAPS * 4096);
         const int bs_nxt = LAST ? bsrcn : bs_cur + TAPS * 4096;
@@ -466,7 +480,7 @@ void launch_conv_p3(const ConvParams& p, hipStream_t s) {
     a.NTN = (p.CoutPad + P3_BN - 1) / P3_BN;
     a.T = ((p.M + P3_BM - 1) / P3_BM) * a.NTN;
     a.G = k3 ? p.Cin / 32 : p.Cin / 128;
-    const int lds_bytes = 2 * (k3 ? p3_hrt(p.W) * P3_PITCH : 128 * 272) + a.NTN * P3_BN * 4;     // two halo stages + the bias (a whole number of N tiles)
+    const int lds_bytes = 2 * (k3 ? p3_hrt(p.W) * P3_PITCH + (p3_hrt(p.W) / (p.W + 2) + 2) * P3_ROWX : 128 * 272) + a.NTN * P3_BN * 4;     // two halo stages + the bias (a whole number of N tiles)
     // (Also built and removed in round 6: the 3x3 / STRIDE-2 layers on the same position grid over the input map (centres at (2 oy, 2 ox), taps still
     // immediates, two-way bank conflicts, 736 / 960 halo rows = one block per CU, 12-15 loader passes): 104x104 -> 52x52 63.0 against 67.1 us on the
     // 128x128 plane tile, 52x52 -> 26x26 66.2 against 70.3, 26x26 -> 13x13 83.1 against 70.1 -- one lone-wave block per CU is no better than the tile
