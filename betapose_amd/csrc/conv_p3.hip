@@ -489,6 +489,10 @@ void launch_conv_p3(const ConvParams& p, hipStream_t s) {
     // one tile per CU -- 20x16 256 -> 256: 140 tiles, 19.2 -> 18.7 us; 1 024 -> 256: 12.2 -> 12.2.  A lone wave already drives 74 % of its SIMD's
     // matrix pipe inside the K loop, so a second wave on the same SIMD can add a quarter at most, and the LDS hand-over takes it back; what these
     // launches lack is the other 116 CUs, i.e. a cross-CU reduction, which costs more than it saves: profiles/r06_plh_splits.txt.)
+    // (Built, bit-identical, and removed in round 6: 64-PIXEL tiles (two 32-pixel sub-tiles per wave) for launches whose 128-pixel tiles leave CUs without
+    // a block -- the key-point detector's 20x16 maps at 28 frames are 140 tiles for 256 CUs.  280 tiles of half the work each were SLOWER one
+    // launch at a time: 3x3 256 -> 256 19.3 -> 26.3 us, 1x1 1 024 -> 256 12.4 -> 14.5, 13x13 1 024 -> 512 12.5 -> 14.6 -- a filter fragment then
+    // feeds two MFMAs instead of four and the ring's two taps of prefetch are half as long in time, so the waves wait on L2 where they did not.)
     // blocks per CU: two.  Three (<= 168 registers: the skip connection requested inside the epilogue, a few spills there) tie one launch at a
     // time and LOSE 3 % with three streams in flight (5 550 against 5 380 frames/s, configs[2] f16r on one box): these layers run AT the socket
     // power cap (profiles/r06_p3_clock_probe.txt), a third resident block adds register-file and LDS traffic, not matrix work.
